@@ -1,0 +1,188 @@
+"""ctypes front-end of oracle/carma_oracle.c (CPU oracle, test infrastructure only).
+
+The C file restates the reference's algorithm (file:line citations are in the C source);
+this module only marshals numpy arrays.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcarma_oracle.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    """Compile libcarma_oracle.so with gcc (no-op when up to date)."""
+    src = os.path.join(_HERE, "carma_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libcarma_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_model_create.restype = C.c_void_p
+        L.orc_model_create.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.orc_model_destroy.argtypes = [C.c_void_p]
+        L.orc_model_n.argtypes = [C.c_void_p]
+        L.orc_model_n.restype = C.c_int
+        L.orc_model_get_data.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_model_get_prior.argtypes = [C.c_void_p, _dp]
+        L.orc_log_prior.argtypes = [C.c_void_p, _dp]
+        L.orc_log_prior.restype = C.c_double
+        L.orc_check_prior_bounds_carma.argtypes = [C.c_void_p, _dp, C.c_int]
+        L.orc_check_prior_bounds_carma.restype = C.c_int
+        L.orc_check_prior_bounds_car1.argtypes = [C.c_void_p, _dp]
+        L.orc_check_prior_bounds_car1.restype = C.c_int
+        L.orc_logdensity_carma.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.orc_logdensity_carma.restype = C.c_double
+        L.orc_logdensity_car1.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_logdensity_car1.restype = C.c_double
+        L.orc_logdensity_batch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, _dp]
+        L.orc_kfilter_carma.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, _dp, _dp, _dp,
+                                        _dp, _dp]
+        L.orc_kfilter_carma.restype = C.c_int
+        L.orc_kfilter_car1.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp]
+        L.orc_ar_roots.argtypes = [_dp, C.c_int, _dp, _dp]
+        L.orc_ma_coefs.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        L.orc_variance.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double]
+        L.orc_variance.restype = C.c_double
+        L.orc_sort_dedup.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.orc_sort_dedup.restype = C.c_int
+        L.orc_chol_update_r1.argtypes = [C.c_int, _dp, _dp, C.c_int]
+        L.orc_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _a(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def _p(x):
+    return x.ctypes.data_as(_dp)
+
+
+def max_threads():
+    return lib().orc_max_threads()
+
+
+def ar_roots(theta, p):
+    theta = _a(theta)
+    re, im = np.empty(p), np.empty(p)
+    lib().orc_ar_roots(_p(theta), p, _p(re), _p(im))
+    return re + 1j * im
+
+
+def ma_coefs(theta, p, q):
+    theta = _a(theta)
+    ma = np.empty(p)
+    lib().orc_ma_coefs(_p(theta), p, q, _p(ma))
+    return ma
+
+
+def variance(roots, ma, sigma=1.0, dt=0.0):
+    roots = np.asarray(roots, dtype=complex)
+    p = roots.size
+    re, im = _a(roots.real), _a(roots.imag)
+    mav = np.zeros(p)
+    mav[: len(ma)] = ma
+    return lib().orc_variance(p, _p(re), _p(im), _p(mav), float(sigma), float(dt))
+
+
+def sort_dedup(t, y, yerr):
+    t, y, yerr = _a(t).copy(), _a(y).copy(), _a(yerr).copy()
+    n = lib().orc_sort_dedup(t.size, _p(t), _p(y), _p(yerr))
+    return t[:n], y[:n], yerr[:n]
+
+
+def kfilter_carma(t, y, yerr, sigsqr, roots, ma):
+    """Kalman mean/var for centred y and (already scaled) yerr."""
+    t, y, yerr = _a(t), _a(y), _a(yerr)
+    roots = np.asarray(roots, dtype=complex)
+    p = roots.size
+    re, im = _a(roots.real), _a(roots.imag)
+    mav = np.zeros(p)
+    mav[: len(ma)] = ma
+    mean, var = np.empty(t.size), np.empty(t.size)
+    rc = lib().orc_kfilter_carma(t.size, _p(t), _p(y), _p(yerr), p, float(sigsqr), _p(re), _p(im),
+                                 _p(mav), _p(mean), _p(var))
+    if rc != 0:
+        raise RuntimeError("singular EigenMat solve")
+    return mean, var
+
+
+def kfilter_car1(t, y, yerr, sigsqr, omega):
+    t, y, yerr = _a(t), _a(y), _a(yerr)
+    mean, var = np.empty(t.size), np.empty(t.size)
+    lib().orc_kfilter_car1(t.size, _p(t), _p(y), _p(yerr), float(sigsqr), float(omega), _p(mean), _p(var))
+    return mean, var
+
+
+def chol_update_r1(L, v, downdate):
+    L = _a(L).copy()
+    v = _a(v).copy()
+    lib().orc_chol_update_r1(L.shape[0], _p(L), _p(v), int(bool(downdate)))
+    return L, v
+
+
+class OracleModel:
+    """CARMA_Base-like object: data + prior bounds + LogDensity (p==1 -> CAR1)."""
+
+    def __init__(self, t, y, yerr, p, q=0, max_stdev=None):
+        t, y, yerr = _a(t), _a(y), _a(yerr)
+        if max_stdev is None:
+            # RunCarmaSampler's population variance (src/carmcmc.cpp:85-89)
+            max_stdev = 10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)
+        self.p, self.q = int(p), int(q)
+        self.d = 4 if self.p == 1 else 3 + self.p + self.q
+        self._h = C.c_void_p(lib().orc_model_create(_p(t), _p(y), _p(yerr), t.size, self.p, self.q,
+                                                    float(max_stdev)))
+        self.n = lib().orc_model_n(self._h)
+        pr = np.empty(3)
+        lib().orc_model_get_prior(self._h, _p(pr))
+        self.max_stdev, self.max_freq, self.min_freq = pr
+
+    def __del__(self):
+        try:
+            lib().orc_model_destroy(self._h)
+        except Exception:
+            pass
+
+    def data(self):
+        t, y, e = np.empty(self.n), np.empty(self.n), np.empty(self.n)
+        lib().orc_model_get_data(self._h, _p(t), _p(y), _p(e))
+        return t, y, e
+
+    def log_prior(self, theta):
+        theta = _a(theta)
+        return lib().orc_log_prior(self._h, _p(theta))
+
+    def check_prior_bounds(self, theta, ignore_prior=False):
+        theta = _a(theta)
+        if self.p == 1:
+            return bool(lib().orc_check_prior_bounds_car1(self._h, _p(theta)))
+        return bool(lib().orc_check_prior_bounds_carma(self._h, _p(theta), int(ignore_prior)))
+
+    def logdensity(self, theta, ignore_prior=False):
+        theta = _a(theta)
+        assert theta.size == self.d
+        if self.p == 1:
+            return lib().orc_logdensity_car1(self._h, _p(theta), None)
+        return lib().orc_logdensity_carma(self._h, _p(theta), int(ignore_prior), None)
+
+    def logdensity_batch(self, thetas, ignore_prior=False, nthreads=1):
+        thetas = _a(thetas).reshape(-1, self.d)
+        out = np.empty(thetas.shape[0])
+        lib().orc_logdensity_batch(self._h, _p(thetas), thetas.shape[0], int(ignore_prior), int(nthreads),
+                                   _p(out))
+        return out

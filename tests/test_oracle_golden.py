@@ -1,0 +1,202 @@
+"""Pins the CPU oracle (oracle/carma_oracle.c) against the golden vectors generated from the
+reference's own Python (tests/golden/make_golden.py) and against the reference's known answers.
+No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+RTOL_LL = 1e-12   # SURVEY §7 stage 1 bar for the restatement
+RTOL_ILL = 1e-11  # cases with cond(E) > 1e5
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _check_case(t, y, yerr, th, p, q, g_omega, g_ma, g_sig, g_mean, g_var, g_ll, cond):
+    """Restatement vs reference Python (scipy/LAPACK LU): the two LU's differ at rounding level, so
+    per-element bars are loose where the Vandermonde system is ill-conditioned; the log-likelihood
+    bar is the tight one (1e-11 always, 1e-12 on well-conditioned cases)."""
+    om = orc.ar_roots(th, p)
+    ma = orc.ma_coefs(th, p, q)
+    np.testing.assert_allclose(om, g_omega, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(ma, g_ma, rtol=1e-12, atol=1e-15)
+    sig = th[0] ** 2 / orc.variance(om, ma)
+    assert abs(sig - g_sig) <= 1e-11 * abs(g_sig)
+    mean, var = orc.kfilter_carma(t, y - th[2], np.sqrt(th[1]) * yerr, sig, om, ma)
+    np.testing.assert_allclose(var, g_var, rtol=1e-8)
+    np.testing.assert_allclose(mean, g_mean, rtol=0, atol=1e-10 * np.abs(y - th[2]).max())
+    m = orc.OracleModel(t, y, yerr, p, q)
+    ll = m.logdensity(th, ignore_prior=True) - m.log_prior(th)
+    tol = RTOL_ILL if cond > 1e3 else RTOL_LL
+    assert abs(ll - g_ll) <= tol * abs(g_ll)
+    return abs(ll - g_ll) / abs(g_ll)
+
+
+def test_readme_carma53_matches_reference_python(golden_dir):
+    g = _load(golden_dir, "carma53_readme.npz")
+    t, y, yerr, p, q = g["t"], g["y"], g["yerr"], int(g["p"]), int(g["q"])
+    assert t.size == 270 and (p, q) == (5, 3)
+    for i in range(g["theta"].shape[0]):
+        _check_case(t, y, yerr, g["theta"][i], p, q, g["omega"][i], g["ma"][i], g["sigsqr"][i],
+                    g["mean"][i], g["var"][i], g["loglik"][i], g["cond"][i])
+
+
+def test_readme_dense_gp_identity(golden_dir):
+    """carma_unit_tests.cpp:564-594: Kalman log-lik == dense GP log-lik."""
+    g = _load(golden_dir, "carma53_readme.npz")
+    m = orc.OracleModel(g["t"], g["y"], g["yerr"], 5, 3)
+    idx = np.flatnonzero(np.isfinite(g["dense_loglik"]))
+    assert idx.size >= 4
+    for i in idx:
+        th = g["theta"][i]
+        ll = m.logdensity(th, ignore_prior=True) - m.log_prior(th)
+        assert abs(ll - g["dense_loglik"][i]) <= 1e-9 * abs(ll)
+
+
+def test_readme_true_model_filter(golden_dir):
+    g = _load(golden_dir, "carma53_readme.npz")
+    mean, var = orc.kfilter_carma(g["t"], g["y"] - 17.0, g["yerr"], float(g["true_sigsqr"]), g["true_omega"],
+                                  g["true_ma"])
+    np.testing.assert_allclose(var, g["true_var"], rtol=1e-12)
+    np.testing.assert_allclose(mean, g["true_mean"], rtol=0, atol=1e-12)
+    # var(0) identity (carma_unit_tests.cpp:443-444): var0 = sigma_y^2 + yerr0^2, sigma_y = 2.3
+    assert abs(var[0] - (2.3 ** 2 + g["yerr"][0] ** 2)) < 1e-10
+
+
+def test_car1_matches_dense_gp(golden_dir):
+    g = _load(golden_dir, "car1_n100.npz")
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    m = orc.OracleModel(t, y, yerr, 1)
+    for i in range(g["theta"].shape[0]):
+        th = g["theta"][i]
+        omega = np.exp(th[3])
+        mean, var = orc.kfilter_car1(t, y - th[2], np.sqrt(th[1]) * yerr, 2 * th[0] ** 2 * omega, omega)
+        np.testing.assert_allclose(var, g["var"][i], rtol=1e-9)
+        np.testing.assert_allclose(mean, g["mean"][i], rtol=0, atol=1e-9)
+        # var(0) identity (carma_unit_tests.cpp:215-216)
+        assert abs(var[0] - (th[0] ** 2 + th[1] * yerr[0] ** 2)) < 1e-10
+        # logdensity - prior == dense GP loglik; the CAR1 bounds have no ignore_prior switch
+        if m.check_prior_bounds(th):
+            ll = m.logdensity(th) - m.log_prior(th)
+            assert abs(ll - g["dense_loglik"][i]) <= 1e-9 * abs(ll)
+
+
+def test_ogle_grid(golden_dir):
+    g = _load(golden_dir, "ogle_grid.npz")
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    assert t.size == 437
+    n_checked = 0
+    for p in range(2, 8):
+        for q in range(p):
+            k = "p%dq%d_" % (p, q)
+            for i in range(g[k + "theta"].shape[0]):
+                cond = g[k + "cond"][i]
+                _check_case(t, y, yerr, g[k + "theta"][i], p, q, g[k + "omega"][i], g[k + "ma"][i],
+                            g[k + "sigsqr"][i], g[k + "mean"][i], g[k + "var"][i], g[k + "loglik"][i], cond)
+                n_checked += 1
+    assert n_checked == 81
+
+
+def test_cpp_fixture_filter(golden_dir):
+    """First 300 rows of cpp_tests/data/carma_test.dat with the true ZCARMA(5) parameters of
+    carma_unit_tests.cpp:387-503."""
+    g = _load(golden_dir, "cpp_carma_test300.npz")
+    mean, var = orc.kfilter_carma(g["t"], g["y"], g["yerr"], float(g["sigsqr"]), g["omega"], g["ma"])
+    np.testing.assert_allclose(var, g["var"], rtol=1e-11)
+    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=1e-11)
+    assert abs(var[0] - (2.3 ** 2 + g["yerr"][0] ** 2)) < 1e-10
+
+
+def test_variance_known_answer(golden_dir):
+    """carma_unit_tests.cpp:1269-1317: Variance(...) = 223003.230567 to rel 1e-8."""
+    s = json.load(open(os.path.join(golden_dir, "summary.json")))["variance_kat"]
+    om = np.array(s["omega_re"]) + 1j * np.array(s["omega_im"])
+    v = orc.variance(om, s["ma"], sigma=2.3)
+    assert abs(v - s["expected_cpp"]) / s["expected_cpp"] < 1e-8
+    assert abs(v - s["python"]) / s["python"] < 1e-13
+    for lag, ref in zip(s["lags"], s["lagged"]):
+        assert abs(orc.variance(om, s["ma"], sigma=2.3, dt=lag) - ref) / abs(ref) < 1e-12
+
+
+def test_sort_and_dedup():
+    """carma_unit_tests.cpp:55-187: n=100 linspace, swap idx 12<->43, duplicate idx 43."""
+    t = np.linspace(0.0, 99.0, 100)
+    y = np.arange(100.0) * 2
+    e = np.arange(100.0) + 0.5
+    t2, y2, e2 = t.copy(), y.copy(), e.copy()
+    for a in (t2, y2, e2):
+        a[[12, 43]] = a[[43, 12]]
+    ts, ys, es = orc.sort_dedup(t2, y2, e2)
+    np.testing.assert_array_equal(ts, t)
+    np.testing.assert_array_equal(ys, y)
+    np.testing.assert_array_equal(es, e)
+    t3 = np.insert(t, 43, t[43])
+    y3 = np.insert(y, 43, -1.0)
+    e3 = np.insert(e, 43, -1.0)
+    ts, ys, es = orc.sort_dedup(t3, y3, e3)
+    assert ts.size == 100 and np.all(np.diff(ts) > 0)
+    # the FIRST of the duplicated pair is kept (unique_values = {0} U 1+find(dt != 0))
+    assert ys[43] == -1.0 and ys[44] == y[44]
+
+
+def test_prior_bounds(golden_dir):
+    """carma_unit_tests.cpp:1116-1267 + carpack.cpp:314-374."""
+    g = _load(golden_dir, "carma53_readme.npz")
+    m = orc.OracleModel(g["t"], g["y"], g["yerr"], 5, 3)
+    th = g["theta"][0].copy()
+    assert np.isfinite(m.logdensity(th))
+
+    def bad(mod):
+        x = th.copy()
+        mod(x)
+        assert m.logdensity(x) == -np.inf
+        assert np.isfinite(m.logdensity(x, ignore_prior=True)) or np.isnan(m.logdensity(x, ignore_prior=True))
+
+    bad(lambda x: x.__setitem__(0, m.max_stdev * 1.01))
+    bad(lambda x: x.__setitem__(0, -0.1))
+    bad(lambda x: x.__setitem__(1, 0.49))
+    bad(lambda x: x.__setitem__(1, 2.01))
+    # width above max_freq: quad_term2 = 2*2pi*width
+    bad(lambda x: x.__setitem__(4, np.log(2 * 2 * np.pi * m.max_freq * 1.01)))
+    # width below min_freq on the real root
+    bad(lambda x: x.__setitem__(7, np.log(2 * np.pi * m.min_freq * 0.99)))
+    # centroids out of order: swap the two quadratic factors
+    def swap(x):
+        x[3:5], x[5:7] = x[5:7].copy(), x[3:5].copy()
+    bad(swap)
+    # duplicate roots (fractional difference < 1e-4)
+    def dup(x):
+        x[5:7] = x[3:5] + 1e-6
+    bad(dup)
+    # log prior formula (carpack.hpp:118-126)
+    assert abs(m.log_prior(th) - (-0.5 * 50 / th[1] - 26.0 * np.log(th[1]))) < 1e-14
+
+
+def test_chol_update_r1():
+    rng = np.random.default_rng(0)
+    d = 11
+    A = rng.standard_normal((d, d))
+    S = A @ A.T + d * np.eye(d)
+    R = np.linalg.cholesky(S).T            # upper, S = R^T R (arma::chol convention, steps.cpp:32)
+    v = rng.standard_normal(d)
+    R2, _ = orc.chol_update_r1(R, v, False)
+    np.testing.assert_allclose(R2.T @ R2, S + np.outer(v, v), rtol=1e-12)
+    assert np.allclose(R2, np.triu(R2))
+    v = 0.1 * v
+    R3, _ = orc.chol_update_r1(R, v, True)
+    np.testing.assert_allclose(R3.T @ R3, S - np.outer(v, v), rtol=1e-12)
+
+
+def test_batch_threads_agree(golden_dir):
+    g = _load(golden_dir, "carma53_readme.npz")
+    m = orc.OracleModel(g["t"], g["y"], g["yerr"], 5, 3)
+    a = m.logdensity_batch(g["theta"], nthreads=1)
+    b = m.logdensity_batch(g["theta"], nthreads=4)
+    np.testing.assert_array_equal(a, b)
+    for i in range(4):
+        assert a[i] == m.logdensity(g["theta"][i])
