@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- Kalman log-likelihood evals/s, CARMA(5,3), n=270 (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: B=1024 batched CARMA_Base::LogDensity
+evaluations (BASELINE configs[1]) on the README synthetic series, parameter vectors already
+resident in HBM, one kernel launch through the C ABI (carma_logdensity_batch_dev).
+
+    python bench.py --gpus 1 --steps 2000 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  The batch is sharded by rank with no data-path collective (independent
+evaluations -> weak scaling: every rank runs its own 1024-eval batches); RCCL is used only for
+the barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (import torch BEFORE the HIP library so both share one HIP runtime)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6   # public MI355X FP64 vector peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=1024, help="evals per step (BASELINE config 2: 1024)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import carma_pack_amd as cpa
+    from carma_pack_amd.synth import theta_batch
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    p, q = 5, 3
+    n, d, B = t.size, 3 + p + q, args.batch
+    max_stdev = 10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)      # src/carmcmc.cpp:85-89
+    ctx = cpa.Context(t, y, yerr, p, q, max_stdev=max_stdev, device=local_rank)
+
+    # synthetic parameter vectors: posterior-like + prior-like, 8 distinct
+    # batches per rank so consecutive steps never see the same input.
+    NPOOL = 8
+    rng = np.random.default_rng(2 + 1000 * rank)
+    pool_h = [theta_batch(rng, B, p, q, t, y, theta_center=g["theta"][0]) for _ in range(NPOOL)]
+    pool = [torch.from_numpy(a).to(dev) for a in pool_h]
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+
+    def step(i):
+        ctx.logdensity_dev(pool[i % NPOOL].data_ptr(), B, out.data_ptr(), ignore_prior=False, stream=sh)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY K steps --------------------------------------------------------
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity: the last step's output is the real thing
+    last = out.cpu().numpy()
+    n_finite = int(np.isfinite(last).sum())
+
+    # ---- per-launch kernel duration (HIP events on the launch stream) ------------------------
+    M = max(1, min(args.steps, 256))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(M)]
+    for i, (a, b) in enumerate(evs):
+        a.record(stream)
+        step(i)
+        b.record(stream)
+    torch.cuda.synchronize()
+    kdur_ms = np.array([a.elapsed_time(b) for a, b in evs])
+    kernel_ms = float(np.mean(kdur_ms))
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        bytes_per_eval = 24 * n + 8 * d + 8
+        flops_per_eval = (n - 1) * (42 * p * p + 22 * p + 9)
+        achieved_gbs = bytes_per_eval * B / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: CARMA(5,3), n=270 README synthetic series, %d batched "
+                            "log-density evals per step (one launch), thetas resident in HBM" % B,
+                "p": p, "q": q, "n": int(n), "batch_per_gpu": B, "parallelism": "batch sharded by rank, no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "k_logdens_carma<5,8,1>",
+                "kernel_avg_us": 1e3 * kernel_ms,
+                "kernel_min_us": 1e3 * float(kdur_ms.min()),
+                "launch_period_us": 1e3 * dev_ms / args.steps,
+                "algorithmic_bytes_per_launch": bytes_per_eval * B,
+                "note": "latency/FP64-VALU bound by construction (sequential n-step recursion); "
+                        "HBM roofline reported as north_star asks",
+                "fp64_valu": {
+                    "flops_per_eval": flops_per_eval,
+                    "achieved_tflops": flops_per_eval * B / (kernel_ms * 1e-3) / 1e12,
+                    "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                },
+            },
+            "finite_in_last_batch": n_finite,
+        }
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(t, y, yerr, p, q, max_stdev, pool_h[0], args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(t, y, yerr, p, q, max_stdev, theta, budget_s):
+    """The CPU oracle (a port of kfilter.cpp + carpack LogDensity; the reference's own C++ is
+    unbuildable here) timed on this box's host cores on a bounded sample of the same workload."""
+    import oracle as orc
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=max_stdev)
+    cores = os.cpu_count() or 1
+    cores = min(cores, orc.max_threads())
+    B = theta.shape[0]
+    # single thread: ~1/3 of the budget
+    t0 = time.perf_counter()
+    reps1 = 0
+    while time.perf_counter() - t0 < budget_s / 3.0:
+        m.logdensity_batch(theta, nthreads=1)
+        reps1 += 1
+    v1 = reps1 * B / (time.perf_counter() - t0)
+    # all cores: a larger tile so OpenMP start-up is amortised
+    big = np.tile(theta, (max(1, 8 * cores * 1024 // B // 8), 1))
+    m.logdensity_batch(big, nthreads=cores)
+    t0 = time.perf_counter()
+    repsN = 0
+    while time.perf_counter() - t0 < budget_s * 2.0 / 3.0:
+        m.logdensity_batch(big, nthreads=cores)
+        repsN += 1
+    vN = repsN * big.shape[0] / (time.perf_counter() - t0)
+    return {
+        "value": vN,
+        "unit": "evals/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "the step's own 1024-theta batch (CARMA(5,3), n=270): %d evals on %d OpenMP threads "
+                  "(+ %d evals single-threaded)" % (repsN * big.shape[0], cores, reps1 * B),
+        "single_thread_value": v1,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+"""ctypes binding of libcarma_mi355.so (the C ABI declared in include/carma_mi355.h).
+
+This is the ONLY route from Python to the compute path.  There is no CPU fallback: if the
+shared library is missing the import fails, and without a gfx950 device every compute call
+raises ``CarmaDeviceError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcarma_mi355.so")
+
+CARMA_OK, CARMA_EINVAL, CARMA_ENODEV, CARMA_ENOMEM, CARMA_EHIP = 0, -22, -19, -12, -5
+PMAX = 7
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class CarmaError(RuntimeError):
+    """Boost.Python turned C++ exceptions into RuntimeError; so do we."""
+
+
+class CarmaDeviceError(CarmaError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "carma_pack_amd: %s not found -- build it with ./build.sh (or __graft_entry__.build()); "
+            "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.carma_version.restype = C.c_char_p
+    L.carma_last_error.restype = C.c_char_p
+    L.carma_device_count.restype = C.c_int
+    L.carma_ctx_create.restype = C.c_void_p
+    L.carma_ctx_create.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+    L.carma_ctx_destroy.argtypes = [C.c_void_p]
+    L.carma_ctx_destroy.restype = None
+    L.carma_ctx_n.argtypes = [C.c_void_p]
+    L.carma_ctx_dim.argtypes = [C.c_void_p]
+    L.carma_ctx_get_data.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    L.carma_ctx_get_prior.argtypes = [C.c_void_p, _dp]
+    L.carma_ctx_set_prior.argtypes = [C.c_void_p, C.c_double]
+    L.carma_logdensity_batch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
+    L.carma_logdensity_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.carma_logprior.argtypes = [C.c_void_p, _dp]
+    L.carma_logprior.restype = C.c_double
+    L.carma_kfilter_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp,
+                                      _ip, C.c_int]
+    L.carma_kfilter_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _ip, C.c_int]
+    return L
+
+
+lib = _load()
+
+# every symbol include/carma_mi355.h declares (kept in sync by tests/test_capi_symbols.py)
+EXPORTS = [
+    "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
+    "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
+    "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logprior", "carma_kfilter_carma",
+    "carma_kfilter_car1",
+]
+
+
+def last_error():
+    return lib.carma_last_error().decode()
+
+
+def check(rc, what):
+    if rc == CARMA_OK:
+        return
+    msg = "%s failed (%d): %s" % (what, rc, last_error())
+    if rc == CARMA_ENODEV:
+        raise CarmaDeviceError(msg)
+    if rc == CARMA_EINVAL:
+        raise ValueError(msg)
+    raise CarmaError(msg)
+
+
+def as_f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def default_device():
+    """One process per GPU: LOCAL_RANK picks the device when launched by torch.distributed.run."""
+    n = lib.carma_device_count()
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    return lr % n if n > 0 else 0
+
+
+class Context:
+    """Owns one carma_ctx (series resident in HBM + prior bounds)."""
+
+    def __init__(self, time, y, yerr, p, q=0, max_stdev=None, device=None):
+        time, y, yerr = as_f64(time), as_f64(y), as_f64(yerr)
+        if not (time.size == y.size == yerr.size):
+            raise ValueError("time, y, yerr must have the same length")
+        if max_stdev is None:
+            # default of the CARMA_Base ctor: 10*sqrt(arma::var(y)) (sample variance, carpack.hpp:71)
+            max_stdev = 10.0 * np.sqrt(np.var(y, ddof=1)) if y.size > 1 else 0.0
+        self.device = default_device() if device is None else int(device)
+        self._h = lib.carma_ctx_create(ptr(time), ptr(y), ptr(yerr), time.size, int(p), int(q), float(max_stdev),
+                                       self.device)
+        if not self._h:
+            msg = "carma_ctx_create failed: " + last_error()
+            if "no HIP device" in msg:
+                raise CarmaDeviceError(msg)
+            raise ValueError(msg)
+        self.p, self.q = int(p), int(q)
+        self.n = lib.carma_ctx_n(self._h)
+        self.d = lib.carma_ctx_dim(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.carma_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def data(self):
+        t, y, e = np.empty(self.n), np.empty(self.n), np.empty(self.n)
+        check(lib.carma_ctx_get_data(self._h, ptr(t), ptr(y), ptr(e)), "carma_ctx_get_data")
+        return t, y, e
+
+    def prior(self):
+        out = np.empty(3)
+        check(lib.carma_ctx_get_prior(self._h, ptr(out)), "carma_ctx_get_prior")
+        return tuple(out)
+
+    def set_prior(self, max_stdev):
+        check(lib.carma_ctx_set_prior(self._h, float(max_stdev)), "carma_ctx_set_prior")
+
+    def logdensity(self, thetas, ignore_prior=False):
+        thetas = as_f64(thetas)
+        one = thetas.ndim == 1
+        thetas = thetas.reshape(-1, self.d)
+        out = np.empty(thetas.shape[0])
+        check(lib.carma_logdensity_batch(self._h, ptr(thetas), thetas.shape[0], int(bool(ignore_prior)), ptr(out)),
+              "carma_logdensity_batch")
+        return float(out[0]) if one else out
+
+    def logdensity_dev(self, d_theta_ptr, B, d_out_ptr, ignore_prior=False, stream=0):
+        """Enqueue on `stream` (a hipStream_t as int); pointers are device addresses."""
+        check(lib.carma_logdensity_batch_dev(self._h, C.c_void_p(d_theta_ptr), int(B), int(bool(ignore_prior)),
+                                             C.c_void_p(d_out_ptr), C.c_void_p(stream)),
+              "carma_logdensity_batch_dev")
+
+    def logprior(self, theta):
+        theta = as_f64(theta)
+        return lib.carma_logprior(self._h, ptr(theta))
+
+
+def kfilter_carma(time, y, yerr, sigsqr, omega, ma, device=None):
+    time, y, yerr = as_f64(time), as_f64(y), as_f64(yerr)
+    omega = np.asarray(omega, dtype=complex)
+    om = as_f64(np.c_[omega.real, omega.imag])
+    ma = as_f64(ma)
+    mean, var = np.empty(time.size), np.empty(time.size)
+    nout = C.c_int(0)
+    rc = lib.carma_kfilter_carma(ptr(time), ptr(y), ptr(yerr), time.size, omega.size, float(sigsqr), ptr(om), ptr(ma),
+                                 ma.size, ptr(mean), ptr(var), C.byref(nout),
+                                 default_device() if device is None else device)
+    if rc == 1:
+        raise CarmaError("KalmanFilterp: singular eigenvector matrix (solve failed)")
+    check(rc, "carma_kfilter_carma")
+    return mean[:nout.value], var[:nout.value]
+
+
+def kfilter_car1(time, y, yerr, sigsqr, omega, device=None):
+    time, y, yerr = as_f64(time), as_f64(y), as_f64(yerr)
+    mean, var = np.empty(time.size), np.empty(time.size)
+    nout = C.c_int(0)
+    rc = lib.carma_kfilter_car1(ptr(time), ptr(y), ptr(yerr), time.size, float(sigsqr), float(omega), ptr(mean),
+                                ptr(var), C.byref(nout), default_device() if device is None else device)
+    check(rc, "carma_kfilter_car1")
+    return mean[:nout.value], var[:nout.value]

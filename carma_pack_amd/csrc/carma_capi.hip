@@ -1,0 +1,357 @@
+// carma_capi.hip -- C ABI of libcarma_mi355.so (see include/carma_mi355.h for the contract and
+// the reference interface each entry point replaces).  Host side only: argument checking, the
+// series preparation of KalmanFilter::init, HBM residency, launches.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+#include "../../include/carma_mi355.h"
+#include "carma_host.h"
+
+namespace carma {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    set_error("%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ? CARMA_ENODEV
+           : (e == hipErrorOutOfMemory)                                                             ? CARMA_ENOMEM
+                                                                                                    : CARMA_EHIP;
+}
+
+// KalmanFilter::init (src/include/kfilter.hpp:43-76): sort by time when any dt < 0, then keep
+// sample 0 and every sample whose dt to its predecessor in the sorted series is non-zero.
+void sort_dedup(std::vector<double>& t, std::vector<double>& y, std::vector<double>& e)
+{
+    const size_t n = t.size();
+    bool need_sort = false;
+    for (size_t i = 1; i < n; i++) need_sort |= (t[i] - t[i - 1] < 0);
+    if (need_sort) {
+        std::vector<size_t> idx(n);
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return t[a] < t[b]; });
+        std::vector<double> t2(n), y2(n), e2(n);
+        for (size_t i = 0; i < n; i++) {
+            t2[i] = t[idx[i]];
+            y2[i] = y[idx[i]];
+            e2[i] = e[idx[i]];
+        }
+        t.swap(t2);
+        y.swap(y2);
+        e.swap(e2);
+    }
+    std::vector<char> keep(n, 1);
+    bool dup = false;
+    for (size_t i = 1; i < n; i++) {
+        if (t[i] - t[i - 1] == 0) {
+            keep[i] = 0;
+            dup = true;
+        }
+    }
+    if (dup) {
+        size_t m = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (keep[i]) {
+                t[m] = t[i];
+                y[m] = y[i];
+                e[m] = e[i];
+                m++;
+            }
+        }
+        t.resize(m);
+        y.resize(m);
+        e.resize(m);
+    }
+}
+
+// series records {dt_k, y_k, yerr_k^2, t_k}
+std::vector<double> pack_series(const std::vector<double>& t, const std::vector<double>& y, const std::vector<double>& e)
+{
+    const size_t n = t.size();
+    std::vector<double> s(4 * n);
+    for (size_t k = 0; k < n; k++) {
+        s[4 * k + 0] = k ? t[k] - t[k - 1] : 0.0;
+        s[4 * k + 1] = y[k];
+        s[4 * k + 2] = e[k] * e[k];
+        s[4 * k + 3] = t[k];
+    }
+    return s;
+}
+
+int select_device(int device)
+{
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible (this library has no CPU fallback)");
+        return CARMA_ENODEV;
+    }
+    if (device < 0 || device >= cnt) {
+        set_error("device %d out of range (have %d)", device, cnt);
+        return CARMA_EINVAL;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return CARMA_OK;
+}
+
+int Ctx::ensure_staging(int B)
+{
+    if (B <= cap) return CARMA_OK;
+    if (d_theta) (void)hipFree(d_theta);
+    if (d_out) (void)hipFree(d_out);
+    d_theta = d_out = nullptr;
+    cap = 0;
+    int newcap = std::max(B, 1024);
+    hipError_t e = hipMalloc(&d_theta, sizeof(double) * (size_t)newcap * d);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(theta)");
+    e = hipMalloc(&d_out, sizeof(double) * (size_t)newcap);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(out)");
+    cap = newcap;
+    return CARMA_OK;
+}
+
+}  // namespace carma
+
+using namespace carma;
+
+extern "C" {
+
+const char* carma_version(void) { return "carma_mi355 0.1 (gfx950)"; }
+const char* carma_last_error(void) { return g_err; }
+
+int carma_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return cnt;
+}
+
+carma_ctx* carma_ctx_create(const double* time, const double* y, const double* yerr, int n, int p, int q,
+                            double max_stdev, int device)
+{
+    if (!time || !y || !yerr || n < 2) {
+        set_error("carma_ctx_create: need n >= 2 and non-null arrays");
+        return nullptr;
+    }
+    if (p < 1 || p > CARMA_PMAX || q < 0 || (p == 1 && q != 0) || (p > 1 && q >= p)) {
+        // BOOST_ASSERT_MSG(q < p, ...) src/include/carpack.hpp:377
+        set_error("carma_ctx_create: need 1 <= p <= %d and q < p (got p=%d q=%d)", CARMA_PMAX, p, q);
+        return nullptr;
+    }
+    if (select_device(device) != CARMA_OK) return nullptr;
+    Ctx* c = new Ctx();
+    c->device = device;
+    c->p = p;
+    c->q = q;
+    c->d = (p == 1) ? 4 : 3 + p + q;
+    c->t.assign(time, time + n);
+    c->y.assign(y, y + n);
+    c->yerr.assign(yerr, yerr + n);
+    sort_dedup(c->t, c->y, c->yerr);
+    c->n = (int)c->t.size();
+    if (c->n < 2) {
+        set_error("carma_ctx_create: fewer than 2 distinct times");
+        delete c;
+        return nullptr;
+    }
+    c->pr.measerr_dof = 50.0;   // src/include/carpack.hpp:63
+    carma_ctx_set_prior(reinterpret_cast<carma_ctx*>(c), max_stdev);
+    std::vector<double> s = pack_series(c->t, c->y, c->yerr);
+    hipError_t e = hipMalloc(&c->d_series, sizeof(double) * s.size());
+    if (e == hipSuccess) e = hipMemcpy(c->d_series, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        hip_fail(e, "carma_ctx_create");
+        carma_ctx_destroy(reinterpret_cast<carma_ctx*>(c));
+        return nullptr;
+    }
+    return reinterpret_cast<carma_ctx*>(c);
+}
+
+void carma_ctx_destroy(carma_ctx* h)
+{
+    if (!h) return;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    (void)hipSetDevice(c->device);
+    if (c->pt) pt_state_free(c);
+    if (c->d_series) (void)hipFree(c->d_series);
+    if (c->d_theta) (void)hipFree(c->d_theta);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int carma_ctx_n(const carma_ctx* h) { return h ? reinterpret_cast<const Ctx*>(h)->n : CARMA_EINVAL; }
+int carma_ctx_dim(const carma_ctx* h) { return h ? reinterpret_cast<const Ctx*>(h)->d : CARMA_EINVAL; }
+
+int carma_ctx_get_data(const carma_ctx* h, double* time, double* y, double* yerr)
+{
+    if (!h) return CARMA_EINVAL;
+    const Ctx* c = reinterpret_cast<const Ctx*>(h);
+    if (time) std::memcpy(time, c->t.data(), sizeof(double) * c->n);
+    if (y) std::memcpy(y, c->y.data(), sizeof(double) * c->n);
+    if (yerr) std::memcpy(yerr, c->yerr.data(), sizeof(double) * c->n);
+    return CARMA_OK;
+}
+
+int carma_ctx_get_prior(const carma_ctx* h, double* out3)
+{
+    if (!h || !out3) return CARMA_EINVAL;
+    const Ctx* c = reinterpret_cast<const Ctx*>(h);
+    out3[0] = c->pr.max_stdev;
+    out3[1] = c->pr.max_freq;
+    out3[2] = c->pr.min_freq;
+    return CARMA_OK;
+}
+
+int carma_ctx_set_prior(carma_ctx* h, double max_stdev)
+{
+    if (!h) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    // SetPrior (src/include/carpack.hpp:201-207)
+    c->pr.max_stdev = max_stdev;
+    double dtmin = std::numeric_limits<double>::infinity();
+    for (int i = 1; i < c->n; i++) dtmin = std::min(dtmin, c->t[i] - c->t[i - 1]);
+    c->pr.max_freq = 1.0 / dtmin;
+    c->pr.min_freq = 1.0 / (*std::max_element(c->t.begin(), c->t.end()) - *std::min_element(c->t.begin(), c->t.end()));
+    return CARMA_OK;
+}
+
+int carma_logdensity_batch_dev(carma_ctx* h, const double* d_theta, int B, int ignore_prior, double* d_out, void* stream)
+{
+    if (!h || !d_theta || !d_out || B < 0) {
+        set_error("carma_logdensity_batch_dev: bad argument");
+        return CARMA_EINVAL;
+    }
+    if (B == 0) return CARMA_OK;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (c->p == 1)
+        e = launch_logdens_car1(d_theta, B, reinterpret_cast<const double4*>(c->d_series), c->n, c->pr, d_out, st);
+    else
+        e = launch_logdens_carma(c->p, d_theta, B, c->d, c->q, reinterpret_cast<const double4*>(c->d_series), c->n, c->pr,
+                                 ignore_prior, d_out, st);
+    if (e != hipSuccess) return hip_fail(e, "launch logdensity");
+    return CARMA_OK;
+}
+
+int carma_logdensity_batch(carma_ctx* h, const double* theta, int B, int ignore_prior, double* out)
+{
+    if (!h || !theta || !out || B < 0) {
+        set_error("carma_logdensity_batch: bad argument");
+        return CARMA_EINVAL;
+    }
+    if (B == 0) return CARMA_OK;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int rc = c->ensure_staging(B);
+    if (rc != CARMA_OK) return rc;
+    e = hipMemcpyAsync(c->d_theta, theta, sizeof(double) * (size_t)B * c->d, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return hip_fail(e, "H2D theta");
+    rc = carma_logdensity_batch_dev(h, c->d_theta, B, ignore_prior, c->d_out, c->stream);
+    if (rc != CARMA_OK) return rc;
+    e = hipMemcpyAsync(out, c->d_out, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(e, "D2H logdensity");
+    return CARMA_OK;
+}
+
+double carma_logprior(const carma_ctx* h, const double* theta)
+{
+    if (!h || !theta) return std::numeric_limits<double>::quiet_NaN();
+    const Ctx* c = reinterpret_cast<const Ctx*>(h);
+    // src/include/carpack.hpp:118-126
+    const double s = theta[1];
+    return -0.5 * c->pr.measerr_dof / s - (1.0 + c->pr.measerr_dof / 2.0) * std::log(s);
+}
+
+static int kfilter_common(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
+                          const double* omega_re_im, const double* ma, int nma, double car1_omega, double* mean,
+                          double* var, int* n_out, int device)
+{
+    if (!time || !y || !yerr || !mean || !var || n < 1) {
+        set_error("carma_kfilter: bad argument");
+        return CARMA_EINVAL;
+    }
+    int rc = select_device(device);
+    if (rc != CARMA_OK) return rc;
+    std::vector<double> t(time, time + n), yy(y, y + n), ee(yerr, yerr + n);
+    if (n >= 2) sort_dedup(t, yy, ee);
+    const int m = (int)t.size();
+    if (n_out) *n_out = m;
+    std::vector<double> s = pack_series(t, yy, ee);
+    std::vector<double> par(2 * CARMA_PMAX + CARMA_PMAX, 0.0);
+    if (p > 1) {
+        for (int i = 0; i < 2 * p; i++) par[i] = omega_re_im[i];
+        for (int i = 0; i < p && i < nma; i++) par[2 * CARMA_PMAX + i] = ma[i];   // zero padded (kfilter.hpp:318-320)
+    }
+    double *d_s = nullptr, *d_par = nullptr, *d_mv = nullptr;
+    int* d_sing = nullptr;
+    hipError_t e = hipMalloc(&d_s, sizeof(double) * s.size());
+    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = hipMalloc(&d_mv, sizeof(double) * 2 * m);
+    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_sing, 0, sizeof(int));
+    if (e == hipSuccess) {
+        if (p == 1)
+            e = launch_kfilter_car1(sigsqr, car1_omega, reinterpret_cast<const double4*>(d_s), m, d_mv, d_mv + m, nullptr);
+        else
+            e = launch_kfilter_carma(p, d_par, d_par + 2 * CARMA_PMAX, sigsqr, reinterpret_cast<const double4*>(d_s), m,
+                                     d_mv, d_mv + m, d_sing, nullptr);
+    }
+    int sing = 0;
+    if (e == hipSuccess) e = hipMemcpy(mean, d_mv, sizeof(double) * m, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(var, d_mv + m, sizeof(double) * m, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&sing, d_sing, sizeof(int), hipMemcpyDeviceToHost);
+    if (d_s) (void)hipFree(d_s);
+    if (d_par) (void)hipFree(d_par);
+    if (d_mv) (void)hipFree(d_mv);
+    if (d_sing) (void)hipFree(d_sing);
+    if (e != hipSuccess) return hip_fail(e, "carma_kfilter");
+    return sing ? 1 : CARMA_OK;
+}
+
+int carma_kfilter_carma(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
+                        const double* omega_re_im, const double* ma, int nma, double* mean, double* var, int* n_out,
+                        int device)
+{
+    if (p < 2 || p > CARMA_PMAX || !omega_re_im || !ma || nma < 1) {
+        set_error("carma_kfilter_carma: need 2 <= p <= %d, omega and ma", CARMA_PMAX);
+        return CARMA_EINVAL;
+    }
+    return kfilter_common(time, y, yerr, n, p, sigsqr, omega_re_im, ma, nma, 0.0, mean, var, n_out, device);
+}
+
+int carma_kfilter_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr, double omega,
+                       double* mean, double* var, int* n_out, int device)
+{
+    return kfilter_common(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, mean, var, n_out, device);
+}
+
+}  // extern "C"

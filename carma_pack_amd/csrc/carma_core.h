@@ -1,0 +1,461 @@
+// carma_core.h -- the batched CARMA(p,q) / CAR(1) Kalman log-density, written once for a
+// "lane group" of G lanes per evaluation.  Included by carma_kernels.hip (gfx950, grp_device.h)
+// and by tests/emu/emu_core.cpp (CPU lane emulator, test harness only).
+//
+// What it computes (reference file:line under /root/reference):
+//   * theta -> AR roots            src/carpack.cpp:137-172   (CARp::ARRoots)
+//   * theta -> MA coefficients     src/carpack.cpp:522-580, :742-756 (CARMA::ExtractMA, polycoefs)
+//   * sigma^2 = theta0^2/Variance  src/carpack.cpp:377-409, src/include/carpack.hpp:316-319,391-395
+//   * prior bounds / log prior     src/carpack.cpp:314-374, :709-732, src/include/carpack.hpp:118-126
+//   * Kalman Reset                 src/kfilter.cpp:138-186
+//   * Kalman Update (n-1 times)    src/kfilter.cpp:189-215
+//   * log-likelihood sum           src/include/carpack.hpp:167-171
+//   * CAR(1) Reset/Update          src/kfilter.cpp:19-48
+//
+// Layout: lane r (< P) of a group owns ROW r of the p x p Hermitian matrix D = P - V
+// (prediction covariance minus stationary covariance), its own root omega_r, rotated MA
+// coefficient b_r, state x_r and c_r = (V b^H)_r.  Algebraically identical to the reference
+// recursion but restructured so that the stationary matrix V never has to be kept:
+//     u      = P b^H            = D b^H + c
+//     var_k  = Re(b P b^H)+e_k  = s0 + Re(b D b^H) + e_k,      s0 = Re(b V b^H)
+//     D     <- (rho rho^H) o (D - u u^H / var)                 (kfilter.cpp:197,204)
+//     x     <- rho o (x + u innov / var)                        (kfilter.cpp:194,201)
+// Per step every lane needs all u_j and rho_j: one 32-byte publish + P reads through the
+// group's exchange slots (LDS on the GPU); var/mean need one 2-value butterfly all-reduce.
+// sum log(var) is accumulated as a mantissa product + integer exponent sum, so the loop has no
+// log(); 1/var is the only division.
+#pragma once
+#include "carma_types.h"
+
+namespace carma {
+
+// series record k: {dt_k = t_k - t_{k-1} (dt_0 = 0), y_k, yerr_k^2, t_k}
+// (double4 so that one 32-byte scalar load fetches a step)
+
+constexpr double TWO_PI = 6.283185307179586476925286766559;
+constexpr double LN2 = 0.693147180559945309417232121458;
+
+struct Cx {
+    double re, im;
+};
+CARMA_DEV Cx cmul(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+CARMA_DEV Cx cmulc(Cx a, Cx b) { return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }  // a*conj(b)
+CARMA_DEV Cx cadd(Cx a, Cx b) { return {a.re + b.re, a.im + b.im}; }
+CARMA_DEV Cx csub(Cx a, Cx b) { return {a.re - b.re, a.im - b.im}; }
+CARMA_DEV Cx cscale(Cx a, double s) { return {a.re * s, a.im * s}; }
+CARMA_DEV Cx cdiv(Cx a, Cx b)
+{
+    double den = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+}
+CARMA_DEV Cx csel(bool m, Cx a, Cx b) { return {m ? a.re : b.re, m ? a.im : b.im}; }
+
+// ---------------------------------------------------------------------------------------------
+// One quadratic factor -> its two roots (carpack.cpp:143-163); which = 0 / 1 picks the member.
+CARMA_DEV Cx quad_root(double lq1, double lq2, int which)
+{
+    double q1 = exp(lq1), q2 = exp(lq2);
+    double disc = q2 * q2 - 4.0 * q1;
+    Cx r;
+    if (disc > 0) {
+        double sq = sqrt(disc);
+        r.re = which ? -0.5 * (q2 - sq) : -0.5 * (q2 + sq);
+        r.im = 0.0;
+    } else {
+        r.re = -0.5 * q2;
+        double im = -0.5 * sqrt(-disc);
+        r.im = which ? -im : im;
+    }
+    return r;
+}
+
+// Model quantities of one evaluation, as held by lane r of its group.
+template <int P>
+struct Model {
+    Cx w;            // omega_r (own AR root)
+    Cx wall[P];      // all roots (replicated)
+    double beta[P];  // MA coefficients, zero padded (replicated)
+    double sigsqr;   // driving-noise variance
+    double mu, scale;
+    bool valid;      // prior bounds satisfied (or ignored)
+};
+
+// theta -> Model  (ARRoots, ExtractMA, ExtractSigsqr, CheckPriorBounds)
+template <int P, int G, class GrpT>
+CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const Prior& pr, int ignore_prior,
+                                Model<P>& m)
+{
+    const int r = g.lane();
+    const int rr = r < P ? r : P - 1;
+    // --- own AR root (carpack.cpp:137-172)
+    if ((P & 1) && rr == P - 1) {
+        m.w.re = -exp(theta[3 + P - 1]);
+        m.w.im = 0.0;
+    } else {
+        int pair = rr >> 1;
+        m.w = quad_root(theta[3 + 2 * pair], theta[3 + 2 * pair + 1], rr & 1);
+    }
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        m.wall[j].re = g.bcast(m.w.re, j);
+        m.wall[j].im = g.bcast(m.w.im, j);
+    }
+    // --- MA coefficients (carpack.cpp:522-580, polycoefs :742-756); identical in every lane
+#pragma unroll
+    for (int i = 0; i < P; i++) m.beta[i] = 0.0;
+    if (q == 0) {
+        m.beta[0] = 1.0;
+    } else {
+        Cx cf[P];  // coefficients of prod (x - root_i), cf[0] = 1
+#pragma unroll
+        for (int i = 0; i < P; i++) cf[i] = {0.0, 0.0};
+        cf[0] = {1.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < P - 1; i++) {
+            if (i < q) {
+                Cx root;
+                if ((q & 1) && i == q - 1) {
+                    root.re = -exp(theta[3 + P + q - 1]);
+                    root.im = 0.0;
+                } else {
+                    int pair = i >> 1;
+                    root = quad_root(theta[3 + P + 2 * pair], theta[3 + P + 2 * pair + 1], i & 1);
+                }
+#pragma unroll
+                for (int k = P - 1; k >= 1; k--) {
+                    if (k <= i + 1) cf[k] = csub(cf[k], cmul(root, cf[k - 1]));
+                }
+            }
+        }
+        double cq = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) cq = (i == q) ? cf[i].re : cq;
+#pragma unroll
+        for (int i = 0; i < P; i++) {      // beta_i = pc[q-i]/pc[q], i <= q
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; j++) v = (j == q - i) ? cf[j].re : v;
+            m.beta[i] = (i <= q) ? v / cq : 0.0;
+        }
+    }
+    // --- sigma^2 = theta0^2 / Variance(omega, beta, 1)   (carpack.cpp:377-409)
+    {
+        Cx dp = {1.0, 0.0};
+#pragma unroll
+        for (int l = 0; l < P; l++) {
+            Cx a = csub(m.wall[l], m.w);
+            Cx b = {m.wall[l].re + m.w.re, -m.wall[l].im + m.w.im};
+            Cx f = cmul(a, b);
+            dp = (l != rr) ? cmul(dp, f) : dp;
+        }
+        Cx denom = cscale(dp, -2.0 * m.w.re);
+        Cx s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, pw1 = {1.0, 0.0}, pw2 = {1.0, 0.0};
+        Cx nw = {-m.w.re, -m.w.im};
+#pragma unroll
+        for (int l = 0; l < P; l++) {
+            s1 = cadd(s1, cscale(pw1, m.beta[l]));
+            s2 = cadd(s2, cscale(pw2, m.beta[l]));
+            pw1 = cmul(pw1, m.w);
+            pw2 = cmul(pw2, nw);
+        }
+        Cx term = cdiv(cmul(s1, s2), denom);
+        double var1 = g.sum(r < P ? term.re : 0.0);
+        m.sigsqr = theta[0] * theta[0] / var1;
+    }
+    m.scale = theta[1];
+    m.mu = theta[2];
+    // --- prior bounds (carpack.cpp:314-374, unique_roots :709-732)
+    m.valid = true;
+    if (!ignore_prior) {
+        double cent = fabs(m.w.im) / 2.0 / (TWO_PI / 2.0);
+        double width = -m.w.re / 2.0 / (TWO_PI / 2.0);
+        bool viol = !(cent < pr.max_freq) || !(width < pr.max_freq) || !(width > pr.min_freq);
+        double cent_prev = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) cent_prev = (j == rr - 1) ? fabs(m.wall[j].im) / 2.0 / (TWO_PI / 2.0) : cent_prev;
+        if (rr >= 1 && (cent - cent_prev) > 1e-8) viol = true;
+#pragma unroll
+        for (int j = 1; j < P; j++) {
+            if (j > rr) {
+                Cx qd = cdiv(csub(m.w, m.wall[j]), cadd(m.w, m.wall[j]));
+                double frac = hypot(qd.re, qd.im);
+                if (frac <= 1e-4) viol = true;
+            }
+        }
+        double nviol = g.sum((r < P && viol) ? 1.0 : 0.0);
+        double ysigma = theta[0], ms = theta[1];
+        if (nviol != 0.0 || (ysigma > pr.max_stdev) || (ysigma < 0) || (ms < 0.5) || (ms > 2.0)) m.valid = false;
+    }
+}
+
+// Running -0.5*sum(log var) - 0.5*sum(innov^2/var) without a log in the loop.
+struct LogLikAcc {
+    double prod;   // product of mantissas in [0.5,1)
+    int esum;      // sum of binary exponents
+    double chi2;
+    bool bad;      // some var was <= 0 or NaN  (reference: log(var) = NaN -> NaN total)
+    int since;
+    CARMA_DEV void init()
+    {
+        prod = 1.0;
+        esum = 0;
+        chi2 = 0.0;
+        bad = false;
+        since = 0;
+    }
+    CARMA_DEV void add_var(double var)
+    {
+        int e;
+        double mnt = frexp(var, &e);
+        bad = bad || !(var > 0.0) || !(var < 1.7976931348623157e308);
+        prod *= mnt;
+        esum += e;
+        if (++since == 512) {   // keep the mantissa product far from underflow
+            int e2;
+            prod = frexp(prod, &e2);
+            esum += e2;
+            since = 0;
+        }
+    }
+    CARMA_DEV double total() const
+    {
+        double nan_ = prod - prod;  // 0, or NaN if prod is not finite
+        if (bad) nan_ = (prod - prod) / (prod - prod);
+        return -0.5 * (log(prod) + (double)esum * LN2) - 0.5 * chi2 + nan_;
+    }
+};
+
+// Kalman filter of one evaluation (Reset + n-1 Updates) -> log-likelihood sum (no prior).
+// y is centred with m.mu and yerr^2 scaled with m.scale on the fly (carpack.hpp:150-153).
+// If WRITE_MV, lane 0 of the group also stores the one-step means/variances.
+// *singular is set when the Vandermonde solve hits an exactly zero pivot (arma::solve throws).
+template <int P, int G, bool WRITE_MV, class GrpT>
+CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __restrict__ series, int n,
+                            double* mean_out, double* var_out, bool* singular)
+{
+    const int r = g.lane();
+    const bool act = r < P;
+
+    // ---- Reset (kfilter.cpp:138-186) --------------------------------------------------------
+    // Column r of the Vandermonde matrix E_ir = omega_r^i lives in lane r; the right-hand side
+    // e_{p-1} is replicated.  LU with partial pivoting (|re|+|im| pivot rule), forward
+    // substitution folded in, then column-oriented back substitution.
+    Cx a[P], rhs[P];
+    {
+        Cx pw = {1.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            a[i] = pw;
+            pw = cmul(pw, m.w);
+            rhs[i] = {i == P - 1 ? 1.0 : 0.0, 0.0};
+        }
+    }
+    Cx b_own = {0.0, 0.0};   // rotated MA coefficient b_r = sum_i beta_i omega_r^i (kfilter.cpp:162)
+#pragma unroll
+    for (int i = 0; i < P; i++) b_own = cadd(b_own, cscale(a[i], m.beta[i]));
+
+    bool sing = false;
+#pragma unroll
+    for (int k = 0; k < P; k++) {
+        int piv = k;
+        double best = fabs(a[k].re) + fabs(a[k].im);
+#pragma unroll
+        for (int i = k + 1; i < P; i++) {
+            double v = fabs(a[i].re) + fabs(a[i].im);
+            bool gt = v > best;
+            best = gt ? v : best;
+            piv = gt ? i : piv;
+        }
+        piv = g.bcast_i(piv, k);
+        best = g.bcast(best, k);
+        if (best == 0.0) sing = true;
+#pragma unroll
+        for (int i = k + 1; i < P; i++) {
+            bool sw = (piv == i);
+            Cx t = a[i];
+            a[i] = csel(sw, a[k], a[i]);
+            a[k] = csel(sw, t, a[k]);
+            Cx tr = rhs[i];
+            rhs[i] = csel(sw, rhs[k], rhs[i]);
+            rhs[k] = csel(sw, tr, rhs[k]);
+        }
+        Cx rinv = cdiv(Cx{1.0, 0.0}, a[k]);
+#pragma unroll
+        for (int i = k + 1; i < P; i++) {
+            Cx l = cmul(a[i], rinv);
+            l.re = g.bcast(l.re, k);
+            l.im = g.bcast(l.im, k);
+            Cx upd = csub(a[i], cmul(l, a[k]));
+            a[i] = csel(r > k, upd, a[i]);
+            rhs[i] = csub(rhs[i], cmul(l, rhs[k]));
+        }
+    }
+#pragma unroll
+    for (int k = P - 1; k >= 0; k--) {
+        Cx ukk = {g.bcast(a[k].re, k), g.bcast(a[k].im, k)};
+        rhs[k] = cdiv(rhs[k], ukk);
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+            Cx uik = {g.bcast(a[i].re, k), g.bcast(a[i].im, k)};
+            rhs[i] = csub(rhs[i], cmul(rhs[k], uik));
+        }
+    }
+    // rhs[] now holds J (replicated).  b for all lanes:
+    Cx ball[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        ball[j].re = g.bcast(b_own.re, j);
+        ball[j].im = g.bcast(b_own.im, j);
+    }
+    // own row of V (kfilter.cpp:165-172) folded straight into c_r = sum_j V_rj conj(b_j)
+    Cx Jr = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < P; j++) Jr = csel(j == r, rhs[j], Jr);
+    Cx c_own = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        Cx num = cmulc(cscale(Jr, -m.sigsqr), rhs[j]);
+        Cx den = {m.w.re + m.wall[j].re, m.w.im - m.wall[j].im};
+        Cx v = cdiv(num, den);
+        c_own = cadd(c_own, cmulc(v, ball[j]));
+    }
+    const double s0 = g.sum(act ? (b_own.re * c_own.re - b_own.im * c_own.im) : 0.0);
+
+    // ---- state ------------------------------------------------------------------------------
+    Cx D[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) D[j] = {0.0, 0.0};
+    Cx x = {0.0, 0.0};
+    Cx u = c_own;            // (P b^H)_r with P = V
+    double4 rec = series[0];
+    double var = s0 + rec.z * m.scale;      // kfilter.cpp:180-182
+    double mean = 0.0;
+    double innov = rec.y - m.mu;            // kfilter.cpp:184
+    LogLikAcc acc;
+    acc.init();
+    acc.add_var(var);
+    if (WRITE_MV && r == 0) {
+        mean_out[0] = mean;
+        var_out[0] = var;
+    }
+
+    // ---- Update x (n-1)  (kfilter.cpp:189-215) -----------------------------------------------
+    for (int k = 1; k < n; k++) {
+        rec = series[k];
+        const double s = 1.0 / var;
+        acc.chi2 += innov * innov * s;
+        const double sinn = s * innov;
+        // own transition factor rho_r = exp(omega_r dt)  (kfilter.cpp:200)
+        double ea = exp(m.w.re * rec.x), sn, cs;
+        sincos(m.w.im * rec.x, &sn, &cs);
+        Cx rho = {ea * cs, ea * sn};
+        g.publish(u.re, u.im, rho.re, rho.im);
+        // state: x <- rho o (x + g innov)      (kfilter.cpp:194,201)
+        x = cmul(rho, Cx{x.re + u.re * sinn, x.im + u.im * sinn});
+        Cx w = {0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            double4 o = g.peek(j);                       // {u_j, rho_j}
+            Cx t = cmulc(u, Cx{o.x, o.y});               // u_r conj(u_j)
+            Cx d = {D[j].re - t.re * s, D[j].im - t.im * s};        // kfilter.cpp:197
+            Cx R = cmulc(rho, Cx{o.z, o.w});             // rho_r conj(rho_j)
+            D[j] = cmul(R, d);                           // kfilter.cpp:204 (minus V on both sides)
+            w = cadd(w, cmulc(D[j], ball[j]));           // (D b^H)_r
+        }
+        g.done_reading();
+        u = cadd(w, c_own);
+        double pv = act ? (b_own.re * w.re - b_own.im * w.im) : 0.0;   // Re(b_r w_r)
+        double pm = act ? (b_own.re * x.re - b_own.im * x.im) : 0.0;   // Re(b_r x_r)
+        pv = g.sum(pv);
+        pm = g.sum(pm);
+        mean = pm;                                  // kfilter.cpp:207
+        var = s0 + pv + rec.z * m.scale;            // kfilter.cpp:209-210
+        innov = (rec.y - m.mu) - mean;              // kfilter.cpp:213
+        acc.add_var(var);
+        if (WRITE_MV && r == 0) {
+            mean_out[k] = mean;
+            var_out[k] = var;
+        }
+    }
+    acc.chi2 += innov * innov / var;
+    *singular = sing;
+    return acc.total();
+}
+
+// log prior (carpack.hpp:118-126)
+CARMA_DEV double log_prior(double measerr_scale, double dof)
+{
+    return -0.5 * dof / measerr_scale - (1.0 + dof / 2.0) * log(measerr_scale);
+}
+
+// CARMA_Base::LogDensity (carpack.hpp:131-176) for CARp/CARMA: -inf outside the prior bounds
+// or on a singular solve, else log-likelihood + log prior.
+template <int P, int G, class GrpT>
+CARMA_DEV double logdensity_carma(const GrpT& g, const double* theta, int q, const double4* __restrict__ series,
+                                  int n, const Prior& pr, int ignore_prior)
+{
+    Model<P> m;
+    model_from_theta<P, G>(g, theta, q, pr, ignore_prior, m);
+    bool sing;
+    double ll = filter_run<P, G, false>(g, m, series, n, nullptr, nullptr, &sing);
+    ll += log_prior(m.scale, pr.measerr_dof);
+    const double ninf = -1.0 / 0.0;
+    if (sing || !m.valid) ll = ninf;
+    return ll;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CAR(1): one LANE per evaluation (kfilter.cpp:19-48, carpack.hpp:265,273-275, carpack.cpp:116-130)
+CARMA_DEV double car1_filter(double sigsqr, double omega, double mu, double scale,
+                             const double4* __restrict__ series, int n, bool write_mv, double* mean_out,
+                             double* var_out)
+{
+    double4 rec = series[0];
+    double e2 = rec.z * scale;
+    double mean = 0.0;
+    double var = sigsqr / (2.0 * omega) + e2;
+    double yc = rec.y - mu;
+    LogLikAcc acc;
+    acc.init();
+    acc.add_var(var);
+    if (write_mv) {
+        mean_out[0] = mean;
+        var_out[0] = var;
+    }
+    for (int k = 1; k < n; k++) {
+        double innov = yc - mean;
+        acc.chi2 += innov * innov / var;
+        rec = series[k];
+        double rho = exp(-1.0 * omega * rec.x);
+        double previous_var = var - e2;
+        double var_ratio = previous_var / var;
+        mean = rho * mean + rho * var_ratio * innov;
+        var = sigsqr / (2.0 * omega) * (1.0 - rho * rho) + rho * rho * previous_var * (1.0 - var_ratio);
+        e2 = rec.z * scale;
+        var += e2;
+        yc = rec.y - mu;
+        acc.add_var(var);
+        if (write_mv) {
+            mean_out[k] = mean;
+            var_out[k] = var;
+        }
+    }
+    double innov = yc - mean;
+    acc.chi2 += innov * innov / var;
+    return acc.total();
+}
+
+CARMA_DEV double logdensity_car1(const double* theta, const double4* __restrict__ series, int n, const Prior& pr)
+{
+    double ysigma = theta[0], ms = theta[1], mu = theta[2];
+    double omega = exp(theta[3]);
+    double sigsqr = 2.0 * ysigma * ysigma * exp(theta[3]);
+    bool ok = !((omega > pr.max_freq) || (omega < pr.min_freq) || (ysigma > pr.max_stdev) || (ysigma < 0) ||
+                (ms < 0.5) || (ms > 2.0));
+    double ll = car1_filter(sigsqr, omega, mu, ms, series, n, false, nullptr, nullptr);
+    ll += log_prior(ms, pr.measerr_dof);
+    const double ninf = -1.0 / 0.0;
+    return ok ? ll : ninf;
+}
+
+}  // namespace carma

@@ -1,0 +1,157 @@
+// carma_kernels.hip -- gfx950 kernels for the batched CARMA / CAR(1) Kalman log-density.
+//
+// K1  k_logdens_carma<P,G,WAVES> : B independent CARMA_Base::LogDensity evaluations
+//      (src/include/carpack.hpp:131-176 over src/kfilter.cpp:138-215).  G lanes per evaluation
+//      (G = 8 for p = 5..7, 4 for p = 3..4, 2 for p = 2), i.e. 8/16/32 evaluations per wave64;
+//      lane r owns row r of the Hermitian state covariance (registers), the per-step all-gather
+//      of (u_r, rho_r) goes through 2 KiB of LDS per wave, var/mean through a DPP butterfly.
+//      The series record of step k is wave-uniform -> one 32-byte scalar load per step.
+// K2  k_logdens_car1            : CAR(1), one lane per evaluation (src/kfilter.cpp:19-48).
+// K1m k_kfilter_carma<P,G>      : one evaluation that also stores mean[n], var[n]
+//      (KalmanFilterp::Filter, src/include/kfilter.hpp:126-132).
+//
+// FP64 vector ALU + software exp/sincos; not a contraction, so no MFMA.  HBM traffic is the
+// series (24 B/datum, shared by every evaluation and L2/scalar-cache resident) + 8(d+1) B/eval.
+#include <hip/hip_runtime.h>
+
+#include "grp_device.h"
+#include "carma_core.h"
+#include "carma_launch.h"
+
+namespace carma {
+
+template <int P>
+struct GroupOf {
+    static constexpr int value = P <= 2 ? 2 : (P <= 4 ? 4 : 8);
+};
+
+template <int P, int G, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_logdens_carma(const double* __restrict__ theta, int B, int d, int q,
+                                                             const double4* __restrict__ series, int n, Prior pr,
+                                                             int ignore_prior, double* __restrict__ out)
+{
+    __shared__ double4 xch[64 * WAVES];
+    const int tid = threadIdx.x;
+    Grp<G> g{xch + (tid & ~63), tid & 63};
+    long e = ((long)blockIdx.x * (64 * WAVES) + tid) / G;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    double ll = logdensity_carma<P, G>(g, theta + e * d, q, series, n, pr, ignore_prior);
+    if (live && g.lane() == 0) out[e] = ll;
+}
+
+__global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ theta, int B,
+                                                     const double4* __restrict__ series, int n, Prior pr,
+                                                     double* __restrict__ out)
+{
+    long e = (long)blockIdx.x * 64 + threadIdx.x;
+    if (e < B) out[e] = logdensity_car1(theta + 4 * e, series, n, pr);
+}
+
+template <int P, int G>
+__global__ __launch_bounds__(64) void k_kfilter_carma(const double* __restrict__ om_re_im, const double* __restrict__ ma,
+                                                      double sigsqr, const double4* __restrict__ series, int n,
+                                                      double* __restrict__ mean, double* __restrict__ var,
+                                                      int* __restrict__ singular)
+{
+    __shared__ double4 xch[64];
+    const int tid = threadIdx.x;
+    Grp<G> g{xch, tid & 63};
+    Model<P> m;
+    const int r = g.lane() < P ? g.lane() : P - 1;
+    m.w = {om_re_im[2 * r], om_re_im[2 * r + 1]};
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        m.wall[j] = {om_re_im[2 * j], om_re_im[2 * j + 1]};
+        m.beta[j] = ma[j];
+    }
+    m.sigsqr = sigsqr;
+    m.mu = 0.0;
+    m.scale = 1.0;
+    m.valid = true;
+    bool sing;
+    // every group of the wave runs the same evaluation and stores the same values
+    filter_run<P, G, true>(g, m, series, n, mean, var, &sing);
+    if (tid == 0) *singular = sing ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_kfilter_car1(double sigsqr, double omega, const double4* __restrict__ series,
+                                                     int n, double* __restrict__ mean, double* __restrict__ var)
+{
+    if (threadIdx.x == 0) car1_filter(sigsqr, omega, 0.0, 1.0, series, n, true, mean, var);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int P>
+static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, const double4* series, int n,
+                                   const Prior& pr, int ignore_prior, double* out, hipStream_t st)
+{
+    constexpr int G = GroupOf<P>::value;
+    constexpr int EPW = 64 / G;   // evaluations per wave
+    // Latency-bound path: spread waves over as many CUs as possible (1 wave/block) until the
+    // chip is covered, then pack 4 waves per block.
+    const long waves = ((long)B + EPW - 1) / EPW;
+    if (waves <= 2048) {
+        hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n,
+                           pr, ignore_prior, out);
+    } else {
+        const long blocks = (waves + 3) / 4;
+        hipLaunchKernelGGL((k_logdens_carma<P, G, 4>), dim3((unsigned)blocks), dim3(256), 0, st, theta, B, d, q, series,
+                           n, pr, ignore_prior, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,
+                                const Prior& pr, int ignore_prior, double* out, hipStream_t st)
+{
+    switch (p) {
+        case 2: return launch_logdens_p<2>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
+        case 3: return launch_logdens_p<3>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
+        case 4: return launch_logdens_p<4>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
+        case 5: return launch_logdens_p<5>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
+        case 6: return launch_logdens_p<6>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
+        case 7: return launch_logdens_p<7>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_logdens_car1(const double* theta, int B, const double4* series, int n, const Prior& pr, double* out,
+                               hipStream_t st)
+{
+    const unsigned blocks = (unsigned)(((long)B + 63) / 64);
+    hipLaunchKernelGGL(k_logdens_car1, dim3(blocks), dim3(64), 0, st, theta, B, series, n, pr, out);
+    return hipGetLastError();
+}
+
+template <int P>
+static hipError_t launch_kfilter_p(const double* om, const double* ma, double sigsqr, const double4* series, int n,
+                                   double* mean, double* var, int* singular, hipStream_t st)
+{
+    constexpr int G = GroupOf<P>::value;
+    hipLaunchKernelGGL((k_kfilter_carma<P, G>), dim3(1), dim3(64), 0, st, om, ma, sigsqr, series, n, mean, var, singular);
+    return hipGetLastError();
+}
+
+hipError_t launch_kfilter_carma(int p, const double* om, const double* ma, double sigsqr, const double4* series, int n,
+                                double* mean, double* var, int* singular, hipStream_t st)
+{
+    switch (p) {
+        case 2: return launch_kfilter_p<2>(om, ma, sigsqr, series, n, mean, var, singular, st);
+        case 3: return launch_kfilter_p<3>(om, ma, sigsqr, series, n, mean, var, singular, st);
+        case 4: return launch_kfilter_p<4>(om, ma, sigsqr, series, n, mean, var, singular, st);
+        case 5: return launch_kfilter_p<5>(om, ma, sigsqr, series, n, mean, var, singular, st);
+        case 6: return launch_kfilter_p<6>(om, ma, sigsqr, series, n, mean, var, singular, st);
+        case 7: return launch_kfilter_p<7>(om, ma, sigsqr, series, n, mean, var, singular, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* series, int n, double* mean, double* var,
+                               hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kfilter_car1, dim3(1), dim3(64), 0, st, sigsqr, omega, series, n, mean, var);
+    return hipGetLastError();
+}
+
+}  // namespace carma

@@ -1,0 +1,18 @@
+// carma_launch.h -- host-callable launchers implemented in carma_kernels.hip / carma_pt.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "carma_types.h"
+
+namespace carma {
+
+hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,
+                                const Prior& pr, int ignore_prior, double* out, hipStream_t st);
+hipError_t launch_logdens_car1(const double* theta, int B, const double4* series, int n, const Prior& pr, double* out,
+                               hipStream_t st);
+hipError_t launch_kfilter_carma(int p, const double* om_re_im, const double* ma, double sigsqr, const double4* series,
+                                int n, double* mean, double* var, int* singular, hipStream_t st);
+hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* series, int n, double* mean, double* var,
+                               hipStream_t st);
+
+}  // namespace carma

@@ -1,0 +1,75 @@
+// grp_device.h -- lane-group primitives for gfx950 (wave64).
+//
+// An "eval group" is G consecutive lanes of one wavefront (G = 2,4,8,16) that cooperate on one
+// CARMA log-density evaluation; lane r of the group owns row r of the p x p state covariance.
+// All cross-lane traffic is DPP (v_mov_b32_dpp) for the butterflies and ds_bpermute for
+// broadcasts with a run-time source lane; nothing here uses __syncthreads().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define CARMA_DEV __device__ __forceinline__
+
+namespace carma {
+
+// DPP controls (gfx9): quad_perm[a,b,c,d] = a | b<<2 | c<<4 | d<<6
+constexpr int DPP_QUAD_XOR1 = 0xB1;   // [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;   // [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane i <-> 7-i inside each 8 lanes
+constexpr int DPP_ROW_MIRROR = 0x140;        // lane i <-> 15-i inside each 16 lanes
+
+template <int CTRL>
+CARMA_DEV double dpp_mov(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int G>
+struct Grp {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group size");
+
+    // scratch for the per-step all-gather: one 32-byte slot per lane, in LDS
+    double4* xch;      // points at this WAVE's 64 slots
+    int lane64;        // lane id inside the wave
+
+    CARMA_DEV int lane() const { return lane64 & (G - 1); }
+    CARMA_DEV int gbase() const { return lane64 & ~(G - 1); }
+
+    // Butterfly all-reduce; every lane of the group ends with the bit-identical total.
+    CARMA_DEV static double sum(double v)
+    {
+        if (G >= 2) v += dpp_mov<DPP_QUAD_XOR1>(v);
+        if (G >= 4) v += dpp_mov<DPP_QUAD_XOR2>(v);
+        if (G >= 8) v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+        if (G >= 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
+        return v;
+    }
+    CARMA_DEV static double max(double v)
+    {
+        if (G >= 2) v = fmax(v, dpp_mov<DPP_QUAD_XOR1>(v));
+        if (G >= 4) v = fmax(v, dpp_mov<DPP_QUAD_XOR2>(v));
+        if (G >= 8) v = fmax(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+        if (G >= 16) v = fmax(v, dpp_mov<DPP_ROW_MIRROR>(v));
+        return v;
+    }
+    // value of v held by lane j of this group (j identical in every lane of the group)
+    CARMA_DEV double bcast(double v, int j) const { return __shfl(v, gbase() + j, 64); }
+    CARMA_DEV int bcast_i(int v, int j) const { return __shfl(v, gbase() + j, 64); }
+
+    // Per-step exchange: every lane publishes 4 doubles and then reads lane j's 4 doubles.
+    // LDS operations of one wave execute in issue order, so no barrier is needed; the fences
+    // only stop the compiler from moving the loads above the store.
+    CARMA_DEV void publish(double a, double b, double c, double d) const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        xch[lane64] = make_double4(a, b, c, d);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    CARMA_DEV double4 peek(int j) const { return xch[gbase() + j]; }
+    CARMA_DEV void done_reading() const { __builtin_amdgcn_wave_barrier(); }
+};
+
+}  // namespace carma

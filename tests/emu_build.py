@@ -1,0 +1,70 @@
+"""Builds/loads the CPU lane emulator of the kernel core (tests/emu) -- test harness only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO = os.path.join(HERE, "emu", "libcarma_emu.so")
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(HERE, "emu", "emu_core.cpp"), os.path.join(HERE, "emu", "grp_emu.h")]
+        csrc = os.path.join(ROOT, "carma_pack_amd", "csrc")
+        srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+        if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+                                   "-o", SO, srcs[0]])
+        _lib = C.CDLL(SO)
+    return _lib
+
+
+def pack_series(t, y, yerr):
+    s = np.zeros((t.size, 4))
+    s[1:, 0] = np.diff(t)
+    s[:, 1] = y
+    s[:, 2] = yerr ** 2
+    s[:, 3] = t
+    return s
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def logdensity_carma(t, y, yerr, p, q, thetas, prior, ignore_prior=False):
+    s = pack_series(t, y, yerr)
+    th = np.ascontiguousarray(thetas, dtype=float).reshape(-1, 3 + p + q)
+    pr = np.array(list(prior) + [50.0])
+    out = np.empty(th.shape[0])
+    rc = lib().emu_logdensity_carma(p, q, _p(th), th.shape[0], _p(s), t.size, _p(pr), int(ignore_prior), _p(out))
+    assert rc == 0
+    return out
+
+
+def logdensity_car1(t, y, yerr, thetas, prior):
+    s = pack_series(t, y, yerr)
+    th = np.ascontiguousarray(thetas, dtype=float).reshape(-1, 4)
+    pr = np.array(list(prior) + [50.0])
+    out = np.empty(th.shape[0])
+    lib().emu_logdensity_car1(_p(th), th.shape[0], _p(s), t.size, _p(pr), _p(out))
+    return out
+
+
+def kfilter_carma(t, y, yerr, sigsqr, omega, ma):
+    s = pack_series(t, y, yerr)
+    omega = np.asarray(omega, dtype=complex)
+    p = omega.size
+    re, im = np.ascontiguousarray(omega.real), np.ascontiguousarray(omega.imag)
+    mav = np.zeros(p)
+    mav[:len(ma)] = ma
+    mean, var, ll = np.empty(t.size), np.empty(t.size), np.empty(1)
+    lib().emu_kfilter_carma.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int, _dp, _dp, _dp]
+    rc = lib().emu_kfilter_carma(p, _p(re), _p(im), _p(mav), float(sigsqr), _p(s), t.size, _p(mean), _p(var), _p(ll))
+    return mean, var, ll[0], rc

@@ -1,0 +1,220 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the committed
+golden vectors from the reference's Python, and size-independent properties at full size.
+Tolerance (north_star): 1e-10 relative on the log-density."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from helpers import assert_parity, irregular_series, prior_like_theta, theta_batch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import carma_pack_amd
+    assert carma_pack_amd._lib.lib.carma_device_count() >= 1, "no MI355X visible"
+    return carma_pack_amd
+
+
+@pytest.fixture(scope="module")
+def readme(golden_dir):
+    return np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+
+
+def _pop_var_stdev(y):
+    return 10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)
+
+
+def test_readme_golden_loglik(cpa, readme):
+    g = readme
+    ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3, max_stdev=_pop_var_stdev(g["y"]))
+    ld = ctx.logdensity(g["theta"], ignore_prior=True)
+    ll = ld - np.array([ctx.logprior(th) for th in g["theta"]])
+    assert_parity(ll, g["loglik"], RTOL, "golden loglik")
+    # dense-GP identity (carma_unit_tests.cpp:564-594)
+    idx = np.flatnonzero(np.isfinite(g["dense_loglik"]))
+    assert np.all(np.abs(ll[idx] - g["dense_loglik"][idx]) <= 1e-9 * np.abs(ll[idx]))
+    # and the oracle on the full log-density incl. prior bounds
+    m = orc.OracleModel(g["t"], g["y"], g["yerr"], 5, 3)
+    assert_parity(ctx.logdensity(g["theta"]), m.logdensity_batch(g["theta"]), RTOL, "oracle logdensity")
+
+
+def test_readme_kfilter_mean_var(cpa, readme):
+    g = readme
+    for i in (0, 3, 16, 19, 30):
+        th = g["theta"][i]
+        mean, var = cpa.kfilter_carma(g["t"], g["y"] - th[2], np.sqrt(th[1]) * g["yerr"], g["sigsqr"][i],
+                                      g["omega"][i], g["ma"][i])
+        np.testing.assert_allclose(var, g["var"][i], rtol=1e-8)
+        np.testing.assert_allclose(mean, g["mean"][i], rtol=0, atol=1e-9 * np.abs(g["y"] - th[2]).max())
+    mean, var = cpa.kfilter_carma(g["t"], g["y"] - 17.0, g["yerr"], float(g["true_sigsqr"]), g["true_omega"],
+                                  g["true_ma"][:3])     # short ma -> zero padded (kfilter.hpp:318-320)
+    np.testing.assert_allclose(var, g["true_var"], rtol=1e-10)
+    assert abs(var[0] - (2.3 ** 2 + g["yerr"][0] ** 2)) < 1e-10     # carma_unit_tests.cpp:443-444
+
+
+def test_ogle_grid_all_orders(cpa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ogle_grid.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    worst = 0.0
+    for p in range(2, 8):
+        for q in range(p):
+            k = "p%dq%d_" % (p, q)
+            ctx = cpa.Context(t, y, yerr, p, q)
+            th = g[k + "theta"]
+            ll = ctx.logdensity(th, ignore_prior=True) - np.array([ctx.logprior(x) for x in th])
+            worst = max(worst, assert_parity(ll, g[k + "loglik"], RTOL, "ogle p=%d q=%d" % (p, q)))
+            ctx.close()
+    print("worst rel err on OGLE grid: %.2e" % worst)
+
+
+def test_car1_golden(cpa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "car1_n100.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ctx = cpa.Context(t, y, yerr, 1, 0, max_stdev=_pop_var_stdev(y))
+    m = orc.OracleModel(t, y, yerr, 1)
+    assert_parity(ctx.logdensity(g["theta"]), m.logdensity_batch(g["theta"]), RTOL, "car1 oracle")
+    for i, th in enumerate(g["theta"]):
+        om = np.exp(th[3])
+        mean, var = cpa.kfilter_car1(t, y - th[2], np.sqrt(th[1]) * yerr, 2 * th[0] ** 2 * om, om)
+        np.testing.assert_allclose(var, g["var"][i], rtol=1e-9)
+        np.testing.assert_allclose(mean, g["mean"][i], rtol=0, atol=1e-9)
+        if m.check_prior_bounds(th):
+            ll = ctx.logdensity(th) - ctx.logprior(th)
+            assert abs(ll - g["dense_loglik"][i]) <= 1e-9 * abs(ll)
+    # batch of prior-like CAR(1) draws incl. bound violations
+    rng = np.random.default_rng(11)
+    th = np.array([prior_like_theta(rng, 1, 0, t, y) for _ in range(300)])
+    th[::7, 3] = np.log(ctx.prior()[1] * 1.5)        # omega > max_freq -> -inf
+    assert_parity(ctx.logdensity(th), m.logdensity_batch(th), RTOL, "car1 batch")
+
+
+def test_cpp_fixture(cpa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "cpp_carma_test300.npz"))
+    mean, var = cpa.kfilter_carma(g["t"], g["y"], g["yerr"], float(g["sigsqr"]), g["omega"], g["ma"])
+    np.testing.assert_allclose(var, g["var"], rtol=1e-9)
+    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=1e-9)
+
+
+def test_prior_bounds_and_failures(cpa, readme):
+    g = readme
+    ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3, max_stdev=_pop_var_stdev(g["y"]))
+    m = orc.OracleModel(g["t"], g["y"], g["yerr"], 5, 3)
+    th0 = g["theta"][0]
+    cases = [th0.copy() for _ in range(10)]
+    cases[1][0] = m.max_stdev * 1.01
+    cases[2][0] = -0.1
+    cases[3][1] = 0.49
+    cases[4][1] = 2.01
+    cases[5][4] = np.log(2 * 2 * np.pi * m.max_freq * 1.01)
+    cases[6][7] = np.log(2 * np.pi * m.min_freq * 0.99)
+    cases[7][3:5], cases[7][5:7] = th0[5:7], th0[3:5]
+    cases[8][5:7] = th0[3:5] + 1e-6
+    cases[9][5:7] = th0[3:5]          # exactly repeated roots -> singular solve under ignore_prior
+    cases = np.array(cases)
+    got = ctx.logdensity(cases)
+    want = m.logdensity_batch(cases)
+    assert np.isfinite(got[0]) and np.all(np.isneginf(got[1:]))
+    assert_parity(got, want, RTOL, "bounds")
+    got = ctx.logdensity(cases[:9], ignore_prior=True)
+    want = m.logdensity_batch(cases[:9], ignore_prior=True)
+    fin = np.isfinite(want)
+    assert_parity(got[fin], want[fin], 1e-6, "ignore_prior")   # near-duplicate roots: ill-conditioned
+    assert not np.isfinite(ctx.logdensity(cases[9], ignore_prior=True))
+
+
+def test_random_batch_vs_oracle_config2(cpa, readme):
+    """BASELINE config 2: 1024 thetas on the README series, posterior-like and prior-like."""
+    g = readme
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    rng = np.random.default_rng(2)
+    th = theta_batch(rng, 1024, 5, 3, t, y, theta_center=g["theta"][0])
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_var_stdev(y))
+    m = orc.OracleModel(t, y, yerr, 5, 3)
+    got = ctx.logdensity(th)
+    want = m.logdensity_batch(th, nthreads=8)
+    worst = assert_parity(got, want, RTOL, "config2")
+    assert np.isfinite(want).sum() > 600
+    got = ctx.logdensity(th, ignore_prior=True)
+    want = m.logdensity_batch(th, ignore_prior=True, nthreads=8)
+    worst2 = assert_parity(got, want, RTOL, "config2 ignore_prior")
+    print("config2 worst rel err %.2e / %.2e" % (worst, worst2))
+
+
+def test_ragged_and_empty_batches(cpa, readme):
+    g = readme
+    ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3, max_stdev=_pop_var_stdev(g["y"]))
+    full = ctx.logdensity(np.tile(g["theta"], (40, 1)))       # 1280 evals
+    assert ctx.logdensity(np.empty((0, 11))).shape == (0,)
+    for B in (1, 7, 8, 9, 63, 65, 1025):
+        th = np.tile(g["theta"], (B // 32 + 1, 1))[:B]
+        got = ctx.logdensity(th)
+        # bit-identical regardless of batch size / position in the wave
+        assert np.array_equal(got, full[:B], equal_nan=True)
+    with pytest.raises(ValueError):
+        cpa.Context(g["t"], g["y"], g["yerr"], 3, 3)
+    with pytest.raises(ValueError):
+        cpa.Context(g["t"], g["y"], g["yerr"], 9, 0)
+
+
+def test_input_sort_dedup_invariance(cpa, readme):
+    """KalmanFilter::init semantics (carma_unit_tests.cpp:55-187): unsorted input and duplicated
+    times give the same answer as the clean series."""
+    g = readme
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ms = _pop_var_stdev(y)
+    base = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms).logdensity(g["theta"])
+    perm = np.random.default_rng(0).permutation(t.size)
+    got = cpa.Context(t[perm], y[perm], yerr[perm], 5, 3, max_stdev=ms).logdensity(g["theta"])
+    assert np.array_equal(got, base, equal_nan=True)
+    t2, y2, e2 = np.insert(t, 44, t[43]), np.insert(y, 44, 99.0), np.insert(yerr, 44, 1.0)
+    c2 = cpa.Context(t2, y2, e2, 5, 3, max_stdev=ms)
+    assert c2.n == 270
+    assert np.array_equal(c2.logdensity(g["theta"]), base, equal_nan=True)
+
+
+def test_full_size_properties(cpa, readme):
+    """Size-independent properties at the benchmark size (B = 1024 x n = 270 and beyond)."""
+    g = readme
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ms = _pop_var_stdev(y)
+    rng = np.random.default_rng(3)
+    th = theta_batch(rng, 4096, 5, 3, t, y, theta_center=g["theta"][0], frac_post=0.8)
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms)
+    a = ctx.logdensity(th)
+    # (1) determinism + batch-order independence
+    perm = rng.permutation(th.shape[0])
+    b = ctx.logdensity(th[perm])
+    assert np.array_equal(a[perm], b, equal_nan=True)
+    # (2) mean-shift invariance: (y + c, mu + c) leaves the likelihood unchanged
+    c = 3.25
+    ctx2 = cpa.Context(t, y + c, yerr, 5, 3, max_stdev=ms)
+    th2 = th.copy()
+    th2[:, 2] += c
+    assert_parity(ctx2.logdensity(th2), a, 1e-9, "mean shift")
+    # (3) time-shift invariance (only dt enters)
+    ctx3 = cpa.Context(t + 1000.0, y, yerr, 5, 3, max_stdev=ms)
+    assert_parity(ctx3.logdensity(th), a, 1e-9, "time shift")
+    # (4) ignore_prior only removes the bounds: finite entries agree exactly
+    d = ctx.logdensity(th, ignore_prior=True)
+    fin = np.isfinite(a)
+    assert np.array_equal(a[fin], d[fin])
+
+
+@pytest.mark.parametrize("p,q,n", [(7, 6, 10000), (6, 2, 3001), (2, 1, 513), (3, 0, 1000), (4, 3, 64)])
+def test_long_series_vs_oracle(cpa, p, q, n):
+    """BASELINE config 4 shape (CARMA(7,6), n = 10^4) and other orders on long irregular series."""
+    t, y, yerr = irregular_series(n, seed=4)
+    rng = np.random.default_rng(40 + p)
+    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(40)])
+    ctx = cpa.Context(t, y, yerr, p, q)
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    got = ctx.logdensity(th, ignore_prior=True)
+    want = m.logdensity_batch(th, ignore_prior=True, nthreads=8)
+    worst = assert_parity(got, want, RTOL, "p=%d q=%d n=%d" % (p, q, n))
+    print("p=%d q=%d n=%d worst rel err %.2e" % (p, q, n, worst))
