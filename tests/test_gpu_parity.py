@@ -121,10 +121,13 @@ def test_prior_bounds_and_failures(cpa, readme):
     want = m.logdensity_batch(cases)
     assert np.isfinite(got[0]) and np.all(np.isneginf(got[1:]))
     assert_parity(got, want, RTOL, "bounds")
-    got = ctx.logdensity(cases[:9], ignore_prior=True)
-    want = m.logdensity_batch(cases[:9], ignore_prior=True)
+    got = ctx.logdensity(cases[:8], ignore_prior=True)
+    want = m.logdensity_batch(cases[:8], ignore_prior=True)
     fin = np.isfinite(want)
-    assert_parity(got[fin], want[fin], 1e-6, "ignore_prior")   # near-duplicate roots: ill-conditioned
+    assert_parity(got[fin], want[fin], RTOL, "ignore_prior")
+    # roots 1e-6 apart: cond(E) ~ 1e12+, both LU's are noise-dominated; only the magnitude is pinned
+    g8, w8 = ctx.logdensity(cases[8], ignore_prior=True), m.logdensity(cases[8], ignore_prior=True)
+    assert np.isfinite(g8) and abs(g8 - w8) < 1e-3 * abs(w8)
     assert not np.isfinite(ctx.logdensity(cases[9], ignore_prior=True))
 
 
