@@ -52,6 +52,19 @@ def _load():
     L.carma_kfilter_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp,
                                       _ip, C.c_int]
     L.carma_kfilter_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _ip, C.c_int]
+    L.carma_pt_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64,
+                               _dp, _dp]
+    L.carma_pt_create.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64]
+    L.carma_pt_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.carma_pt_bind_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.carma_pt_start.argtypes = [C.c_void_p, _dp, C.c_int]
+    L.carma_pt_set_chains.argtypes = [C.c_void_p, _dp, _dp]
+    L.carma_pt_get_chains.argtypes = [C.c_void_p, _dp, _dp]
+    L.carma_pt_iterate.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    L.carma_pt_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp]
+    L.carma_pt_stats.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+    L.carma_pt_iterations_done.argtypes = [C.c_void_p]
+    L.carma_pt_iterations_done.restype = C.c_long
     return L
 
 
@@ -62,7 +75,9 @@ EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
     "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logprior", "carma_kfilter_carma",
-    "carma_kfilter_car1",
+    "carma_kfilter_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
+    "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
+    "carma_pt_stats", "carma_pt_iterations_done",
 ]
 
 
@@ -164,6 +179,67 @@ class Context:
     def logprior(self, theta):
         theta = as_f64(theta)
         return lib.carma_logprior(self._h, ptr(theta))
+
+    # ---- parallel-tempering sampler (RunCarmaSampler / RunCar1Sampler on the GPU) ----------------
+    def pt_run(self, ntemps, nreplicas, sample_size, burnin, thin=1, init=None, seed=0):
+        """Whole Sampler::Run; returns (samples[R][S][d], logposts[R][S]) of the coldest chains."""
+        init_a = as_f64(init) if init is not None and len(init) else None
+        samples = np.empty((nreplicas, sample_size, self.d))
+        logposts = np.empty((nreplicas, sample_size))
+        check(lib.carma_pt_run(self._h, int(ntemps), int(nreplicas), int(sample_size), int(burnin), int(thin),
+                               ptr(init_a) if init_a is not None else None,
+                               init_a.size if init_a is not None else 0, C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                               ptr(samples), ptr(logposts)), "carma_pt_run")
+        self._pt_shape = (int(nreplicas), int(ntemps))
+        return samples, logposts
+
+    def pt_create(self, ntemps, nreplicas, adapt_iters, seed=0, temperatures=None):
+        tt = as_f64(temperatures) if temperatures is not None else None
+        check(lib.carma_pt_create(self._h, int(ntemps), int(nreplicas), ptr(tt) if tt is not None else None,
+                                  int(adapt_iters), C.c_uint64(int(seed) & (2 ** 64 - 1))), "carma_pt_create")
+        self._pt_shape = (int(nreplicas), int(ntemps))
+
+    def pt_shard(self, ntemps_global, slot0, replica0):
+        check(lib.carma_pt_shard(self._h, int(ntemps_global), int(slot0), int(replica0)), "carma_pt_shard")
+
+    def pt_bind_state(self, d_theta_ptr, d_logpost_ptr):
+        check(lib.carma_pt_bind_state(self._h, C.c_void_p(d_theta_ptr), C.c_void_p(d_logpost_ptr)),
+              "carma_pt_bind_state")
+
+    def pt_start(self, init=None):
+        init_a = as_f64(init) if init is not None and len(init) else None
+        check(lib.carma_pt_start(self._h, ptr(init_a) if init_a is not None else None,
+                                 init_a.size if init_a is not None else 0), "carma_pt_start")
+
+    def pt_set_chains(self, theta, logpost=None):
+        R, T = self._pt_shape
+        theta = as_f64(theta).reshape(R, T, self.d)
+        lp = as_f64(logpost).reshape(R, T) if logpost is not None else None
+        check(lib.carma_pt_set_chains(self._h, ptr(theta), ptr(lp) if lp is not None else None), "carma_pt_set_chains")
+
+    def pt_get_chains(self):
+        R, T = self._pt_shape
+        theta, lp = np.empty((R, T, self.d)), np.empty((R, T))
+        check(lib.carma_pt_get_chains(self._h, ptr(theta), ptr(lp)), "carma_pt_get_chains")
+        return theta, lp
+
+    def pt_iterate(self, niter, do_exchange=True):
+        check(lib.carma_pt_iterate(self._h, int(niter), int(bool(do_exchange))), "carma_pt_iterate")
+
+    def pt_sample(self, nsamples, thin=1):
+        R, T = self._pt_shape
+        samples, logposts = np.empty((R, nsamples, self.d)), np.empty((R, nsamples))
+        check(lib.carma_pt_sample(self._h, int(nsamples), int(thin), ptr(samples), ptr(logposts)), "carma_pt_sample")
+        return samples, logposts
+
+    def pt_stats(self, reset=False):
+        R, T = self._pt_shape
+        acc, swp = np.empty((R, T)), np.empty((R, T))
+        check(lib.carma_pt_stats(self._h, ptr(acc), ptr(swp), int(bool(reset))), "carma_pt_stats")
+        return acc, swp
+
+    def pt_iterations_done(self):
+        return lib.carma_pt_iterations_done(self._h)
 
 
 def kfilter_carma(time, y, yerr, sigsqr, omega, ma, device=None):

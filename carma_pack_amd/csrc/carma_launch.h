@@ -15,4 +15,10 @@ hipError_t launch_kfilter_carma(int p, const double* om_re_im, const double* ma,
 hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* series, int n, double* mean, double* var,
                                hipStream_t st);
 
+// one chunk of the persistent PT sampler kernel (carma_pt.hip)
+hipError_t launch_pt(int p, const PtLaunch& L, const double4* series, const Prior& pr, const double* temps,
+                     double* theta, double* logpost, double* chol, unsigned* naccept, unsigned* nswap, double* samples,
+                     double* sample_lp, hipStream_t st);
+size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out);
+
 }  // namespace carma

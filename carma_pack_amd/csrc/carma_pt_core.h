@@ -1,0 +1,130 @@
+// carma_pt_core.h -- one Robust-Adaptive-Metropolis step of one tempered chain, and the
+// adjacent-temperature exchange sweep.  Shared by carma_pt.hip (gfx950) and the CPU lane
+// emulator (tests/emu, test harness only).
+//
+// Reference (file:line under /root/reference):
+//   AdaptiveMetro::DoStep / Accept   src/steps.cpp:36-107   (Vihola 2012 RAM, target 0.25, gamma 2/3)
+//   CholUpdateR1                     src/steps.cpp:111-131
+//   StudentProposal(8,1)             src/carmcmc.cpp:139, src/random.cpp:158
+//   ExchangeStep::DoStep             src/include/steps.hpp:318-362
+// A chain is worked on by the same G-lane group that evaluates its log-density; vectors of
+// length d (<= 16) are spread over the lanes (component j lives in lane j % G) and live in the
+// chain's scratch (LDS on the GPU): th[d], thn[d], z[d], v[d], R[d*d] (upper triangular,
+// row-major, Sigma = R^T R as arma::chol returns, steps.cpp:32).
+#pragma once
+#include "carma_core.h"
+#include "carma_rng.h"
+
+namespace carma {
+
+struct ChainScratch {
+    double* th;    // current value
+    double* thn;   // proposal
+    double* z;     // unit proposal
+    double* v;     // scaled proposal / rank-1 vector
+    double* R;     // Cholesky factor of the proposal scale matrix
+};
+
+// src/steps.cpp:111-131, columns j > k spread over the lanes.
+template <int G, class GrpT>
+CARMA_DEV void chol_update_r1(const GrpT& g, int d, double* R, double* v, bool downdate)
+{
+    const int r = g.lane();
+    const double sign = downdate ? -1.0 : 1.0;
+    for (int k = 0; k < d; k++) {
+        const double Rkk = R[k * d + k], vk = v[k];
+        const double rr = sqrt(Rkk * Rkk + sign * vk * vk);
+        const double c = rr / Rkk, s = vk / Rkk;
+        g.sync();                      // everybody has read R_kk, v_k
+        if (r == 0) R[k * d + k] = rr;
+        for (int j = k + 1 + r; j < d; j += G) {
+            double Rkj = (R[k * d + j] + sign * s * v[j]) / c;
+            R[k * d + j] = Rkj;
+            v[j] = c * v[j] - s * Rkj;
+        }
+        g.sync();
+    }
+}
+
+// One RAM step (steps.cpp:60-107).  lp = stored log-posterior of the chain (updated on accept).
+// Returns true when the proposal was accepted.
+template <int P, int G, class GrpT>
+CARMA_DEV bool ram_step(const GrpT& g, const ChainScratch& cs, int d, int q, double temperature, uint64_t iter,
+                        int maxiter, const RngKey& key, const double4* __restrict__ series, int n, const Prior& pr,
+                        double* lp)
+{
+    const int r = g.lane();
+    // unit proposal z_k ~ t_8 (steps.cpp:65-69)
+    for (int k = r; k < d; k += G) cs.z[k] = rng_student_t8(key, iter, (uint32_t)k);
+    g.sync();
+    // scaled = R^T z ; new = old + scaled (steps.cpp:72-73)
+    double znorm2 = 0.0;
+    for (int k = 0; k < d; k++) znorm2 += cs.z[k] * cs.z[k];
+    for (int j = r; j < d; j += G) {
+        double acc = 0.0;
+        for (int k = 0; k <= j; k++) acc += cs.R[k * d + j] * cs.z[k];
+        cs.v[j] = acc;
+        cs.thn[j] = cs.th[j] + acc;
+    }
+    g.sync();
+    // Accept (steps.cpp:36-56): one Kalman log-density of the proposal, tempered
+    double ll;
+    if constexpr (P == 1)
+        ll = logdensity_car1(cs.thn, series, n, pr);
+    else
+        ll = logdensity_carma<P, G>(g, cs.thn, q, series, n, pr, 0);
+    double alpha = (ll - *lp) / temperature;
+    bool accept = false;
+    const bool fin = (alpha - alpha) == 0.0;   // finite
+    if (!fin) {
+        alpha = 0.0;                           // steps.cpp:41-46
+    } else {
+        const double u = rng_uniform(key, iter, RNG_ACCEPT, 0);
+        alpha = fmin(exp(alpha), 1.0);
+        accept = u < alpha;
+    }
+    if (accept) {                              // parameter_.Save(new_value) (steps.cpp:77)
+        for (int j = r; j < d; j += G) cs.th[j] = cs.thn[j];
+        *lp = ll;
+    }
+    // adaptation of the scale matrix while niter < maxiter (steps.cpp:82-99)
+    if ((long)iter < (long)maxiter) {
+        const double step = fmin(1.0, (double)d / pow((double)iter, 2.0 / 3.0));   // iter = 0 -> 1
+        const double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(znorm2);
+        for (int j = r; j < d; j += G) cs.v[j] *= fac;
+        g.sync();
+        chol_update_r1<G>(g, d, cs.R, cs.v, alpha < 0.25);
+    }
+    g.sync();
+    return accept;
+}
+
+// ExchangeStep sweep hot -> cold over the T chains of one replica (steps.hpp:318-362), executed by
+// ONE lane.  th = T vectors of length d, `stride` doubles apart; lp = [T], temps = [T]
+// (temps[i] > temps[i-1]); chain_base is the global
+// slot of chain 0 of this replica (the swap uniform is keyed by the hotter chain's global slot so a
+// ladder split across GPUs draws the same number on both sides).
+CARMA_DEV void exchange_sweep(int T, int d, int stride, double* th, double* lp, const double* temps, RngKey key,
+                              uint32_t chain_base, uint64_t iter, unsigned* nswap)
+{
+    for (int i = T - 1; i > 0; i--) {
+        const double this_lp = lp[i], other_lp = lp[i - 1];
+        double alpha = 1.0 / temps[i] * (other_lp - this_lp) + 1.0 / temps[i - 1] * (this_lp - other_lp);
+        key.chain = chain_base + (uint32_t)i;
+        const double u = rng_uniform(key, iter, RNG_SWAP, 0);
+        alpha = fmin(exp(alpha), 1.0);
+        if (!((alpha - alpha) == 0.0)) alpha = 0.0;
+        if (u < alpha) {
+            for (int j = 0; j < d; j++) {
+                double tmp = th[i * stride + j];
+                th[i * stride + j] = th[(i - 1) * stride + j];
+                th[(i - 1) * stride + j] = tmp;
+            }
+            lp[i] = other_lp;
+            lp[i - 1] = this_lp;
+            nswap[i]++;
+        }
+    }
+}
+
+}  // namespace carma

@@ -1,5 +1,451 @@
-// placeholder until the sampler lands
+// carma_pt_host.hip -- host side of the parallel-tempering sampler behind the C ABI:
+// temperature ladder, initial proposal covariance, starting values, chunked launches of the
+// persistent kernel (carma_pt.hip), sample collection.
+// Reference: RunCarmaSampler / RunCar1Sampler (src/carmcmc.cpp:30-177), Sampler::Run
+// (src/samplers.cpp:57-115), StartingValue routines (src/carpack.cpp:38-81,175-230,268-311,416-477).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <vector>
+
+#include "../../include/carma_mi355.h"
 #include "carma_host.h"
+
 namespace carma {
-void pt_state_free(Ctx* c) { (void)c; }
+
+struct PtState {
+    int T = 0, R = 0;
+    unsigned T_global = 0, slot0 = 0, replica0 = 0;
+    int maxiter = 0;
+    uint64_t seed = 0;
+    unsigned long long iter = 0;
+    std::vector<double> temps;
+    double *d_temps = nullptr, *d_theta = nullptr, *d_lp = nullptr, *d_chol = nullptr;
+    bool ext_state = false;
+    unsigned *d_nacc = nullptr, *d_nswap = nullptr;
+    double *d_samples = nullptr, *d_slp = nullptr;
+    long cap = 0;
+    bool started = false;
+    unsigned long long stat_iters = 0;
+};
+
+void pt_state_free(Ctx* c)
+{
+    PtState* s = c->pt;
+    if (!s) return;
+    if (s->d_temps) (void)hipFree(s->d_temps);
+    if (!s->ext_state) {
+        if (s->d_theta) (void)hipFree(s->d_theta);
+        if (s->d_lp) (void)hipFree(s->d_lp);
+    }
+    if (s->d_chol) (void)hipFree(s->d_chol);
+    if (s->d_nacc) (void)hipFree(s->d_nacc);
+    if (s->d_nswap) (void)hipFree(s->d_nswap);
+    if (s->d_samples) (void)hipFree(s->d_samples);
+    if (s->d_slp) (void)hipFree(s->d_slp);
+    delete s;
+    c->pt = nullptr;
 }
+
+static double pop_var(const std::vector<double>& y)
+{
+    // src/carmcmc.cpp:85-88
+    double sum = 0, sq = 0;
+    for (double v : y) {
+        sum += v;
+        sq += v * v;
+    }
+    const double mean = sum / y.size();
+    return sq / y.size() - mean * mean;
+}
+
+static double sample_var(const std::vector<double>& y)   // arma::var
+{
+    double mean = 0;
+    for (double v : y) mean += v;
+    mean /= y.size();
+    double s = 0;
+    for (double v : y) s += (v - mean) * (v - mean);
+    return s / (y.size() - 1);
+}
+
+static int chunk_iters(const Ctx* c)
+{
+    // keep one launch around a quarter of a second: ~0.8 us per datum per iteration for p >= 5
+    const double est_us = std::max(1.0, 0.8 * c->n * (c->p >= 5 ? 1.0 : 0.5));
+    return (int)std::max(1.0, std::min(4096.0, 250000.0 / est_us));
+}
+
+// One draw from the reference's starting-value distribution.
+static void draw_start(const Ctx* c, std::mt19937_64& rng, double* theta)
+{
+    const int n = c->n, p = c->p, q = c->q;
+    std::normal_distribution<double> norm(0.0, 1.0);
+    std::uniform_real_distribution<double> unif(0.0, 1.0);
+    auto scaled_inv_chisq = [&](int dof, double ssqr) {       // src/random.cpp:180-186
+        std::chi_squared_distribution<double> chi(dof);
+        return ssqr / chi(rng) * (double)dof;
+    };
+    double ymean = 0;
+    for (double v : c->y) ymean += v;
+    ymean /= n;
+    const double yvar = scaled_inv_chisq(n - 1, sample_var(c->y));
+    const double mu = ymean + std::sqrt(yvar) / n * norm(rng);
+    double scale = scaled_inv_chisq((int)c->pr.measerr_dof, 1.0);
+    scale = std::max(std::min(scale, 1.99), 0.51);
+    theta[0] = std::sqrt(yvar);
+    theta[1] = scale;
+    theta[2] = mu;
+    if (p == 1) {
+        // CAR1::StartingValue (src/carpack.cpp:38-81)
+        std::vector<double> dt(n - 1);
+        for (int i = 1; i < n; i++) dt[i - 1] = c->t[i] - c->t[i - 1];
+        std::sort(dt.begin(), dt.end());
+        const double med = (dt.size() % 2) ? dt[dt.size() / 2] : 0.5 * (dt[dt.size() / 2 - 1] + dt[dt.size() / 2]);
+        double lw = -1.0 * std::log(med * (1.0 + 49.0 * unif(rng)));
+        lw = std::min(lw, c->pr.max_freq);     // sic (carpack.cpp:56)
+        theta[3] = lw;
+        return;
+    }
+    // CARp::StartingAR (src/carpack.cpp:268-311)
+    const double min_freq = c->pr.min_freq, max_freq = c->pr.max_freq;
+    const int nc = (p + 1) / 2;
+    std::vector<double> cent(nc), width(nc);
+    for (int i = 0; i < nc; i++) cent[i] = std::exp(std::log(max_freq / min_freq) * unif(rng) + std::log(min_freq));
+    std::sort(cent.begin(), cent.end(), std::greater<double>());
+    for (int i = 0; i < nc; i++) width[i] = std::exp(std::log(max_freq / min_freq) * unif(rng) + std::log(min_freq));
+    if (p % 2 == 1) {
+        cent[p / 2] = 0.0;
+        const double lo = std::log(min_freq), hi = std::log(cent[p / 2 - 1]);
+        width[p / 2] = std::exp(lo + (hi - lo) * unif(rng));
+    }
+    for (int i = 0; i < p / 2; i++) {
+        const double re = -2.0 * M_PI * width[i], im = 2.0 * M_PI * cent[i];
+        theta[3 + 2 * i] = std::log(re * re + im * im);
+        theta[3 + 2 * i + 1] = std::log(-2.0 * re);
+    }
+    if (p % 2 == 1) theta[3 + p - 1] = std::log(2.0 * M_PI * width[p / 2]);
+    // CARMA::StartingMA (src/carpack.cpp:515-519)
+    for (int i = 0; i < q; i++) theta[3 + p + i] = std::fabs(norm(rng));
+}
+
+static int pt_launch_chunks(Ctx* c, long niter, int do_exchange, int thin, long* save_offset)
+{
+    PtState* s = c->pt;
+    const int chunk0 = chunk_iters(c);
+    long left = niter;
+    while (left > 0) {
+        long ch = std::min<long>(left, chunk0);
+        if (thin > 0) {
+            ch = std::max<long>(thin, (ch / thin) * thin);   // whole thinning intervals per launch
+            ch = std::min(ch, left);
+        }
+        PtLaunch L{};
+        L.d = c->d;
+        L.q = c->q;
+        L.n = c->n;
+        L.T = s->T;
+        L.R = s->R;
+        L.maxiter = s->maxiter;
+        L.iter0 = s->iter;
+        L.niter = (int)ch;
+        L.do_exchange = do_exchange;
+        L.save_thin = thin;
+        L.save_offset = save_offset ? *save_offset : 0;
+        L.sample_cap = s->cap;
+        L.seed0 = (unsigned)(s->seed & 0xffffffffu);
+        L.seed1 = (unsigned)(s->seed >> 32);
+        L.slot0 = s->slot0;
+        L.T_global = s->T_global;
+        L.replica0 = s->replica0;
+        hipError_t e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta,
+                                 s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->stream);
+        if (e != hipSuccess) return hip_fail(e, "launch pt kernel");
+        s->iter += ch;
+        s->stat_iters += ch;
+        if (thin > 0 && save_offset) *save_offset += ch / thin;
+        left -= ch;
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(e, "pt kernel");
+    return CARMA_OK;
+}
+
+}  // namespace carma
+
+using namespace carma;
+
+extern "C" {
+
+int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* temperatures, int adapt_iters, uint64_t seed)
+{
+    if (!h || ntemps < 1 || nreplicas < 1 || adapt_iters < 0) {
+        set_error("carma_pt_create: bad argument");
+        return CARMA_EINVAL;
+    }
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    int nthr = 0;
+    const size_t lds = pt_lds_bytes(c->p, c->d, ntemps, &nthr);
+    if (nthr > 1024 || lds > 160 * 1024) {
+        set_error("carma_pt_create: %d temperatures do not fit one workgroup (threads %d, LDS %zu B)", ntemps, nthr, lds);
+        return CARMA_EINVAL;
+    }
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    pt_state_free(c);
+    PtState* s = new PtState();
+    c->pt = s;
+    s->T = ntemps;
+    s->R = nreplicas;
+    s->T_global = ntemps;
+    s->maxiter = adapt_iters;
+    s->seed = seed;
+    s->temps.resize(ntemps);
+    for (int i = 0; i < ntemps; i++) {
+        // src/carmcmc.cpp:92-95: exp(linspace(0, ln 100, nwalkers))
+        if (temperatures)
+            s->temps[i] = temperatures[i];
+        else
+            s->temps[i] = (ntemps == 1) ? 1.0 : std::exp(std::log(100.0) * (double)i / (double)(ntemps - 1));
+    }
+    const int d = c->d;
+    const size_t nchain = (size_t)ntemps * nreplicas;
+    // initial proposal covariance (src/carmcmc.cpp:132-136 / :50-54): diag(1e-4), [0,0]=2 var^2/n, [2,2]=var/n
+    const double var = pop_var(c->y);
+    std::vector<double> R0((size_t)d * d, 0.0);
+    for (int i = 0; i < d; i++) R0[(size_t)i * d + i] = 0.01;
+    R0[0] = std::sqrt(2.0 * var * var / c->n);
+    R0[(size_t)2 * d + 2] = std::sqrt(var / c->n);
+    std::vector<double> chol(nchain * d * d);
+    for (size_t k = 0; k < nchain; k++) std::memcpy(&chol[k * d * d], R0.data(), sizeof(double) * d * d);
+    e = hipMalloc(&s->d_temps, sizeof(double) * ntemps);
+    if (e == hipSuccess) e = hipMalloc(&s->d_theta, sizeof(double) * nchain * d);
+    if (e == hipSuccess) e = hipMalloc(&s->d_lp, sizeof(double) * nchain);
+    if (e == hipSuccess) e = hipMalloc(&s->d_chol, sizeof(double) * nchain * d * d);
+    if (e == hipSuccess) e = hipMalloc(&s->d_nacc, sizeof(unsigned) * nchain);
+    if (e == hipSuccess) e = hipMalloc(&s->d_nswap, sizeof(unsigned) * nchain);
+    if (e == hipSuccess) e = hipMemcpy(s->d_temps, s->temps.data(), sizeof(double) * ntemps, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_chol, chol.data(), sizeof(double) * chol.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(s->d_nacc, 0, sizeof(unsigned) * nchain);
+    if (e == hipSuccess) e = hipMemset(s->d_nswap, 0, sizeof(unsigned) * nchain);
+    if (e != hipSuccess) {
+        int rc = hip_fail(e, "carma_pt_create");
+        pt_state_free(c);
+        return rc;
+    }
+    return CARMA_OK;
+}
+
+int carma_pt_shard(carma_ctx* h, int ntemps_global, int slot0, int replica0)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt) return CARMA_EINVAL;
+    PtState* s = reinterpret_cast<Ctx*>(h)->pt;
+    if (ntemps_global < s->T || slot0 < 0 || slot0 + s->T > ntemps_global || replica0 < 0) {
+        set_error("carma_pt_shard: bad shard");
+        return CARMA_EINVAL;
+    }
+    s->T_global = (unsigned)ntemps_global;
+    s->slot0 = (unsigned)slot0;
+    s->replica0 = (unsigned)replica0;
+    return CARMA_OK;
+}
+
+int carma_pt_bind_state(carma_ctx* h, double* d_theta, double* d_logpost)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || !d_theta || !d_logpost) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    const size_t nchain = (size_t)s->T * s->R;
+    hipError_t e = hipMemcpy(d_theta, s->d_theta, sizeof(double) * nchain * c->d, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_logpost, s->d_lp, sizeof(double) * nchain, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_bind_state");
+    if (!s->ext_state) {
+        (void)hipFree(s->d_theta);
+        (void)hipFree(s->d_lp);
+    }
+    s->d_theta = d_theta;
+    s->d_lp = d_logpost;
+    s->ext_state = true;
+    return CARMA_OK;
+}
+
+int carma_pt_set_chains(carma_ctx* h, const double* theta, const double* logpost)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || !theta) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    const size_t nchain = (size_t)s->T * s->R;
+    std::vector<double> lp(nchain);
+    if (logpost) {
+        std::memcpy(lp.data(), logpost, sizeof(double) * nchain);
+    } else {
+        int rc = carma_logdensity_batch(h, theta, (int)nchain, 0, lp.data());
+        if (rc != CARMA_OK) return rc;
+    }
+    hipError_t e = hipMemcpy(s->d_theta, theta, sizeof(double) * nchain * c->d, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_lp, lp.data(), sizeof(double) * nchain, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_set_chains");
+    s->started = true;
+    return CARMA_OK;
+}
+
+int carma_pt_get_chains(carma_ctx* h, double* theta, double* logpost)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    const size_t nchain = (size_t)s->T * s->R;
+    hipError_t e = hipSuccess;
+    if (theta) e = hipMemcpy(theta, s->d_theta, sizeof(double) * nchain * c->d, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && logpost) e = hipMemcpy(logpost, s->d_lp, sizeof(double) * nchain, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_get_chains");
+    return CARMA_OK;
+}
+
+int carma_pt_start(carma_ctx* h, const double* init, int ninit)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt) {
+        set_error("carma_pt_start: call carma_pt_create first");
+        return CARMA_EINVAL;
+    }
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    const int d = c->d;
+    const size_t nchain = (size_t)s->T * s->R;
+    std::vector<double> theta(nchain * d), lp(nchain, -std::numeric_limits<double>::infinity());
+    std::vector<char> done(nchain, 0);
+    // user-provided start is honoured only if its length is d and its posterior is finite
+    // (src/samplers.cpp:75-93, src/carpack.cpp:479-490)
+    if (init && ninit == d) {
+        double l0 = 0;
+        int rc = carma_logdensity_batch(h, init, 1, 0, &l0);
+        if (rc != CARMA_OK) return rc;
+        if (std::isfinite(l0)) {
+            for (size_t k = 0; k < nchain; k++) {
+                std::memcpy(&theta[k * d], init, sizeof(double) * d);
+                lp[k] = l0;
+                done[k] = 1;
+            }
+        }
+    }
+    std::mt19937_64 rng(s->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull + ((uint64_t)s->replica0 << 20) + s->slot0);
+    for (int round = 0; round < 4000; round++) {
+        std::vector<size_t> todo;
+        for (size_t k = 0; k < nchain; k++)
+            if (!done[k]) todo.push_back(k);
+        if (todo.empty()) break;
+        std::vector<double> cand(todo.size() * d), out(todo.size());
+        for (size_t i = 0; i < todo.size(); i++) draw_start(c, rng, &cand[i * d]);
+        int rc = carma_logdensity_batch(h, cand.data(), (int)todo.size(), 0, out.data());
+        if (rc != CARMA_OK) return rc;
+        for (size_t i = 0; i < todo.size(); i++) {
+            if (std::isfinite(out[i])) {
+                std::memcpy(&theta[todo[i] * d], &cand[i * d], sizeof(double) * d);
+                lp[todo[i]] = out[i];
+                done[todo[i]] = 1;
+            }
+        }
+    }
+    for (size_t k = 0; k < nchain; k++) {
+        if (!done[k]) {
+            set_error("carma_pt_start: no finite starting value found for chain %zu", k);
+            return CARMA_EINVAL;
+        }
+    }
+    return carma_pt_set_chains(h, theta.data(), lp.data());
+}
+
+int carma_pt_iterate(carma_ctx* h, long niter, int do_exchange)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || niter < 0) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c->pt->started) {
+        set_error("carma_pt_iterate: chains have no starting values");
+        return CARMA_EINVAL;
+    }
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return pt_launch_chunks(c, niter, do_exchange, 0, nullptr);
+}
+
+int carma_pt_sample(carma_ctx* h, int nsamples, int thin, double* samples, double* logposts)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || nsamples < 1 || thin < 1 || !samples || !logposts) {
+        set_error("carma_pt_sample: bad argument");
+        return CARMA_EINVAL;
+    }
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    if (!s->started) {
+        set_error("carma_pt_sample: chains have no starting values");
+        return CARMA_EINVAL;
+    }
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (s->cap < nsamples) {
+        if (s->d_samples) (void)hipFree(s->d_samples);
+        if (s->d_slp) (void)hipFree(s->d_slp);
+        s->d_samples = s->d_slp = nullptr;
+        s->cap = 0;
+        e = hipMalloc(&s->d_samples, sizeof(double) * (size_t)s->R * nsamples * c->d);
+        if (e == hipSuccess) e = hipMalloc(&s->d_slp, sizeof(double) * (size_t)s->R * nsamples);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(samples)");
+        s->cap = nsamples;
+    }
+    long off = 0;
+    const long cap_saved = s->cap;
+    s->cap = nsamples;   // stride of this call's output
+    int rc = pt_launch_chunks(c, (long)nsamples * thin, 1, thin, &off);
+    if (rc == CARMA_OK) {
+        e = hipMemcpy(samples, s->d_samples, sizeof(double) * (size_t)s->R * nsamples * c->d, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(logposts, s->d_slp, sizeof(double) * (size_t)s->R * nsamples, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "D2H samples");
+    }
+    s->cap = cap_saved;
+    return rc;
+}
+
+int carma_pt_stats(carma_ctx* h, double* accept_rate, double* swap_rate, int reset)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    const size_t nchain = (size_t)s->T * s->R;
+    std::vector<unsigned> a(nchain), w(nchain);
+    hipError_t e = hipMemcpy(a.data(), s->d_nacc, sizeof(unsigned) * nchain, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(w.data(), s->d_nswap, sizeof(unsigned) * nchain, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_stats");
+    const double it = s->stat_iters ? (double)s->stat_iters : 1.0;
+    for (size_t k = 0; k < nchain; k++) {
+        if (accept_rate) accept_rate[k] = a[k] / it;
+        if (swap_rate) swap_rate[k] = w[k] / it;   // entry i = swaps between temperature i and i-1
+    }
+    if (reset) {
+        (void)hipMemset(s->d_nacc, 0, sizeof(unsigned) * nchain);
+        (void)hipMemset(s->d_nswap, 0, sizeof(unsigned) * nchain);
+        s->stat_iters = 0;
+    }
+    return CARMA_OK;
+}
+
+long carma_pt_iterations_done(const carma_ctx* h)
+{
+    if (!h || !reinterpret_cast<const Ctx*>(h)->pt) return CARMA_EINVAL;
+    return (long)reinterpret_cast<const Ctx*>(h)->pt->iter;
+}
+
+int carma_pt_run(carma_ctx* h, int ntemps, int nreplicas, int sample_size, int burnin, int thin, const double* init,
+                 int ninit, uint64_t seed, double* samples, double* logposts)
+{
+    int rc = carma_pt_create(h, ntemps, nreplicas, nullptr, burnin, seed);
+    if (rc == CARMA_OK) rc = carma_pt_start(h, init, ninit);
+    if (rc == CARMA_OK) rc = carma_pt_iterate(h, burnin, 1);                    // Sampler::Run burn-in (samplers.cpp:97)
+    if (rc == CARMA_OK) rc = carma_pt_sample(h, sample_size, thin, samples, logposts);   // :101-108
+    return rc;
+}
+
+}  // extern "C"

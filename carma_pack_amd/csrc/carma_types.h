@@ -8,4 +8,21 @@ struct Prior {
     double max_stdev, max_freq, min_freq, measerr_dof;
 };
 
+// Arguments of one launch of the persistent PT kernel.
+struct PtLaunch {
+    int d, q, n;                 // parameter dimension, MA order, series length
+    int T, R;                    // temperatures / replicas held by THIS launch (= this GPU)
+    int maxiter;                 // RAM adapts while iteration < maxiter (= burn-in, carmcmc.cpp:149)
+    unsigned long long iter0;    // global index of the first iteration of this launch
+    int niter;                   // iterations to run
+    int do_exchange;             // run the local hot->cold swap sweep after every iteration
+    int save_thin;               // 0: do not save; k: save chain 0 after every k-th iteration
+    long save_offset;            // index of the first sample this launch writes
+    long sample_cap;             // samples per replica the output buffers can hold
+    unsigned seed0, seed1;
+    unsigned slot0;              // global temperature index of local slot 0   (ladder sharding)
+    unsigned T_global;           // global number of temperatures
+    unsigned replica0;           // global index of local replica 0            (replica sharding)
+};
+
 }  // namespace carma

@@ -70,6 +70,15 @@ struct Grp {
     }
     CARMA_DEV double4 peek(int j) const { return xch[gbase() + j]; }
     CARMA_DEV void done_reading() const { __builtin_amdgcn_wave_barrier(); }
+
+    // Make this wave's earlier LDS/global stores visible to its later loads (other lanes of the
+    // same wave).  Hardware executes one wave's memory instructions in order; this is only a
+    // compiler fence.
+    CARMA_DEV void sync() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 };
 
 }  // namespace carma

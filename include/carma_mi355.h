@@ -93,6 +93,45 @@ int carma_kfilter_car1(const double* time, const double* y, const double* yerr, 
                        double sigsqr, double omega, double* mean, double* var, int* n_out,
                        int device);
 
+/*
+ * Parallel-tempered Robust-Adaptive-Metropolis sampler == RunCarmaSampler / RunCar1Sampler
+ * (src/carmcmc.cpp:30-177; bindings run_mcmc_car1 / run_mcmc_carma, boost_python_wrapper.cpp:76-77)
+ * with every chain advanced on the GPU by one persistent kernel (carma_pt.hip).
+ *
+ *   ntemps     number of tempered chains per ladder = the reference's `nwalkers`; default ladder
+ *              T_i = 100^(i/(ntemps-1)) (carmcmc.cpp:92-95), or `temperatures[ntemps]` ascending.
+ *   nreplicas  number of INDEPENDENT ladders run side by side (the reference runs exactly one);
+ *              each yields its own stream of coldest-chain samples.
+ *   adapt_iters  the RAM proposal adapts while iteration < adapt_iters (= burn-in, carmcmc.cpp:149).
+ *   seed       counter-based RNG key; runs are reproducible (the reference seeds with time(NULL)).
+ *
+ * carma_pt_run does the whole Sampler::Run (src/samplers.cpp:57-115): starting values (user
+ * `init` honoured only when ninit == d and its posterior is finite, else drawn from the
+ * reference's starting-value distribution until finite), `burnin` iterations, then sample_size
+ * saves of the coldest chain every `thin` iterations.  samples = [nreplicas][sample_size][d],
+ * logposts = [nreplicas][sample_size] (host pointers).
+ * The finer-grained calls expose the same machinery for chunked runs, benchmarks and for a
+ * temperature ladder sharded across GPUs (carma_pt_shard gives the local block its global
+ * temperature / replica indices so RNG streams and swap decisions line up across ranks;
+ * carma_pt_bind_state lets the caller own the theta/logpost device buffers so that boundary
+ * chains can be exchanged with RCCL send/recv between iterations).
+ */
+int carma_pt_run(carma_ctx* h, int ntemps, int nreplicas, int sample_size, int burnin, int thin,
+                 const double* init, int ninit, uint64_t seed, double* samples, double* logposts);
+
+int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* temperatures,
+                    int adapt_iters, uint64_t seed);
+int carma_pt_shard(carma_ctx* h, int ntemps_global, int slot0, int replica0);
+int carma_pt_bind_state(carma_ctx* h, double* d_theta /* [R][T][d] */, double* d_logpost /* [R][T] */);
+int carma_pt_start(carma_ctx* h, const double* init, int ninit);
+int carma_pt_set_chains(carma_ctx* h, const double* theta /* [R][T][d] */, const double* logpost /* [R][T] or NULL */);
+int carma_pt_get_chains(carma_ctx* h, double* theta, double* logpost);
+int carma_pt_iterate(carma_ctx* h, long niter, int do_exchange);
+int carma_pt_sample(carma_ctx* h, int nsamples, int thin, double* samples, double* logposts);
+/* acceptance rate per chain [R][T]; swap_rate[r][i] = accepted swaps between temperatures i and i-1 */
+int carma_pt_stats(carma_ctx* h, double* accept_rate, double* swap_rate, int reset);
+long carma_pt_iterations_done(const carma_ctx* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,3 +95,95 @@ int emu_logdensity_car1(const double* theta, int B, const double* series, int n,
     return 0;
 }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Sampler emulation: T chains of one replica, each on its own G-thread team, global barrier around
+// the exchange sweep -- the same structure as k_pt in carma_pt.hip.
+#include "../../carma_pack_amd/csrc/carma_pt_core.h"
+
+template <int P>
+struct PtGroupOf {
+    static constexpr int value = P <= 1 ? 4 : (P <= 2 ? 2 : (P <= 4 ? 4 : 8));
+};
+
+template <int P>
+static void pt_run(int q, const double4* series, int n, const Prior& pr, int T, const double* temps, int maxiter,
+                   long niter, int save_from, int thin, uint32_t seed0, uint32_t seed1, double* theta, double* lp,
+                   double* chol, int d, double* samples, double* sample_lp, unsigned* nacc, unsigned* nswap)
+{
+    constexpr int G = PtGroupOf<P>::value;
+    const int per = 4 * d + d * d;
+    std::vector<double> base((size_t)T * per, 0.0);
+    for (int c = 0; c < T; c++) {
+        for (int j = 0; j < d; j++) base[(size_t)c * per + j] = theta[c * d + j];
+        for (int j = 0; j < d * d; j++) base[(size_t)c * per + 4 * d + j] = chol[c * d * d + j];
+    }
+    std::vector<EmuShared> sh(T);
+    for (auto& s : sh) s.bar.n = G;
+    SpinBarrier all;
+    all.n = T * G;
+    std::vector<std::thread> th;
+    for (int c = 0; c < T; c++) {
+        for (int r = 0; r < G; r++) {
+            th.emplace_back([&, c, r]() {
+                Grp<G> g{&sh[c], r};
+                ChainScratch cs;
+                cs.th = &base[(size_t)c * per];
+                cs.thn = cs.th + d;
+                cs.z = cs.th + 2 * d;
+                cs.v = cs.th + 3 * d;
+                cs.R = cs.th + 4 * d;
+                RngKey key{seed0, seed1, (uint32_t)c};
+                double mylp = lp[c];
+                for (long it = 0; it < niter; it++) {
+                    bool acc = ram_step<P, G>(g, cs, d, q, temps[c], (uint64_t)it, maxiter, key, series, n, pr, &mylp);
+                    if (r == 0) {
+                        lp[c] = mylp;
+                        if (acc) nacc[c]++;
+                    }
+                    all.wait();
+                    if (c == 0 && r == 0) {
+                        if (T > 1) exchange_sweep(T, d, per, base.data(), lp, temps, key, 0u, (uint64_t)it, nswap);
+                        if (it >= save_from && ((it - save_from + 1) % thin) == 0) {
+                            long s = (it - save_from + 1) / thin - 1;
+                            for (int j = 0; j < d; j++) samples[s * d + j] = base[j];
+                            sample_lp[s] = lp[0];
+                        }
+                    }
+                    all.wait();
+                    mylp = lp[c];
+                }
+            });
+        }
+    }
+    for (auto& t : th) t.join();
+    for (int c = 0; c < T; c++) {
+        for (int j = 0; j < d; j++) theta[c * d + j] = base[(size_t)c * per + j];
+        for (int j = 0; j < d * d; j++) chol[c * d * d + j] = base[(size_t)c * per + 4 * d + j];
+    }
+}
+
+extern "C" int emu_pt_run(int p, int q, const double* series, int n, const double* prior, int T, const double* temps,
+                          int maxiter, long niter, int save_from, int thin, unsigned seed0, unsigned seed1, double* theta,
+                          double* lp, double* chol, double* samples, double* sample_lp, unsigned* nacc, unsigned* nswap)
+{
+    Prior pr{prior[0], prior[1], prior[2], prior[3]};
+    const double4* s4 = reinterpret_cast<const double4*>(series);
+    const int d = p == 1 ? 4 : 3 + p + q;
+    switch (p) {
+        case 1: pt_run<1>(q, s4, n, pr, T, temps, maxiter, niter, save_from, thin, seed0, seed1, theta, lp, chol, d, samples, sample_lp, nacc, nswap); break;
+        case 2: pt_run<2>(q, s4, n, pr, T, temps, maxiter, niter, save_from, thin, seed0, seed1, theta, lp, chol, d, samples, sample_lp, nacc, nswap); break;
+        case 3: pt_run<3>(q, s4, n, pr, T, temps, maxiter, niter, save_from, thin, seed0, seed1, theta, lp, chol, d, samples, sample_lp, nacc, nswap); break;
+        default: return -1;
+    }
+    return 0;
+}
+
+extern "C" void emu_rng_draws(unsigned seed0, unsigned seed1, unsigned chain, long n, double* t8, double* u)
+{
+    RngKey key{seed0, seed1, chain};
+    for (long i = 0; i < n; i++) {
+        t8[i] = rng_student_t8(key, (uint64_t)i, 0);
+        u[i] = rng_uniform(key, (uint64_t)i, RNG_ACCEPT, 0);
+    }
+}

@@ -20,6 +20,8 @@ static inline double4 make_double4(double a, double b, double c, double d) { ret
 using std::exp;
 using std::fabs;
 using std::fmax;
+using std::fmin;
+using std::pow;
 using std::frexp;
 using std::hypot;
 using std::log;
@@ -91,6 +93,7 @@ struct Grp {
     }
     double4 peek(int j) const { return sh->xch[j]; }
     void done_reading() const { sh->bar.wait(); }
+    void sync() const { sh->bar.wait(); }
 };
 
 // run fn(grp) on G lane-threads

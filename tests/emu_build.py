@@ -68,3 +68,35 @@ def kfilter_carma(t, y, yerr, sigsqr, omega, ma):
     lib().emu_kfilter_carma.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int, _dp, _dp, _dp]
     rc = lib().emu_kfilter_carma(p, _p(re), _p(im), _p(mav), float(sigsqr), _p(s), t.size, _p(mean), _p(var), _p(ll))
     return mean, var, ll[0], rc
+
+
+def pt_run(t, y, yerr, p, q, prior, temps, maxiter, niter, save_from, thin, seed, theta0, lp0, chol0):
+    """Emulated persistent PT kernel for ONE replica (structure of k_pt in carma_pt.hip)."""
+    s = pack_series(t, y, yerr)
+    d = 4 if p == 1 else 3 + p + q
+    T = len(temps)
+    temps = np.ascontiguousarray(temps, dtype=float)
+    theta = np.ascontiguousarray(theta0, dtype=float).reshape(T, d).copy()
+    lp = np.ascontiguousarray(lp0, dtype=float).copy()
+    chol = np.ascontiguousarray(chol0, dtype=float).reshape(T, d, d).copy()
+    ns = max(0, (niter - save_from) // thin)
+    samples, slp = np.zeros((ns, d)), np.zeros(ns)
+    nacc, nswap = np.zeros(T, dtype=np.uint32), np.zeros(T, dtype=np.uint32)
+    pr = np.array(list(prior) + [50.0])
+    up = C.POINTER(C.c_uint)
+    L = lib()
+    L.emu_pt_run.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_long, C.c_int, C.c_int,
+                             C.c_uint, C.c_uint, _dp, _dp, _dp, _dp, _dp, up, up]
+    rc = L.emu_pt_run(p, q, _p(s), t.size, _p(pr), T, _p(temps), maxiter, niter, save_from, thin, seed & 0xffffffff,
+                      seed >> 32, _p(theta), _p(lp), _p(chol), _p(samples), _p(slp), nacc.ctypes.data_as(up),
+                      nswap.ctypes.data_as(up))
+    assert rc == 0
+    return dict(theta=theta, lp=lp, chol=chol, samples=samples, logpost=slp, nacc=nacc, nswap=nswap)
+
+
+def rng_draws(seed, chain, n):
+    t8, u = np.empty(n), np.empty(n)
+    L = lib()
+    L.emu_rng_draws.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_long, _dp, _dp]
+    L.emu_rng_draws(seed & 0xffffffff, seed >> 32, chain, n, _p(t8), _p(u))
+    return t8, u

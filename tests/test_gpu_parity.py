@@ -139,13 +139,15 @@ def test_random_batch_vs_oracle_config2(cpa, readme):
     th = theta_batch(rng, 1024, 5, 3, t, y, theta_center=g["theta"][0])
     ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_var_stdev(y))
     m = orc.OracleModel(t, y, yerr, 5, 3)
+    from mp_truth import loglik_truth
+    arb = lambda i: loglik_truth(t, y, yerr, th[i], 5, 3)[0]   # noqa: E731
     got = ctx.logdensity(th)
     want = m.logdensity_batch(th, nthreads=8)
-    worst = assert_parity(got, want, RTOL, "config2")
+    worst = assert_parity(got, want, RTOL, "config2", arbiter=arb)
     assert np.isfinite(want).sum() > 600
     got = ctx.logdensity(th, ignore_prior=True)
     want = m.logdensity_batch(th, ignore_prior=True, nthreads=8)
-    worst2 = assert_parity(got, want, RTOL, "config2 ignore_prior")
+    worst2 = assert_parity(got, want, RTOL, "config2 ignore_prior", arbiter=arb)
     print("config2 worst rel err %.2e / %.2e" % (worst, worst2))
 
 
@@ -217,7 +219,9 @@ def test_long_series_vs_oracle(cpa, p, q, n):
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(40)])
     ctx = cpa.Context(t, y, yerr, p, q)
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    from mp_truth import loglik_truth
+    arb = lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0]   # noqa: E731
     got = ctx.logdensity(th, ignore_prior=True)
     want = m.logdensity_batch(th, ignore_prior=True, nthreads=8)
-    worst = assert_parity(got, want, RTOL, "p=%d q=%d n=%d" % (p, q, n))
+    worst = assert_parity(got, want, RTOL, "p=%d q=%d n=%d" % (p, q, n), arbiter=arb, max_arbitrated=3)
     print("p=%d q=%d n=%d worst rel err %.2e" % (p, q, n, worst))

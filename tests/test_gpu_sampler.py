@@ -1,0 +1,123 @@
+"""GPU tests of the on-device parallel-tempering RAM sampler (through the C ABI).
+
+Trajectory parity with the reference is impossible (its RNG is seeded with time(NULL),
+src/random.cpp:20), so the sampler is pinned the way the reference's own tests pin it:
+  * stored log-posterior == LogDensity(sample) (carma_unit_tests.cpp:783-1114), checked against
+    the CPU oracle;
+  * posterior recovery of the true parameters (carma_unit_tests.cpp:1319-1376, 1549-1657);
+  * plus agreement with the CPU lane emulator of the very same kernel core on identical seeds."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import carma_pack_amd
+    assert carma_pack_amd._lib.lib.carma_device_count() >= 1
+    return carma_pack_amd
+
+
+def _pop_stdev(y):
+    return 10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)
+
+
+def test_car1_sampler_recovers_truth(cpa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "car1_n100.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ms = _pop_stdev(y)
+    ctx = cpa.Context(t, y, yerr, 1, 0, max_stdev=ms)
+    R, nb, ns = 32, 3000, 3000
+    samples, lp = ctx.pt_run(1, R, ns, nb, 1, seed=7)
+    assert samples.shape == (R, ns, 4) and np.all(np.isfinite(lp))
+    m = orc.OracleModel(t, y, yerr, 1, max_stdev=ms)
+    flat = samples[:, ::211].reshape(-1, 4)
+    np.testing.assert_allclose(lp[:, ::211].reshape(-1), m.logdensity_batch(flat), rtol=1e-10)
+    truth = np.array([2.3, 1.0, 0.0, np.log(0.01)])
+    pooled = samples.reshape(-1, 4)
+    z = np.abs(pooled.mean(0) - truth) / pooled.std(0)
+    assert np.all(z[[0, 2, 3]] < 3.0), z
+    # independent replicas agree with each other: between-replica spread of the mean is small
+    rm = samples.mean(1)
+    assert np.all(rm.std(0) < pooled.std(0))
+    acc, _ = ctx.pt_stats()
+    assert np.all((acc > 0.15) & (acc < 0.45)), acc
+
+
+def test_carma53_tempered_sampler(cpa, golden_dir):
+    """BASELINE config 3 shape at test size: 16 temperatures x 8 replicas on the README series."""
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ms = _pop_stdev(y)
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms)
+    T, R, nb, ns = 16, 8, 1500, 500
+    samples, lp = ctx.pt_run(T, R, ns, nb, 1, seed=3)
+    assert ctx.pt_iterations_done() == nb + ns
+    m = orc.OracleModel(t, y, yerr, 5, 3, max_stdev=ms)
+    flat = samples[:, ::37].reshape(-1, 11)
+    np.testing.assert_allclose(lp[:, ::37].reshape(-1), m.logdensity_batch(flat), rtol=1e-10)
+    th, l2 = ctx.pt_get_chains()
+    np.testing.assert_allclose(l2.reshape(-1), m.logdensity_batch(th.reshape(-1, 11)), rtol=1e-10)
+    acc, swp = ctx.pt_stats()
+    assert np.all(acc > 0.03) and np.all(acc < 0.6), acc
+    assert swp[:, 1:].mean() > 0.02, swp
+    # the sampler climbed to the posterior mode region (true-parameter log-posterior within reach)
+    ll_true = m.logdensity(g["theta"][0])
+    assert lp[:, -100:].max() > ll_true - 15.0
+    # reproducible from the seed, different with another seed
+    s2, _ = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms).pt_run(T, R, 20, 50, 1, seed=3)
+    s3, _ = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms).pt_run(T, R, 20, 50, 1, seed=3)
+    s4, _ = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms).pt_run(T, R, 20, 50, 1, seed=4)
+    assert np.array_equal(s2, s3) and not np.array_equal(s2, s4)
+
+
+def test_user_init_and_thinning(cpa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_stdev(y))
+    init = g["theta"][0]
+    ctx.pt_create(4, 2, adapt_iters=0, seed=1)
+    ctx.pt_start(init)
+    th, lp = ctx.pt_get_chains()
+    assert np.all(th == init) and np.allclose(lp, ctx.logdensity(init))
+    # wrong-length init is ignored, as Sampler::Run does (samplers.cpp:75-76)
+    ctx.pt_start(init[:5])
+    th, _ = ctx.pt_get_chains()
+    assert not np.all(th == init)
+    s, l = ctx.pt_sample(10, thin=7)
+    assert s.shape == (2, 10, 11) and ctx.pt_iterations_done() == 70
+
+
+def test_gpu_matches_emulator_trajectory(cpa):
+    """Same seeds, same start, no adaptation noise: the GPU kernel and the CPU lane emulator of the
+    same core must walk the same trajectory (accept decisions identical; values to rounding)."""
+    import emu_build as emu
+    rng = np.random.default_rng(8)
+    n = 60
+    t = np.cumsum(rng.uniform(0.5, 1.5, n))
+    y = np.sin(t / 3.0) + 0.3 * rng.standard_normal(n)
+    yerr = np.full(n, 0.3)
+    p, q, T = 2, 1, 3
+    ms = _pop_stdev(y)
+    ctx = cpa.Context(t, y, yerr, p, q, max_stdev=ms)
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ms)
+    ctx.pt_create(T, 1, adapt_iters=200, seed=2024)
+    ctx.pt_start(None)
+    th0, lp0 = ctx.pt_get_chains()
+    niter = 300
+    ctx.pt_iterate(niter)
+    th1, lp1 = ctx.pt_get_chains()
+    var = np.mean(y * y) - np.mean(y) ** 2
+    R0 = np.eye(6) * 0.01
+    R0[0, 0] = np.sqrt(2 * var * var / n)
+    R0[2, 2] = np.sqrt(var / n)
+    temps = np.exp(np.linspace(0, np.log(100.0), T))
+    out = emu.pt_run(t, y, yerr, p, q, (m.max_stdev, m.max_freq, m.min_freq), temps, 200, niter, niter, 1, 2024,
+                     th0[0], lp0[0], np.tile(R0, (T, 1, 1)))
+    np.testing.assert_allclose(th1[0], out["theta"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(lp1[0], out["lp"], rtol=1e-8)
