@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="evals per step (BASELINE config 2: 1024)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-mcmc", action="store_true", help="skip the secondary MCMC iterations/s leg")
+    ap.add_argument("--mcmc-iters", type=int, default=2000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +117,35 @@ def main():
     kdur_ms = np.array([a.elapsed_time(b) for a, b in evs])
     kernel_ms = float(np.mean(kdur_ms))
 
+    # ---- secondary metric: MCMC iterations/s, BASELINE configs[2] shape ------------------------
+    # 16 temperatures x 64 independent ladders ("walkers") per GPU, persistent PT kernel; one
+    # iteration = every chain does one RAM step (one Kalman eval) + one exchange sweep.
+    mcmc = None
+    if not args.no_mcmc:
+        T_, R_ = 16, 64
+        ctx.pt_create(T_, R_, adapt_iters=10 ** 9, seed=11 + rank)
+        ctx.pt_shard(T_, 0, rank * R_)
+        ctx.pt_start(None)
+        ctx.pt_iterate(100)
+        barrier()
+        tm0 = time.perf_counter()
+        ctx.pt_iterate(args.mcmc_iters)
+        barrier()
+        tm = time.perf_counter() - tm0
+        if dist is not None:
+            tt = torch.tensor([tm], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tm = float(tt.item())
+        acc_, swp_ = ctx.pt_stats()
+        mcmc = {
+            "metric": "MCMC iterations/s (each iteration advances every chain once)",
+            "iters_per_s": args.mcmc_iters / tm,
+            "chain_evals_per_s": world * T_ * R_ * args.mcmc_iters / tm,
+            "temperatures": T_, "replicas_per_gpu": R_, "iters": args.mcmc_iters,
+            "accept_rate": float(acc_.mean()), "swap_rate": float(swp_[:, 1:].mean()),
+            "config": "configs[2] shape: CARMA(5,3), n=270, 16 temperatures x 64 walkers per GPU, RAM adapting",
+        }
+
     if rank == 0:
         value = world * B * args.steps / elapsed
         bytes_per_eval = 24 * n + 8 * d + 8
@@ -160,6 +191,8 @@ def main():
             },
             "finite_in_last_batch": n_finite,
         }
+        if mcmc is not None:
+            res["mcmc"] = mcmc
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(t, y, yerr, p, q, max_stdev, pool_h[0], args.cpu_seconds)
         print(json.dumps(res), flush=True)
