@@ -1,0 +1,450 @@
+"""carma_pack's Python API (src/carmcmc/carma_pack.py in the reference) on top of the MI355X path.
+
+Same public names and call signatures -- ``CarmaModel`` (``run_mcmc``, ``get_mle``, ``choose_order``),
+``CarmaSample`` / ``Car1Sample`` (``get_samples``, ``parameters``, ``mle``, derived quantities),
+``get_ar_roots``, ``power_spectrum``, ``carma_variance``, ``car1_process``, ``carma_process`` -- but a
+fresh implementation: derived quantities are vectorised numpy, every log-density goes through one
+batched launch, the sampler runs on the GPU, and ``run_mcmc``/``get_mle`` can use many independent
+replicas at once (``nreplicas``).  Plotting bodies and ``predict``/``simulate``/``assess_fit`` (which
+need the device Predict kernel) are not part of the hot path.
+"""
+import numpy as np
+from scipy.optimize import minimize
+
+from . import _carmcmc as carmcmcLib
+
+__all__ = ["CarmaModel", "CarmaSample", "Car1Sample", "MCMCSample", "get_ar_roots", "power_spectrum",
+           "carma_variance", "car1_process", "carma_process"]
+
+
+# ------------------------------------------------------------------------------------------------
+# free functions (reference: carma_pack.py:1038-1259)
+def get_ar_roots(qpo_width, qpo_centroid):
+    """Lorentzian widths/centroids -> roots of the AR polynomial, -2 pi (width + i centroid) with the
+    conjugate appended for every centroid > 1e-10 and one extra real root when there is one more width
+    than centroids (reference :1038-1059)."""
+    qpo_width, qpo_centroid = np.atleast_1d(qpo_width), np.atleast_1d(qpo_centroid)
+    roots = []
+    for w, c in zip(qpo_width, qpo_centroid):
+        roots.append(w + 1j * c)
+        if c > 1e-10:
+            roots.append(w - 1j * c)
+    if qpo_width.size - qpo_centroid.size == 1:
+        roots.append(qpo_width[-1] + 0j)
+    return -2.0 * np.pi * np.array(roots)
+
+
+def power_spectrum(freq, sigma, ar_coef, ma_coefs=(1.0,)):
+    """sigma^2 |beta(2 pi i f)|^2 / |alpha(2 pi i f)|^2 (reference :1062-1081); ar_coef highest order
+    first (np.poly convention), ma_coefs lowest order first."""
+    s = 2.0j * np.pi * np.asarray(freq, dtype=float)
+    num = np.polyval(np.asarray(ma_coefs)[::-1], s)
+    den = np.polyval(np.asarray(ar_coef), s)
+    return sigma ** 2 * np.abs(num) ** 2 / np.abs(den) ** 2
+
+
+def carma_variance(sigsqr, ar_roots, ma_coefs=(1.0,), lag=0.0):
+    """Autocovariance of a CARMA(p,q) process at `lag` (reference :1084-1123 == CARp::Variance,
+    src/carpack.cpp:377-409)."""
+    r = np.asarray(ar_roots, dtype=complex)
+    p = r.size
+    beta = np.zeros(p)
+    beta[:len(ma_coefs)] = ma_coefs
+    powers = np.arange(p)
+    total = 0.0 + 0.0j
+    for k in range(p):
+        others = np.delete(r, k)
+        denom = -2.0 * r[k].real * np.prod((others - r[k]) * (np.conj(others) + r[k]))
+        num = np.sum(beta * r[k] ** powers) * np.sum(beta * (-r[k]) ** powers) * np.exp(r[k] * abs(lag))
+        total += num / denom
+    return sigsqr * total.real
+
+
+def car1_process(time, sigsqr, tau, rng=None):
+    """Exact Ornstein-Uhlenbeck draw at the given times (reference :1126-1146)."""
+    rng = np.random if rng is None else rng
+    time = np.asarray(time, dtype=float)
+    var = sigsqr * tau / 2.0
+    y = np.empty(time.size)
+    y[0] = np.sqrt(var) * rng.standard_normal()
+    rho = np.exp(-np.diff(time) / tau)
+    eps = rng.standard_normal(time.size - 1)
+    for i in range(1, time.size):
+        y[i] = rho[i - 1] * y[i - 1] + np.sqrt(var * (1.0 - rho[i - 1] ** 2)) * eps[i - 1]
+    return y
+
+
+def _rotated_system(sigsqr, ar_roots, ma_coefs):
+    """Diagonalised state space of kfilter.cpp:138-172: returns (b, V) with V Hermitian."""
+    r = np.asarray(ar_roots, dtype=complex)
+    p = r.size
+    E = np.vander(r, p, increasing=True).T           # E[i, j] = r_j ** i
+    e = np.zeros(p, dtype=complex)
+    e[-1] = 1.0
+    J = np.linalg.solve(E, e)
+    beta = np.zeros(p)
+    beta[:len(ma_coefs)] = ma_coefs
+    b = beta @ E
+    V = -sigsqr * np.outer(J, np.conj(J)) / (r[:, None] + np.conj(r)[None, :])
+    return b, V
+
+
+def carma_process(time, sigsqr, ar_roots, ma_coefs=(1.0,), rng=None):
+    """Draw a CARMA(p,q) path at the (sorted) times by sequential conditional simulation: each value
+    is drawn from its one-step predictive distribution (same construction as reference :1148-1259,
+    written with the D = P - V recursion used by the device kernel)."""
+    rng = np.random if rng is None else rng
+    r = np.asarray(ar_roots, dtype=complex)
+    time = np.sort(np.asarray(time, dtype=float))
+    if r.size == 1:
+        return car1_process(time, sigsqr, -1.0 / r.real.item(), rng)
+    b, V = _rotated_system(sigsqr, r, ma_coefs)
+    c = V @ np.conj(b)
+    s0 = float(np.real(b @ c))
+    p = r.size
+    D = np.zeros((p, p), dtype=complex)
+    x = np.zeros(p, dtype=complex)
+    y = np.empty(time.size)
+    var, mean = s0, 0.0
+    y[0] = rng.normal(mean, np.sqrt(var))
+    innov = y[0] - mean
+    u = c.copy()
+    for k in range(1, time.size):
+        rho = np.exp(r * (time[k] - time[k - 1]))
+        x = rho * (x + u * (innov / var))
+        D = np.outer(rho, np.conj(rho)) * (D - np.outer(u, np.conj(u)) / var)
+        w = D @ np.conj(b)
+        u = w + c
+        var = s0 + float(np.real(b @ w))
+        mean = float(np.real(b @ x))
+        y[k] = rng.normal(mean, np.sqrt(var))
+        innov = y[k] - mean
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+class MCMCSample(object):
+    """Minimal sample container (the reference's samplers.MCMCSample holds the same `_samples` dict;
+    its plotting/diagnostic methods are outside the hot path)."""
+
+    def __init__(self, logpost=None, trace=None):
+        self._samples = {}
+        if trace is not None:
+            self.generate_from_trace(trace)
+        if logpost is not None:
+            self.set_logpost(logpost)
+
+    def get_samples(self, name):
+        return self._samples[name].copy()
+
+    def set_logpost(self, logpost):
+        self._samples["logpost"] = np.asarray(logpost)
+
+    def newaxis(self):
+        for k, v in self._samples.items():
+            if v.ndim == 1:
+                self._samples[k] = v[:, np.newaxis]
+
+    def posterior_summaries(self, name):
+        s = self._samples[name]
+        out = dict(median=np.median(s, axis=0), mean=np.mean(s, axis=0), std=np.std(s, axis=0),
+                   ci68=np.percentile(s, [16.0, 84.0], axis=0), ci95=np.percentile(s, [2.5, 97.5], axis=0))
+        return out
+
+
+def _roots_from_log_quads(logq):
+    """[nsamples, m] log quadratic-factor coefficients -> [nsamples, m] complex roots
+    (CARp::ARRoots ordering, src/carpack.cpp:137-172)."""
+    logq = np.atleast_2d(logq)
+    ns, m = logq.shape
+    quad = np.exp(logq)
+    roots = np.empty((ns, m), dtype=complex)
+    for i in range(m // 2):
+        q1, q2 = quad[:, 2 * i], quad[:, 2 * i + 1]
+        disc = q2 * q2 - 4.0 * q1
+        sq = np.where(disc > 0, np.sqrt(np.abs(disc)) + 0j, 1j * np.sqrt(np.abs(disc)))
+        roots[:, 2 * i] = -0.5 * (q2 + sq)
+        roots[:, 2 * i + 1] = -0.5 * (q2 - sq)
+    if m % 2:
+        roots[:, -1] = -quad[:, -1]
+    return roots
+
+
+def _poly_from_roots(roots):
+    """Vectorised np.poly over the first axis: [ns, m] roots -> [ns, m+1] coefficients, highest first."""
+    ns, m = roots.shape
+    coefs = np.zeros((ns, m + 1), dtype=complex)
+    coefs[:, 0] = 1.0
+    for i in range(m):
+        coefs[:, 1:i + 2] = coefs[:, 1:i + 2] - roots[:, i:i + 1] * coefs[:, 0:i + 1]
+    return coefs
+
+
+class CarmaSample(MCMCSample):
+    """MCMC samples of a CARMA(p,q) model plus derived quantities (reference :263-546)."""
+
+    def __init__(self, time, y, ysig, sampler, q=0, filename=None, MLE=None):
+        self.time, self.y, self.ysig, self.q = time, y, ysig, q
+        self._sampler = sampler
+        logpost = np.array(sampler.GetLogLikes())
+        trace = np.array(sampler.getSamples())
+        super(CarmaSample, self).__init__(logpost=logpost, trace=trace)
+        self._ar_roots()
+        self._ar_coefs()
+        self._ma_coefs(trace)
+        self._sigma_noise()
+        # "loglik": LogDensity with the prior bounds ignored -- still includes the measurement-error
+        # prior, exactly as the reference computes it (:305-315, carpack.hpp:173).  One batched launch.
+        if hasattr(sampler, "SetMLE"):
+            sampler.SetMLE(True)
+        self._samples["loglik"] = np.asarray(sampler.getLogDensityBatch(trace))
+        self.parameters = list(self._samples.keys())
+        self.newaxis()
+        self.mle = {}
+        if MLE is not None:
+            self.add_mle(MLE)
+
+    def generate_from_trace(self, trace):
+        self.p = trace.shape[1] - 3 - self.q          # sic: p inferred from the trace width (:415)
+        self._samples["var"] = trace[:, 0] ** 2
+        self._samples["measerr_scale"] = trace[:, 1]
+        self._samples["mu"] = trace[:, 2]
+        self._samples["quad_coefs"] = np.exp(trace[:, 3:self.p + 3])
+
+    def _ar_roots(self):
+        roots = _roots_from_log_quads(np.log(self._samples["quad_coefs"]))
+        self._samples["ar_roots"] = roots
+        self._samples["psd_centroid"] = np.abs(roots.imag) / (2.0 * np.pi)
+        self._samples["psd_width"] = -roots.real / (2.0 * np.pi)
+
+    def _ar_coefs(self):
+        self._samples["ar_coefs"] = _poly_from_roots(self._samples["ar_roots"]).real
+
+    def _ma_coefs(self, trace):
+        ns = trace.shape[0]
+        if self.q == 0:
+            self._samples["ma_coefs"] = np.ones((ns, 1))
+            return
+        roots = _roots_from_log_quads(trace[:, 3 + self.p:3 + self.p + self.q])
+        c = _poly_from_roots(roots)
+        self._samples["ma_coefs"] = (c / c[:, self.q:self.q + 1])[:, ::-1].real
+
+    def _sigma_noise(self):
+        roots, ma = self._samples["ar_roots"], self._samples["ma_coefs"]
+        ns, p = roots.shape
+        beta = np.zeros((ns, p))
+        beta[:, :ma.shape[1]] = ma
+        pw = np.arange(p)[None, :]
+        total = np.zeros(ns, dtype=complex)
+        for k in range(p):
+            rk = roots[:, k:k + 1]
+            others = np.delete(roots, k, axis=1)
+            denom = -2.0 * rk[:, 0].real * np.prod((others - rk) * (np.conj(others) + rk), axis=1)
+            num = np.sum(beta * rk ** pw, axis=1) * np.sum(beta * (-rk) ** pw, axis=1)
+            total += num / denom
+        self._samples["sigma"] = np.sqrt(self._samples["var"] / total.real)
+
+    def add_mle(self, MLE):
+        x = np.asarray(MLE.x, dtype=float)
+        roots = _roots_from_log_quads(x[None, 3:self.p + 3])[0]
+        self.mle = {"loglik": -MLE.fun, "var": x[0] ** 2, "measerr_scale": x[1], "mu": x[2], "ar_roots": roots,
+                    "psd_width": -roots.real / (2 * np.pi), "psd_cent": np.abs(roots.imag) / (2 * np.pi),
+                    "ar_coefs": np.poly(roots).real}
+        if self.q == 0:
+            self.mle["ma_coefs"] = 1.0
+        else:
+            mr = _roots_from_log_quads(x[None, 3 + self.p:])[0]
+            c = np.poly(mr)
+            self.mle["ma_coefs"] = np.real(c / c[self.q])[::-1]
+        unit = carma_variance(1.0, roots, np.atleast_1d(self.mle["ma_coefs"]))
+        self.mle["sigma"] = np.sqrt(self.mle["var"] / unit)
+
+    def DIC(self):
+        """Deviance information criterion from the stored log-likelihoods."""
+        loglik = self._samples["loglik"].ravel()
+        dev = -2.0 * loglik
+        return float(np.mean(dev) + 0.5 * np.var(dev))
+
+    def power_spectrum_band(self, percentile=68.0, nsamples=None, freq=None):
+        """Posterior median and credibility band of the PSD (numerical part of
+        plot_power_spectrum, reference :548-648)."""
+        sig, ar, ma = self._samples["sigma"], self._samples["ar_coefs"], self._samples["ma_coefs"]
+        n = sig.shape[0] if nsamples is None else min(nsamples, sig.shape[0])
+        idx = np.random.permutation(sig.shape[0])[:n]
+        if freq is None:
+            dt = np.diff(self.time)
+            freq = np.logspace(np.log10(1.0 / (self.time.max() - self.time.min())), np.log10(0.5 / dt.min()), 1000)
+        s = 2.0j * np.pi * freq
+        psd = np.empty((n, freq.size))
+        for i, k in enumerate(idx):
+            psd[i] = power_spectrum(freq, sig[k].item() if np.ndim(sig[k]) else sig[k], ar[k], ma[k])
+        lo, hi = (100.0 - percentile) / 2.0, 100.0 - (100.0 - percentile) / 2.0
+        return np.percentile(psd, lo, axis=0), np.percentile(psd, hi, axis=0), np.median(psd, axis=0), freq
+
+    def makeKalmanFilter(self, bestfit):
+        """KalmanFilterp for a point estimate ('map', 'median', 'mean' or a sample index),
+        reference :650-685."""
+        if bestfit == "map":
+            i = int(np.argmax(self._samples["logpost"]))
+            pick = lambda a: a[i]  # noqa: E731
+        elif bestfit == "median":
+            pick = lambda a: np.median(a, axis=0)  # noqa: E731
+        elif bestfit == "mean":
+            pick = lambda a: np.mean(a, axis=0)  # noqa: E731
+        else:
+            pick = lambda a: a[int(bestfit)]  # noqa: E731
+        sigsqr = float(np.ravel(pick(self._samples["sigma"]))[0]) ** 2
+        mu = float(np.ravel(pick(self._samples["mu"]))[0])
+        roots = np.atleast_1d(pick(self._samples["ar_roots"]))
+        ma = np.atleast_1d(pick(self._samples["ma_coefs"]))
+        omega = carmcmcLib.vecC(roots.tolist())
+        kf = carmcmcLib.KalmanFilterp(carmcmcLib.vecD(self.time), carmcmcLib.vecD(self.y - mu),
+                                      carmcmcLib.vecD(self.ysig), sigsqr, omega, carmcmcLib.vecD(ma.tolist()))
+        return kf, mu
+
+    def predict(self, time, bestfit="map"):
+        raise NotImplementedError("needs the device Predict kernel (SURVEY.md §8f rank 1)")
+
+    simulate = assess_fit = predict
+
+
+class Car1Sample(CarmaSample):
+    """Samples of a CAR(1) model (reference :866-1035): theta = (sigma_y, scale, mu, ln omega)."""
+
+    def __init__(self, time, y, ysig, sampler, filename=None):
+        self.time, self.y, self.ysig, self.q, self.p = time, y, ysig, 0, 1
+        self._sampler = sampler
+        logpost = np.array(sampler.GetLogLikes())
+        trace = np.array(sampler.getSamples())
+        MCMCSample.__init__(self, logpost=logpost, trace=trace)
+        self._samples["loglik"] = self._samples["logpost"] - np.array(
+            [sampler.getLogPrior(carmcmcLib.vecD(row)) for row in trace])
+        self.parameters = list(self._samples.keys())
+        self.newaxis()
+        self.mle = {}
+
+    def generate_from_trace(self, trace):
+        omega = np.exp(trace[:, 3])
+        self._samples["var"] = trace[:, 0] ** 2
+        self._samples["measerr_scale"] = trace[:, 1]
+        self._samples["mu"] = trace[:, 2]
+        self._samples["log_omega"] = trace[:, 3]
+        self._samples["ar_roots"] = (-omega)[:, None] + 0j
+        self._samples["psd_centroid"] = np.zeros((trace.shape[0], 1))
+        self._samples["psd_width"] = omega[:, None] / (2.0 * np.pi)
+        self._samples["ar_coefs"] = np.c_[np.ones_like(omega), omega]
+        self._samples["ma_coefs"] = np.ones((trace.shape[0], 1))
+        self._samples["sigma"] = np.sqrt(2.0 * omega * trace[:, 0] ** 2)
+
+
+# ------------------------------------------------------------------------------------------------
+def _vec(a):
+    v = carmcmcLib.vecD()
+    v.extend(np.asarray(a, dtype=float).tolist())
+    return v
+
+
+class CarmaModel(object):
+    """Statistical inference with a CARMA(p,q) model (reference :12-192)."""
+
+    def __init__(self, time, y, ysig, p=1, q=0):
+        time, y, ysig = np.asarray(time, dtype=float), np.asarray(y, dtype=float), np.asarray(ysig, dtype=float)
+        if not p > q:
+            raise ValueError("Order of AR polynomial, p, must be larger than order of MA polynomial, q.")
+        _, idx = np.unique(time, return_index=True)    # sorted, first occurrence of each time
+        self.time, self.y, self.ysig = time[idx], y[idx], ysig[idx]
+        self._time, self._y, self._ysig = _vec(self.time), _vec(self.y), _vec(self.ysig)
+        self.p, self.q = p, q
+        self.mcmc_sample = None
+
+    def run_mcmc(self, nsamples, nburnin=None, ntemperatures=None, nthin=1, init=None, nreplicas=1, seed=None):
+        """Parallel-tempered RAM sampler on the GPU; defaults as the reference (:53-89):
+        ntemperatures = max(10, p+q), nburnin = nsamples/2."""
+        if ntemperatures is None:
+            ntemperatures = max(10, self.p + self.q)
+        if nburnin is None:
+            nburnin = nsamples // 2
+        init = carmcmcLib.vecD() if init is None else _vec(init)
+        if self.p == 1:
+            cpp = carmcmcLib.run_mcmc_car1(nsamples, int(nburnin), self._time, self._y, self._ysig, nthin, init,
+                                           nreplicas=nreplicas, seed=seed)
+            sample = Car1Sample(self.time, self.y, self.ysig, cpp)
+        else:
+            cpp = carmcmcLib.run_mcmc_carma(nsamples, int(nburnin), self._time, self._y, self._ysig, self.p, self.q,
+                                            ntemperatures, False, nthin, init, nreplicas=nreplicas, seed=seed)
+            sample = CarmaSample(self.time, self.y, self.ysig, cpp, q=self.q)
+        self.mcmc_sample = sample
+        return sample
+
+    # -- maximum likelihood ---------------------------------------------------------------------
+    def _mle_bounds(self, p, q):
+        """L-BFGS-B box of the reference (:219-240)."""
+        ysigma = self.y.std()
+        dt = np.diff(self.time)
+        max_freq, min_freq = 0.9 / dt.min(), 1.0 / (self.time.max() - self.time.min())
+        bnds = [(ysigma / 10.0, 10.0 * ysigma), (0.9, 1.1), (None, None)]
+        if p == 1:
+            bnds.append((np.log(min_freq), np.log(max_freq)))
+        else:
+            lo = np.log(min(min_freq ** 2, 2.0 * min_freq))
+            hi = np.log(max(max_freq ** 2, 2.0 * max_freq))
+            bnds += [(lo, hi)] * p + [(None, None)] * q
+        return bnds
+
+    def get_mle(self, p, q, ntrials=100, njobs=1, seed=None):
+        """Best of `ntrials` bounded L-BFGS-B fits started from short tempered MCMC runs
+        (reference :92-129,195-260).  The reference launches ntrials separate 26-iteration samplers
+        and calls the C++ log-density once per function evaluation; here ONE sampler call with
+        `ntrials` independent replicas provides all starting points and each gradient is one
+        batched launch of 2d central-difference points.  `njobs` is accepted for compatibility."""
+        if p == 1:
+            proc = carmcmcLib.run_mcmc_car1(1, 25, self._time, self._y, self._ysig, 1, nreplicas=ntrials, seed=seed)
+        else:
+            proc = carmcmcLib.run_mcmc_carma(1, 25, self._time, self._y, self._ysig, p, q, 10, False, 1,
+                                             nreplicas=ntrials, seed=seed)
+            proc.SetMLE(True)
+        starts = proc.getAllSamples()[0][:, 0, :].copy()
+        bnds = self._mle_bounds(p, q)
+        rng = np.random.default_rng(seed)
+        d = starts.shape[1]
+
+        def fun_and_grad(x):
+            h = 1e-6 * np.maximum(1.0, np.abs(x))
+            pts = np.tile(x, (2 * d + 1, 1))
+            pts[1:d + 1] += np.diag(h)
+            pts[d + 1:] -= np.diag(h)
+            f = -np.asarray(proc.getLogDensityBatch(pts))
+            g = (f[1:d + 1] - f[d + 1:]) / (2.0 * h)
+            g[~np.isfinite(g)] = 0.0
+            return (f[0] if np.isfinite(f[0]) else 1e300), g
+
+        best = None
+        for x0 in starts:
+            x0 = x0.copy()
+            x0[1] = 1.0
+            for j, (lo, hi) in enumerate(bnds):
+                if lo is not None and not (lo <= x0[j] <= hi):
+                    x0[j] = rng.uniform(lo, hi)
+            res = minimize(fun_and_grad, x0, jac=True, method="L-BFGS-B", bounds=bnds)
+            if best is None or res.fun < best.fun:
+                best = res
+        return best
+
+    def choose_order(self, pmax, qmax=None, pqlist=None, njobs=1, ntrials=100, seed=None):
+        """Minimise AICc over a (p,q) grid (reference :131-192); sets self.p, self.q."""
+        if pmax < 1:
+            raise ValueError("Order of AR polynomial must be at least 1.")
+        if qmax is None:
+            qmax = pmax - 1
+        if pqlist is None:
+            pqlist = [(p, q) for p in range(1, pmax + 1) for q in range(min(p, qmax + 1))]
+        MLEs = [self.get_mle(p, q, ntrials=ntrials, njobs=njobs, seed=seed) for p, q in pqlist]
+        AICc, best, best_aicc = [], MLEs[0], 1e300
+        n = self.time.size
+        for mle, (p, q) in zip(MLEs, pqlist):
+            k = 2 + p + q
+            a = 2.0 * k + 2.0 * mle.fun + 2.0 * k * (k + 1.0) / (n - k - 1.0)
+            AICc.append(a)
+            if a < best_aicc:
+                best, best_aicc, self.p, self.q = mle, a, p, q
+        return best, pqlist, AICc

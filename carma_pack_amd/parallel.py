@@ -1,0 +1,154 @@
+"""One-process-per-GPU sharding of the path over ``torch.distributed`` (backend "nccl" == RCCL over
+xGMI on the GPU box, "gloo" in the CPU test-suite).
+
+The path shards naturally: log-density evaluations and independent replicas need no
+data-path collective at all, and the only coupling inside one temperature ladder is the
+adjacent-temperature exchange (ExchangeStep, /root/reference/src/include/steps.hpp:318-362).
+
+  * ``shard_slice`` / ``sharded_logdensity`` -- split a batch of parameter vectors by rank, evaluate
+    locally, all-gather the results (the only collective; B doubles).
+  * ``LadderShard`` -- a ladder of T temperatures split into contiguous blocks, one block per rank
+    (BASELINE config 4: 8 temperatures on 8 GPUs).  Every rank advances its block with the
+    persistent kernel (local swaps inside the block included); then the chains on either side of a
+    rank boundary are exchanged point-to-point: (theta[d], logpost) for all R replicas, R*(d+1)
+    doubles each way (<= 20 KB: latency bound, never link bound).  Both sides compute the SAME
+    Metropolis decision from a counter-based uniform keyed by the hotter chain's global slot
+    (``philox_uniform`` reproduces carma_rng.h bit for bit), so no decision is communicated.
+    Boundaries alternate even/odd per iteration so a rank that holds a single temperature never has
+    both of its boundaries active at once (deterministic even-odd parallel tempering).
+"""
+import numpy as np
+
+RNG_PROPOSAL, RNG_ACCEPT, RNG_SWAP = 0, 1, 2
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+_MASK = 0xFFFFFFFF
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Scalar Philox4x32-10, identical to carma_pack_amd/csrc/carma_rng.h."""
+    for _ in range(10):
+        p0, p1 = _M0 * c0, _M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> 32, p0 & _MASK, p1 >> 32, p1 & _MASK
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & _MASK, lo1, (hi0 ^ c3 ^ k1) & _MASK, lo0
+        k0, k1 = (k0 + _W0) & _MASK, (k1 + _W1) & _MASK
+    return c0, c1, c2, c3
+
+
+def philox_uniform(seed, chain, iteration, purpose, idx=0):
+    """rng_uniform(key{seed, chain}, iteration, purpose, idx) of carma_rng.h -> float in (0,1)."""
+    x = philox4x32_10(iteration & _MASK, (iteration >> 32) & _MASK, chain & _MASK, ((purpose << 24) | idx) & _MASK,
+                      seed & _MASK, (seed >> 32) & _MASK)
+    k = ((x[0] << 32) | x[1]) >> 11
+    return (k + 0.5) / 9007199254740992.0
+
+
+def shard_slice(n, rank, world):
+    """Contiguous, balanced split of range(n)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+def sharded_logdensity(evaluate, thetas, dist=None, device="cpu"):
+    """Every rank evaluates its slice of `thetas` ([B][d], identical on all ranks) with
+    `evaluate(local_thetas) -> [b]` (normally ``Context.logdensity``) and all ranks get the full [B]."""
+    import torch
+    thetas = np.ascontiguousarray(thetas, dtype=np.float64)
+    B = thetas.shape[0]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(evaluate(thetas))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sl = shard_slice(B, rank, world)
+    local = np.asarray(evaluate(thetas[sl]), dtype=np.float64)
+    width = (B + world - 1) // world
+    buf = torch.full((width,), float("nan"), dtype=torch.float64, device=device)
+    buf[:local.size] = torch.from_numpy(local).to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = np.empty(B)
+    for r in range(world):
+        s = shard_slice(B, r, world)
+        out[s] = parts[r][:s.stop - s.start].cpu().numpy()
+    return out
+
+
+def ladder_temperatures(ntemps, tmax=100.0):
+    """T_i = tmax^(i/(ntemps-1)) (src/carmcmc.cpp:92-95)."""
+    if ntemps == 1:
+        return np.ones(1)
+    return np.exp(np.linspace(0.0, np.log(tmax), ntemps))
+
+
+class LadderShard(object):
+    """One rank's contiguous block of a temperature ladder shared by all ranks.
+
+    `backend` is a ``carma_pack_amd.Context`` (or anything with pt_create / pt_shard / pt_start /
+    pt_iterate / pt_get_chains / pt_set_chains / d): the tests plug in a CPU stand-in."""
+
+    def __init__(self, backend, ntemps_global, nreplicas, adapt_iters, seed, dist, device="cpu"):
+        self.b, self.dist, self.device = backend, dist, device
+        self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        if ntemps_global < self.world:
+            raise ValueError("need at least one temperature per rank")
+        sl = shard_slice(ntemps_global, self.rank, self.world)
+        self.slot0, self.T_local, self.T_global = sl.start, sl.stop - sl.start, ntemps_global
+        self.R, self.seed, self.iteration = nreplicas, int(seed), 0
+        self.temps = ladder_temperatures(ntemps_global)
+        backend.pt_create(self.T_local, nreplicas, adapt_iters, seed=seed, temperatures=self.temps[sl])
+        backend.pt_shard(ntemps_global, self.slot0, 0)
+        self.nswap_boundary = 0
+        self.nprop_boundary = 0
+
+    def start(self, init=None):
+        self.b.pt_start(init)
+
+    def _exchange_boundary(self, upper):
+        """Exchange with the rank above (`upper`=True: my hottest chain vs its coldest) or below."""
+        import torch
+        dist = self.dist
+        peer = self.rank + 1 if upper else self.rank - 1
+        th, lp = self.b.pt_get_chains()                      # [R][Tl][d], [R][Tl]
+        mine = self.T_local - 1 if upper else 0
+        d = th.shape[2]
+        send = torch.from_numpy(np.concatenate([th[:, mine, :], lp[:, mine, None]], axis=1).copy()).to(self.device)
+        recv = torch.empty_like(send)
+        ops = [dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        other = recv.cpu().numpy()
+        hot_slot = self.slot0 + self.T_local if upper else self.slot0          # global slot of the hotter chain
+        t_hot, t_cold = self.temps[hot_slot], self.temps[hot_slot - 1]
+        my_lp, ot_lp = lp[:, mine], other[:, d]
+        hot_lp, cold_lp = (ot_lp, my_lp) if upper else (my_lp, ot_lp)
+        # ExchangeStep::DoStep (steps.hpp:331-339)
+        with np.errstate(over="ignore", invalid="ignore"):
+            alpha = np.minimum(np.exp((cold_lp - hot_lp) / t_hot + (hot_lp - cold_lp) / t_cold), 1.0)
+        alpha = np.where(np.isfinite(alpha), alpha, 0.0)
+        u = np.array([philox_uniform(self.seed, r * self.T_global + hot_slot, self.iteration, RNG_SWAP)
+                      for r in range(self.R)])
+        acc = u < alpha
+        if acc.any():
+            th[acc, mine, :] = other[acc, :d]
+            lp[acc, mine] = other[acc, d]
+            self.b.pt_set_chains(th, lp)
+        self.nswap_boundary += int(acc.sum())
+        self.nprop_boundary += self.R
+
+    def iterate(self, niter):
+        """niter x (local RAM steps + local swap sweep, then alternating even/odd boundary swaps)."""
+        for _ in range(int(niter)):
+            self.b.pt_iterate(1, do_exchange=True)
+            if self.world > 1:
+                parity = self.iteration & 1
+                # boundary k sits between rank k and rank k+1; even boundaries on even iterations
+                if self.rank + 1 < self.world and (self.rank & 1) == parity:
+                    self._exchange_boundary(upper=True)
+                if self.rank > 0 and ((self.rank - 1) & 1) == parity:
+                    self._exchange_boundary(upper=False)
+            self.iteration += 1
+
+    def coldest(self):
+        """(theta[R][d], logpost[R]) of temperature 0 -- meaningful on rank 0."""
+        th, lp = self.b.pt_get_chains()
+        return th[:, 0, :], lp[:, 0]

@@ -1,0 +1,136 @@
+"""GPU tests of the `_carmcmc` drop-in and the Python API; they read like the reference's own
+src/tests/testCarmcmc.py (n = 10 series, tiny samplers, binding overloads and defaults)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cm():
+    import carmcmc
+    assert carmcmc._carmcmc._lib.lib.carma_device_count() >= 1
+    return carmcmc
+
+
+@pytest.fixture(scope="module")
+def data(cm):
+    rng = np.random.RandomState(1)
+    npts = 10
+    x = 1.0 * np.arange(npts)
+    ar_roots = np.array([-0.06283185 - 1.25663706j, -0.06283185 + 1.25663706j, -0.02094395 - 0.25132741j,
+                         -0.02094395 + 0.25132741j, -0.03141593 + 0.j])
+    sigsqr = 0.00126811439419
+    y = cm.carma_process(x, sigsqr, ar_roots, rng=rng)
+    dy = np.sqrt(sigsqr) * np.ones(npts)
+    xv, yv, dv = cm.vecD(), cm.vecD(), cm.vecD()
+    xv.extend(x)
+    yv.extend(y)
+    dv.extend(dy)
+    return dict(x=x, y=y, dy=dy, xv=xv, yv=yv, dv=dv, nSample=100, nBurnin=10, nThin=1, nWalkers=2)
+
+
+def _first_sample_consistent(sampler, cm):
+    s = np.array(sampler.getSamples())
+    ll = np.array(sampler.GetLogLikes())
+    v = cm.vecD()
+    v.extend(s[0])
+    assert np.isfinite(sampler.getLogPrior(v))
+    assert abs(ll[0] - sampler.getLogDensity(v)) < 1e-7 * max(1.0, abs(ll[0]))    # testCarmcmc.py:46,69,104
+    return s, ll
+
+
+def test_car1(cm, data):
+    d = data
+    cpp = cm.run_mcmc_car1(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], d["nThin"], seed=1)
+    ps = cm.Car1Sample(d["x"], d["y"], d["dy"], cpp)
+    assert ps.p == 1
+    s, ll = _first_sample_consistent(cpp, cm)
+    assert s.shape == (100, 4)
+    # defaults / overloads (testCar1Defaults)
+    cm.run_mcmc_car1(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"])
+    guess = cpp.getSamples()[0]
+    cm.run_mcmc_car1(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], d["nThin"], guess)
+
+
+def test_carp(cm, data):
+    d = data
+    sampler = cm.run_mcmc_carma(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], 3, 0, d["nWalkers"], False,
+                                d["nThin"], seed=2)
+    assert isinstance(sampler, cm.CARp) and not isinstance(sampler, cm.CARMA)
+    ps = cm.CarmaSample(np.array(d["xv"]), np.array(d["yv"]), np.array(d["dv"]), sampler)
+    assert ps.p == 3
+    _first_sample_consistent(sampler, cm)
+
+
+def test_carp_defaults(cm, data):
+    d = data
+    cm.run_mcmc_carma(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], 3, 1, d["nWalkers"])
+    cm.run_mcmc_carma(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], 3, 1, d["nWalkers"], False)
+    s = cm.run_mcmc_carma(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], 3, 1, d["nWalkers"], False, 1)
+    guess = s.getSamples()[0]
+    s2 = cm.run_mcmc_carma(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], 3, 1, d["nWalkers"], False, 1, guess)
+    assert len(s2.getSamples()) == d["nSample"]
+    with pytest.raises(NotImplementedError):
+        cm.run_mcmc_carma(10, 5, d["xv"], d["yv"], d["dv"], 3, 1, 2, True)
+    with pytest.raises(RuntimeError):
+        cm.run_mcmc_carma(10, 5, d["xv"], d["yv"], d["dv"], 1, 0, 2)
+
+
+def test_carpq(cm, data):
+    d = data
+    sampler = cm.run_mcmc_carma(d["nSample"], d["nBurnin"], d["xv"], d["yv"], d["dv"], 3, 2, d["nWalkers"], False,
+                                d["nThin"], seed=3)
+    assert isinstance(sampler, cm.CARMA)
+    ps = cm.CarmaSample(np.array(d["xv"]), np.array(d["yv"]), np.array(d["dv"]), sampler)
+    assert ps.p == 3 + 2                # quirk: no q= -> p inferred from trace width (testCarmcmc.py:95)
+    _first_sample_consistent(sampler, cm)
+    ps2 = cm.CarmaSample(np.array(d["xv"]), np.array(d["yv"]), np.array(d["dv"]), sampler, q=2)
+    assert ps2.p == 3 and ps2.get_samples("ma_coefs").shape == (100, 3)
+    # loglik = log-density with bounds ignored (prior term kept): never below the bounded value
+    assert np.all(ps2.get_samples("loglik")[:, 0] >= ps2.get_samples("logpost")[:, 0] - 1e-9)
+
+
+def test_kalman_filters(cm, data):
+    d = data
+    kf = cm.KalmanFilter1(d["xv"], d["yv"], d["dv"], 1.0, 1.0)
+    kf.Filter()
+    var = np.array(kf.GetVar())
+    assert abs(var[0] - (1.0 / 2.0 + d["dy"][0] ** 2)) < 1e-12          # var0 = sigsqr/(2 omega) + yerr0^2
+    sampler = cm.run_mcmc_carma(50, 10, d["xv"], d["yv"], d["dv"], 4, 0, 2, False, 1, seed=4)
+    ps = cm.CarmaSample(np.array(d["xv"]), np.array(d["yv"]), np.array(d["dv"]), sampler)
+    sigsqr = float(ps._samples["sigma"][0][0] ** 2)
+    ma = cm.vecD()
+    ma.extend(np.append(ps._samples["ma_coefs"][0], np.zeros(3)))
+    omega = cm.vecC()
+    for i in range(ps.p):
+        omega.append(ps._samples["ar_roots"][0][i])
+    kfp = cm.KalmanFilterp(d["xv"], d["yv"], d["dv"], sigsqr, omega, ma)
+    kfp.Filter()
+    v = np.array(kfp.GetVar())
+    assert v.shape == (10,) and np.all(v > 0)
+    # var0 = process variance + yerr^2 (carma_unit_tests.cpp:443-444)
+    assert abs(v[0] - (float(ps._samples["var"][0][0]) + d["dy"][0] ** 2)) < 1e-9 * v[0]
+    kf2, mu = ps.makeKalmanFilter("map")
+    kf2.Filter()
+    assert len(kf2.GetMean()) == 10
+    with pytest.raises(NotImplementedError):
+        kfp.Predict(11.0)
+
+
+def test_carma_model_mcmc_and_mle(cm, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, e = g["t"], g["y"], g["yerr"]
+    model = cm.CarmaModel(t, y, e, p=3, q=1)
+    sample = model.run_mcmc(300, nburnin=300, nreplicas=4, seed=5)          # ntemperatures default max(10,p+q)
+    assert sample.get_samples("ar_roots").shape == (300, 3)
+    assert set(("logpost", "var", "measerr_scale", "mu", "quad_coefs", "ar_roots", "psd_centroid", "psd_width",
+                "ar_coefs", "ma_coefs", "sigma", "loglik")) <= set(sample.parameters)
+    all_s, all_lp = sample._sampler.getAllSamples()
+    assert all_s.shape == (4, 300, 7)
+    mle = model.get_mle(2, 0, ntrials=8, seed=6)
+    assert np.isfinite(mle.fun) and mle.x.size == 5
+    best, pqlist, aicc = model.choose_order(2, ntrials=4, seed=7)
+    assert pqlist == [(1, 0), (2, 0), (2, 1)] and len(aicc) == 3 and (model.p, model.q) in pqlist
+    sample.add_mle(mle) if sample.p == 2 else None

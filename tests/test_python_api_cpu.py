@@ -1,0 +1,118 @@
+"""CPU-only tests of the host-side Python mirror of carma_pack's API (derived quantities, free
+functions, container types); the compute path itself needs a GPU (tests/test_gpu_*.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import carma_pack_amd as cpa
+import carmcmc as cm
+import oracle as orc
+from carma_pack_amd import carma_pack as cp
+
+
+def test_alias_package_exports():
+    for name in ("vecD", "vecvecD", "vecC", "pairD", "CAR1", "CARp", "CARMA", "run_mcmc_car1", "run_mcmc_carma",
+                 "KalmanFilter1", "KalmanFilterp", "CarmaModel", "CarmaSample", "Car1Sample", "get_ar_roots",
+                 "power_spectrum", "carma_variance", "carma_process", "car1_process"):
+        assert hasattr(cm, name), name
+    v = cm.vecD()
+    v.extend([1.0, 2.0])
+    v.append(3.0)
+    assert len(v) == 3 and v[1] == 2.0
+    pr = cm.pairD()
+    pr.first, pr.second = 1.0, 2.0
+
+
+def test_variance_kat_and_roots(golden_dir):
+    s = json.load(open(os.path.join(golden_dir, "summary.json")))["variance_kat"]
+    om = cm.get_ar_roots(np.array([0.01, 0.01, 0.002]), np.array([0.2, 0.02]))
+    np.testing.assert_allclose(om.real, s["omega_re"], rtol=1e-15)
+    np.testing.assert_allclose(om.imag, s["omega_im"], rtol=1e-15)
+    v = cm.carma_variance(2.3 ** 2, om, s["ma"])
+    assert abs(v - 223003.230567) / 223003.230567 < 1e-8          # carma_unit_tests.cpp:1313-1316
+    for lag, ref in zip(s["lags"], s["lagged"]):
+        assert abs(cm.carma_variance(2.3 ** 2, om, s["ma"], lag=lag) - ref) / abs(ref) < 1e-12
+
+
+def test_derived_quantities_match_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    th = g["theta"]
+    roots = cp._roots_from_log_quads(th[:, 3:8])
+    np.testing.assert_allclose(roots, g["omega"], rtol=1e-13)
+    ma_roots = cp._roots_from_log_quads(th[:, 8:11])
+    c = cp._poly_from_roots(ma_roots)
+    ma = (c / c[:, 3:4])[:, ::-1].real
+    np.testing.assert_allclose(ma, g["ma"][:, :4], rtol=1e-12)
+    np.testing.assert_allclose(cp._poly_from_roots(roots)[3], np.poly(roots[3]), rtol=1e-12)
+
+
+class _FakeSampler(object):
+    """Stands in for the object run_mcmc_carma returns; log-densities from the CPU oracle."""
+
+    def __init__(self, t, y, yerr, p, q, samples):
+        self.m = orc.OracleModel(t, y, yerr, p, q)
+        self.s = samples
+        self.mle = False
+
+    def getSamples(self):
+        return self.s.tolist()
+
+    def GetLogLikes(self):
+        return self.m.logdensity_batch(self.s).tolist()
+
+    def SetMLE(self, flag):
+        self.mle = flag
+
+    def getLogDensityBatch(self, th):
+        return self.m.logdensity_batch(th, ignore_prior=self.mle)
+
+
+def test_carma_sample_dictionary(golden_dir):
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    fake = _FakeSampler(t, y, yerr, 5, 3, g["theta"][:16])
+    s = cp.CarmaSample(t, y, yerr, fake, q=3)
+    for key in ("logpost", "var", "measerr_scale", "mu", "quad_coefs", "ar_roots", "psd_centroid", "psd_width",
+                "ar_coefs", "ma_coefs", "sigma", "loglik"):
+        assert key in s.parameters, key
+    assert s.p == 5
+    np.testing.assert_allclose(s.get_samples("sigma")[:, 0] ** 2, g["sigsqr"][:16], rtol=1e-11)
+    np.testing.assert_allclose(s.get_samples("ar_roots"), g["omega"][:16], rtol=1e-13)
+    np.testing.assert_allclose(s.get_samples("psd_width")[0, :2], [0.01, 0.01], rtol=1e-12)
+    np.testing.assert_allclose(s.get_samples("loglik")[:, 0] -
+                               np.array([fake.m.log_prior(x) for x in g["theta"][:16]]), g["loglik"][:16], rtol=1e-11)
+    # quirk kept: without q= the AR order is inferred as p+q (testCarmcmc.py:95)
+    s2 = cp.CarmaSample(t, y, yerr, _FakeSampler(t, y, yerr, 5, 3, g["theta"][:4]).__class__(t, y, yerr, 5, 3, g["theta"][:4]))
+    assert s2.p == 8
+    lo, hi, med, f = s.power_spectrum_band(nsamples=8)
+    assert np.all(lo <= med) and np.all(med <= hi) and f.size == 1000
+    assert np.isfinite(s.DIC())
+
+
+def test_carma_process_moments():
+    rng = np.random.RandomState(3)
+    roots = cm.get_ar_roots(np.array([0.05, 0.02]), np.array([0.1]))
+    ma = [1.0, 2.0]
+    sigsqr = 1.7 ** 2 / cm.carma_variance(1.0, roots, ma)
+    t = np.arange(4000) * 1.0 + rng.uniform(0, 0.5, 4000)
+    y = cm.carma_process(t, sigsqr, roots, ma, rng=rng)
+    assert abs(y.var() - 1.7 ** 2) < 0.5
+    lag = 5
+    acf = np.mean(y[lag:] * y[:-lag])
+    dtm = np.mean(t[lag:] - t[:-lag])
+    assert abs(acf - cm.carma_variance(sigsqr, roots, ma, lag=dtm)) < 0.6
+    y1 = cm.car1_process(t, 0.5, 20.0, rng=rng)
+    assert abs(y1.var() - 0.5 * 20.0 / 2.0) < 1.5
+
+
+def test_mle_bounds_and_aicc_bookkeeping():
+    rng = np.random.default_rng(0)
+    t = np.sort(rng.uniform(0, 100, 50))
+    m = cpa.CarmaModel(np.r_[t, t[:3]], rng.standard_normal(53), np.ones(53), p=3, q=1)
+    assert m.time.size == 50 and np.all(np.diff(m.time) > 0)       # unique + sorted (:33-35)
+    b = m._mle_bounds(3, 1)
+    assert len(b) == 3 + 3 + 1 and b[1] == (0.9, 1.1) and b[-1] == (None, None)
+    with pytest.raises(ValueError):
+        cpa.CarmaModel(t, t, t, p=2, q=2)
