@@ -26,6 +26,7 @@
 // log(); 1/var is the only division.
 #pragma once
 #include "carma_types.h"
+#include "carma_math.h"
 
 namespace carma {
 
@@ -190,36 +191,27 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
 
 // Running -0.5*sum(log var) - 0.5*sum(innov^2/var) without a log in the loop.
 struct LogLikAcc {
-    double prod;   // product of mantissas in [0.5,1)
-    int esum;      // sum of binary exponents
+    double prod;   // running product of the variances, renormalised to [0.5,1) every step
+    int esum;      // binary exponent taken out of prod so far
     double chi2;
     bool bad;      // some var was <= 0 or NaN  (reference: log(var) = NaN -> NaN total)
-    int since;
     CARMA_DEV void init()
     {
-        prod = 1.0;
-        esum = 0;
+        prod = 0.5;
+        esum = 1;
         chi2 = 0.0;
         bad = false;
-        since = 0;
     }
     CARMA_DEV void add_var(double var)
     {
+        bad = bad || !(var > 0.0);
         int e;
-        double mnt = frexp(var, &e);
-        bad = bad || !(var > 0.0) || !(var < 1.7976931348623157e308);
-        prod *= mnt;
+        prod = frexp(prod * var, &e);      // v_frexp_mant_f64 + v_frexp_exp_i32_f64
         esum += e;
-        if (++since == 512) {   // keep the mantissa product far from underflow
-            int e2;
-            prod = frexp(prod, &e2);
-            esum += e2;
-            since = 0;
-        }
     }
     CARMA_DEV double total() const
     {
-        double nan_ = prod - prod;  // 0, or NaN if prod is not finite
+        double nan_ = 0.0;
         if (bad) nan_ = (prod - prod) / (prod - prod);
         return -0.5 * (log(prod) + (double)esum * LN2) - 0.5 * chi2 + nan_;
     }
@@ -321,6 +313,8 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
     }
     const double s0 = g.sum(act ? (b_own.re * c_own.re - b_own.im * c_own.im) : 0.0);
 
+    const Cx b_msk = {act ? b_own.re : 0.0, act ? b_own.im : 0.0};
+
     // ---- state ------------------------------------------------------------------------------
     Cx D[P];
 #pragma unroll
@@ -340,32 +334,53 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
     }
 
     // ---- Update x (n-1)  (kfilter.cpp:189-215) -----------------------------------------------
+    // rho_r = exp(omega_r dt_k) does not depend on the filter state, so it is computed one step
+    // ahead, between issuing the LDS reads of the all-gather and consuming them (kfilter.cpp:200).
+    // The gain is carried in the normalised form ut = u / sqrt(var), zi = innov / sqrt(var):
+    //   x <- rho o (x + ut zi),  D <- rho rho^H o (D - ut ut^H),  chi2 += zi^2.
+    Cx rho_next;
+    cexp_step(m.w.re, m.w.im, series[n > 1 ? 1 : 0].x, &rho_next.re, &rho_next.im);
     for (int k = 1; k < n; k++) {
         rec = series[k];
-        const double s = 1.0 / var;
-        acc.chi2 += innov * innov * s;
-        const double sinn = s * innov;
-        // own transition factor rho_r = exp(omega_r dt)  (kfilter.cpp:200)
-        double ea = exp(m.w.re * rec.x), sn, cs;
-        sincos(m.w.im * rec.x, &sn, &cs);
-        Cx rho = {ea * cs, ea * sn};
-        g.publish(u.re, u.im, rho.re, rho.im);
+        const Cx rho = rho_next;
+        const double rs = rsqrt(var);
+        const double zi = innov * rs;
+        acc.chi2 += zi * zi;
+        const Cx ut = {u.re * rs, u.im * rs};
+        g.publish(ut.re, ut.im, rho.re, rho.im);
+        double4 o[P];                                    // {ut_j, rho_j} of every lane of the group
+#pragma unroll
+        for (int j = 0; j < P; j++) o[j] = g.peek(j);
+        g.done_reading();
+        {
+            const int kn = (k + 1 < n) ? k + 1 : k;
+            cexp_step(m.w.re, m.w.im, series[kn].x, &rho_next.re, &rho_next.im);
+        }
         // state: x <- rho o (x + g innov)      (kfilter.cpp:194,201)
-        x = cmul(rho, Cx{x.re + u.re * sinn, x.im + u.im * sinn});
-        Cx w = {0.0, 0.0};
+        x = cmul(rho, Cx{x.re + ut.re * zi, x.im + ut.im * zi});
+        // b_msk is zero in the idle lanes of a group, so their partial sums vanish
+        Cx w;
 #pragma unroll
         for (int j = 0; j < P; j++) {
-            double4 o = g.peek(j);                       // {u_j, rho_j}
-            Cx t = cmulc(u, Cx{o.x, o.y});               // u_r conj(u_j)
-            Cx d = {D[j].re - t.re * s, D[j].im - t.im * s};        // kfilter.cpp:197
-            Cx R = cmulc(rho, Cx{o.z, o.w});             // rho_r conj(rho_j)
+            const Cx uj = {o[j].x, o[j].y}, rj = {o[j].z, o[j].w};
+            // d = D_rj - ut_r conj(ut_j)                  kfilter.cpp:197
+            Cx d;
+            d.re = fma(-ut.re, uj.re, fma(-ut.im, uj.im, D[j].re));
+            d.im = fma(-ut.im, uj.re, fma(ut.re, uj.im, D[j].im));
+            Cx R = cmulc(rho, rj);                       // rho_r conj(rho_j)
             D[j] = cmul(R, d);                           // kfilter.cpp:204 (minus V on both sides)
-            w = cadd(w, cmulc(D[j], ball[j]));           // (D b^H)_r
+            // w += D_rj conj(b_j)                        (D b^H)_r
+            if (j == 0) {
+                w.re = fma(D[j].re, ball[j].re, D[j].im * ball[j].im);
+                w.im = fma(D[j].im, ball[j].re, -(D[j].re * ball[j].im));
+            } else {
+                w.re = fma(D[j].re, ball[j].re, fma(D[j].im, ball[j].im, w.re));
+                w.im = fma(D[j].im, ball[j].re, fma(-D[j].re, ball[j].im, w.im));
+            }
         }
-        g.done_reading();
         u = cadd(w, c_own);
-        double pv = act ? (b_own.re * w.re - b_own.im * w.im) : 0.0;   // Re(b_r w_r)
-        double pm = act ? (b_own.re * x.re - b_own.im * x.im) : 0.0;   // Re(b_r x_r)
+        double pv = b_msk.re * w.re - b_msk.im * w.im;   // Re(b_r w_r)
+        double pm = b_msk.re * x.re - b_msk.im * x.im;   // Re(b_r x_r)
         pv = g.sum(pv);
         pm = g.sum(pm);
         mean = pm;                                  // kfilter.cpp:207

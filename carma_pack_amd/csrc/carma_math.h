@@ -1,0 +1,134 @@
+// carma_math.h -- lean FP64 exp / sincos for the transition factor rho = exp(omega dt)
+// (src/kfilter.cpp:200 calls std::exp(std::complex<double>) once per root per step).
+//
+// gfx950 has no FP64 transcendental instructions; the ROCm device-library exp() + sincos() cost
+// ~120 VALU instructions per call pair (40 % of the whole Kalman step).  The versions here do the
+// same argument reductions with FMA and evaluate fixed polynomials: ~20 (exp) + ~30 (sincos)
+// instructions, max error < 2 ulp on the ranges the filter produces:
+//   exp_neg(x)  : any x (meant for x = Re(omega) dt <= 0); Cody-Waite ln2 split + degree-13 Taylor
+//   sincos_cw(x): |x| < 2^20 by 3-term Cody-Waite reduction by pi/2 + fdlibm kernels; larger
+//                 arguments (pathological gap/min-dt ratios) take the library path.
+// Shared with the CPU lane emulator (tests/emu), hence plain C++ with fma().
+#pragma once
+
+namespace carma {
+
+// Three-operand FP64 FMA.  hipcc selects v_fmac_f64 (dst tied to the addend) for fma(), which
+// costs an extra v_mov_b64 whenever the addend is a loop-invariant polynomial coefficient; the asm
+// form keeps one instruction per Horner step.
+#ifdef __HIPCC__
+CARMA_DEV double fma3(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#else
+static inline double fma3(double a, double b, double c) { return fma(a, b, c); }
+#endif
+
+CARMA_DEV double exp_neg(double x)
+{
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01;   // 33 significant bits
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double n = rint(x * LOG2E);
+    double r = fma3(-n, LN2_HI, x);
+    r = fma3(-n, LN2_LO, r);
+    // exp(r), |r| <= ln2/2: Taylor to r^13 (truncation 4e-18)
+    double p = 1.0 / 6227020800.0;
+    p = fma3(p, r, 1.0 / 479001600.0);
+    p = fma3(p, r, 1.0 / 39916800.0);
+    p = fma3(p, r, 1.0 / 3628800.0);
+    p = fma3(p, r, 1.0 / 362880.0);
+    p = fma3(p, r, 1.0 / 40320.0);
+    p = fma3(p, r, 1.0 / 5040.0);
+    p = fma3(p, r, 1.0 / 720.0);
+    p = fma3(p, r, 1.0 / 120.0);
+    p = fma3(p, r, 1.0 / 24.0);
+    p = fma3(p, r, 1.0 / 6.0);
+    p = fma3(p, r, 0.5);
+    p = fma3(p, r, 1.0);
+    p = fma3(p, r, 1.0);
+    // n is integral; beyond +-2000 the result has long over/underflowed, clamp so the int
+    // conversion is well defined
+    double nc = fmin(fmax(n, -2200.0), 2200.0);
+    return ldexp(p, (int)nc);
+}
+
+// sin and cos of x, |x| < 2^20 (caller guarantees); fdlibm __kernel_sin/__kernel_cos polynomials.
+CARMA_DEV void sincos_cw(double x, double* s_out, double* c_out)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;    // first 33 bits of pi/2
+    const double PIO2_2 = 6.07710050630396597660e-11;    // next 33 bits
+    const double PIO2_3 = 2.02226624871116645580e-21;    // next 33 bits
+    const double PIO2_3T = 8.47842766036889956997e-32;   // tail
+    double n = rint(x * TWO_OVER_PI);
+    double r = fma3(-n, PIO2_1, x);
+    r = fma3(-n, PIO2_2, r);
+    r = fma3(-n, PIO2_3, r);
+    r = fma3(-n, PIO2_3T, r);
+    const int q = (int)n;
+    const double z = r * r;
+    // sin(r) = r + r^3 (S1 + z (S2 + ... ))
+    double ps = 1.58969099521155010221e-10;
+    ps = fma3(ps, z, -2.50507602534068634195e-08);
+    ps = fma3(ps, z, 2.75573137070700676789e-06);
+    ps = fma3(ps, z, -1.98412698298579493134e-04);
+    ps = fma3(ps, z, 8.33333333332248946124e-03);
+    ps = fma3(ps, z, -1.66666666666666324348e-01);
+    const double sn = fma3(z * r, ps, r);
+    // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
+    double pc = -1.13596475577881948265e-11;
+    pc = fma3(pc, z, 2.08757232129817482790e-09);
+    pc = fma3(pc, z, -2.75573143513906633035e-07);
+    pc = fma3(pc, z, 2.48015872894767294178e-05);
+    pc = fma3(pc, z, -1.38888888888741095749e-03);
+    pc = fma3(pc, z, 4.16666666666666019037e-02);
+    pc = fma3(pc, z, -0.5);
+    const double cs = fma3(pc, z, 1.0);
+    // quadrant
+    const bool swap = q & 1;
+    double so = swap ? cs : sn;
+    double co = swap ? sn : cs;
+    so = (q & 2) ? -so : so;
+    co = ((q + 1) & 2) ? -co : co;
+    *s_out = so;
+    *c_out = co;
+}
+
+// library sincos kept out of line: it is only reached for |phase| >= 2^20 (or NaN)
+struct SinCos {
+    double s, c;
+};
+#ifdef __HIPCC__
+__device__ __attribute__((noinline)) static SinCos sincos_slow(double x)
+#else
+static inline SinCos sincos_slow(double x)
+#endif
+{
+    SinCos r;
+    r.s = sin(x);
+    r.c = cos(x);
+    return r;
+}
+
+// rho = exp((a + i b) dt) -> (re, im)
+CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im)
+{
+    const double e = exp_neg(a * dt);
+    const double ph = b * dt;
+    double sn, cs;
+    if (fabs(ph) < 1048576.0) {
+        sincos_cw(ph, &sn, &cs);
+    } else {
+        SinCos sc = sincos_slow(ph);   // rare: library reduction for huge arguments (NaN also lands here)
+        sn = sc.s;
+        cs = sc.c;
+    }
+    *re = e * cs;
+    *im = e * sn;
+}
+
+}  // namespace carma

@@ -17,14 +17,23 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;   // [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane i <-> 7-i inside each 8 lanes
 constexpr int DPP_ROW_MIRROR = 0x140;        // lane i <-> 15-i inside each 16 lanes
 
-template <int CTRL>
-CARMA_DEV double dpp_mov(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
+// One v_mov_b32_dpp per 32-bit half, written as asm so that the destination is a fresh register
+// (the builtin ties dst to an `old` operand and costs an extra v_mov per half).  The s_nop covers
+// the "VALU write -> DPP read" hazard, which the compiler does not track through inline asm.
+#define CARMA_DPP_MOV64(NAME, CTRLSTR)                                                          \
+    CARMA_DEV double NAME(double v)                                                             \
+    {                                                                                           \
+        int lo = __double2loint(v), hi = __double2hiint(v), olo, ohi;                           \
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 " CTRLSTR " row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_mov_b32_dpp %1, %3 " CTRLSTR " row_mask:0xf bank_mask:0xf"               \
+                     : "=&v"(olo), "=&v"(ohi)                                                   \
+                     : "v"(lo), "v"(hi));                                                       \
+        return __hiloint2double(ohi, olo);                                                      \
+    }
+CARMA_DPP_MOV64(dpp_xor1, "quad_perm:[1,0,3,2]")
+CARMA_DPP_MOV64(dpp_xor2, "quad_perm:[2,3,0,1]")
+CARMA_DPP_MOV64(dpp_half_mirror, "row_half_mirror")
+CARMA_DPP_MOV64(dpp_mirror, "row_mirror")
 
 template <int G>
 struct Grp {
@@ -40,18 +49,18 @@ struct Grp {
     // Butterfly all-reduce; every lane of the group ends with the bit-identical total.
     CARMA_DEV static double sum(double v)
     {
-        if (G >= 2) v += dpp_mov<DPP_QUAD_XOR1>(v);
-        if (G >= 4) v += dpp_mov<DPP_QUAD_XOR2>(v);
-        if (G >= 8) v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
-        if (G >= 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
+        if (G >= 2) v += dpp_xor1(v);
+        if (G >= 4) v += dpp_xor2(v);
+        if (G >= 8) v += dpp_half_mirror(v);
+        if (G >= 16) v += dpp_mirror(v);
         return v;
     }
     CARMA_DEV static double max(double v)
     {
-        if (G >= 2) v = fmax(v, dpp_mov<DPP_QUAD_XOR1>(v));
-        if (G >= 4) v = fmax(v, dpp_mov<DPP_QUAD_XOR2>(v));
-        if (G >= 8) v = fmax(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
-        if (G >= 16) v = fmax(v, dpp_mov<DPP_ROW_MIRROR>(v));
+        if (G >= 2) v = fmax(v, dpp_xor1(v));
+        if (G >= 4) v = fmax(v, dpp_xor2(v));
+        if (G >= 8) v = fmax(v, dpp_half_mirror(v));
+        if (G >= 16) v = fmax(v, dpp_mirror(v));
         return v;
     }
     // value of v held by lane j of this group (j identical in every lane of the group)

@@ -21,11 +21,17 @@ using std::exp;
 using std::fabs;
 using std::fmax;
 using std::fmin;
+using std::fma;
+using std::ldexp;
+using std::rint;
+static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 using std::pow;
 using std::frexp;
 using std::hypot;
 using std::log;
 using std::sqrt;
+using std::sin;
+using std::cos;
 
 namespace carma {
 

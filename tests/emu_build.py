@@ -19,7 +19,7 @@ def lib():
         csrc = os.path.join(ROOT, "carma_pack_amd", "csrc")
         srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
         if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-mfma",
                                    "-o", SO, srcs[0]])
         _lib = C.CDLL(SO)
     return _lib
