@@ -36,9 +36,6 @@ namespace carma {
 constexpr double TWO_PI = 6.283185307179586476925286766559;
 constexpr double LN2 = 0.693147180559945309417232121458;
 
-struct Cx {
-    double re, im;
-};
 CARMA_DEV Cx cmul(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 CARMA_DEV Cx cmulc(Cx a, Cx b) { return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }  // a*conj(b)
 CARMA_DEV Cx cadd(Cx a, Cx b) { return {a.re + b.re, a.im + b.im}; }
@@ -217,21 +214,26 @@ struct LogLikAcc {
     }
 };
 
-// Kalman filter of one evaluation (Reset + n-1 Updates) -> log-likelihood sum (no prior).
-// y is centred with m.mu and yerr^2 scaled with m.scale on the fly (carpack.hpp:150-153).
-// If WRITE_MV, lane 0 of the group also stores the one-step means/variances.
-// *singular is set when the Vandermonde solve hits an exactly zero pivot (arma::solve throws).
-template <int P, int G, bool WRITE_MV, class GrpT>
-CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __restrict__ series, int n,
-                            double* mean_out, double* var_out, bool* singular)
+// Per-evaluation constants produced by Reset, as held by lane r of the group.
+template <int P>
+struct FilterConsts {
+    Cx b_own;     // rotated MA coefficient b_r
+    Cx b_msk;     // b_r, or 0 in the idle lanes of the group
+    Cx c_own;     // (V b^H)_r
+    Cx ball[P];   // b_j for all j
+    double s0;    // Re(b V b^H)
+    bool sing;    // exactly zero pivot in the Vandermonde solve
+};
+
+// Reset (kfilter.cpp:138-186).
+// Column r of the Vandermonde matrix E_ir = omega_r^i lives in lane r; the right-hand side
+// e_{p-1} is replicated.  LU with partial pivoting (|re|+|im| pivot rule), forward
+// substitution folded in, then column-oriented back substitution.
+template <int P, int G, class GrpT>
+CARMA_DEV void filter_reset(const GrpT& g, const Model<P>& m, FilterConsts<P>& fc)
 {
     const int r = g.lane();
     const bool act = r < P;
-
-    // ---- Reset (kfilter.cpp:138-186) --------------------------------------------------------
-    // Column r of the Vandermonde matrix E_ir = omega_r^i lives in lane r; the right-hand side
-    // e_{p-1} is replicated.  LU with partial pivoting (|re|+|im| pivot rule), forward
-    // substitution folded in, then column-oriented back substitution.
     Cx a[P], rhs[P];
     {
         Cx pw = {1.0, 0.0};
@@ -311,66 +313,126 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
         Cx v = cdiv(num, den);
         c_own = cadd(c_own, cmulc(v, ball[j]));
     }
-    const double s0 = g.sum(act ? (b_own.re * c_own.re - b_own.im * c_own.im) : 0.0);
+    fc.s0 = g.sum(act ? (b_own.re * c_own.re - b_own.im * c_own.im) : 0.0);
+    fc.b_own = b_own;
+    fc.b_msk = {act ? b_own.re : 0.0, act ? b_own.im : 0.0};
+    fc.c_own = c_own;
+#pragma unroll
+    for (int j = 0; j < P; j++) fc.ball[j] = ball[j];
+    fc.sing = sing;
+}
 
-    const Cx b_msk = {act ? b_own.re : 0.0, act ? b_own.im : 0.0};
+// 1/v to ~1 ulp: v_rcp_f64 + two Newton steps on the GPU (the IEEE division expands to 12
+// instructions), plain division on the host.
+CARMA_DEV double recip(double v)
+{
+#ifdef __HIPCC__
+    double s = __builtin_amdgcn_rcp(v);
+    s = fma(fma(-v, s, 1.0), s, s);
+    s = fma(fma(-v, s, 1.0), s, s);
+    return s;
+#else
+    return 1.0 / v;
+#endif
+}
 
-    // ---- state ------------------------------------------------------------------------------
+// Where the transition factors rho_j(k) = exp(omega_j dt_k) of a group come from.
+// RhoInline: every lane computes its own factor one step ahead and shares it through the group's
+// second exchange array.  (carma_ring.h has the variant fed by a producer wave.)
+template <int P, class GrpT>
+struct RhoInline {
+    const GrpT& g;
+    Cx w;            // own root
+    Cx rho_next;     // factor of the upcoming step
+    CARMA_DEV void begin(int, double dt_first) { cexp_step(w.re, w.im, dt_first, &rho_next.re, &rho_next.im); }
+    CARMA_DEV void publish(int) const { g.publish2(rho_next.re, rho_next.im); }
+    CARMA_DEV void fetch(int, Cx& rho, Cx (&rj)[P]) const
+    {
+        rho = rho_next;
+#pragma unroll
+        for (int j = 0; j < P; j++) rj[j] = g.peek2(j);
+    }
+    // called once the group's LDS reads are in flight: independent work that hides their latency
+    CARMA_DEV void prepare(int, double dt_next) { cexp_step(w.re, w.im, dt_next, &rho_next.re, &rho_next.im); }
+};
+
+// Update loop (kfilter.cpp:189-215) + log-likelihood sum (carpack.hpp:167-171), given Reset's
+// constants.  One LDS all-gather per step carries everything the lanes owe each other:
+//   slot_r = { u_r, Re(b_r w_r), Re(b_r x_r) }      (+ rho_r in the second array)
+// Every lane adds the P partial sums in the same order, so var_k / mean_k are bit-identical across
+// the group without a butterfly, and the reduction shares the round trip of the gain exchange.
+// While the reads are in flight the lane forms the state-independent products and (RhoInline)
+// the next step's exp/sincos.  Step k consumes var_{k-1}, innov_{k-1}:
+//   s = 1/var;  x <- rho o (x + u s innov);  D <- rho rho^H o (D - u u^H s);  chi2 += innov^2 s.
+template <int P, int G, bool WRITE_MV, class GrpT, class RhoSrc>
+CARMA_DEV double filter_loop(const GrpT& g, const Model<P>& m, const FilterConsts<P>& fc, RhoSrc& src,
+                             const double4* __restrict__ series, int n, double* mean_out, double* var_out)
+{
+    const int r = g.lane();
+    const Cx b_msk = fc.b_msk, c_own = fc.c_own;
+    const double s0 = fc.s0;
+    Cx ball[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) ball[j] = fc.ball[j];
+
     Cx D[P];
 #pragma unroll
     for (int j = 0; j < P; j++) D[j] = {0.0, 0.0};
     Cx x = {0.0, 0.0};
-    Cx u = c_own;            // (P b^H)_r with P = V
-    double4 rec = series[0];
-    double var = s0 + rec.z * m.scale;      // kfilter.cpp:180-182
-    double mean = 0.0;
-    double innov = rec.y - m.mu;            // kfilter.cpp:184
+    Cx u = c_own;              // (P b^H)_r with P = V                    kfilter.cpp:173
+    double pvr = 0.0, pmr = 0.0;
     LogLikAcc acc;
     acc.init();
-    acc.add_var(var);
-    if (WRITE_MV && r == 0) {
-        mean_out[0] = mean;
-        var_out[0] = var;
-    }
-
-    // ---- Update x (n-1)  (kfilter.cpp:189-215) -----------------------------------------------
-    // rho_r = exp(omega_r dt_k) does not depend on the filter state, so it is computed one step
-    // ahead, between issuing the LDS reads of the all-gather and consuming them (kfilter.cpp:200).
-    // The gain is carried in the normalised form ut = u / sqrt(var), zi = innov / sqrt(var):
-    //   x <- rho o (x + ut zi),  D <- rho rho^H o (D - ut ut^H),  chi2 += zi^2.
-    Cx rho_next;
-    cexp_step(m.w.re, m.w.im, series[n > 1 ? 1 : 0].x, &rho_next.re, &rho_next.im);
-    for (int k = 1; k < n; k++) {
-        rec = series[k];
-        const Cx rho = rho_next;
-        const double rs = rsqrt(var);
-        const double zi = innov * rs;
-        acc.chi2 += zi * zi;
-        const Cx ut = {u.re * rs, u.im * rs};
-        g.publish(ut.re, ut.im, rho.re, rho.im);
-        double4 o[P];                                    // {ut_j, rho_j} of every lane of the group
+    // Series records are fetched ahead of use (scalar loads share the LDS wait counter, so a load
+    // issued right before its use would expose its latency on every LDS wait).
+    double4 rprev = series[0];                       // record k-1: y, yerr^2 for var_{k-1}
+    double4 rcur = series[n > 1 ? 1 : 0];            // record k  : dt_k
+    double4 rnxt = series[n > 2 ? 2 : n - 1];        // record k+1
+    src.begin(1, rcur.x);
+    double var = 0.0, innov = 0.0;
+    for (int k = 1; k <= n; k++) {
+        const bool last = (k == n);                  // extra pass: only closes var_{n-1}, mean_{n-1}
+        const double4 rnn = series[(k + 2 < n) ? k + 2 : n - 1];
+        g.publish(u.re, u.im, pvr, pmr);
+        if (!last) src.publish(k);
+        double4 o[P];
 #pragma unroll
         for (int j = 0; j < P; j++) o[j] = g.peek(j);
+        Cx rho, rj[P];
+        if (!last) src.fetch(k, rho, rj);
         g.done_reading();
-        {
-            const int kn = (k + 1 < n) ? k + 1 : k;
-            cexp_step(m.w.re, m.w.im, series[kn].x, &rho_next.re, &rho_next.im);
+        if (!last) src.prepare(k + 1, rnxt.x);
+        // var_{k-1}, mean_{k-1} (kfilter.cpp:180-182, 207-210), innovation (:184, :213)
+        double pv = o[0].z, pm = o[0].w;
+#pragma unroll
+        for (int j = 1; j < P; j++) {
+            pv += o[j].z;
+            pm += o[j].w;
         }
-        // state: x <- rho o (x + g innov)      (kfilter.cpp:194,201)
-        x = cmul(rho, Cx{x.re + ut.re * zi, x.im + ut.im * zi});
-        // b_msk is zero in the idle lanes of a group, so their partial sums vanish
-        Cx w;
+        var = s0 + pv + rprev.z * m.scale;
+        innov = (rprev.y - m.mu) - pm;
+        acc.add_var(var);
+        if (WRITE_MV && r == 0) {
+            mean_out[k - 1] = pm;
+            var_out[k - 1] = var;
+        }
+        const double s = recip(var);
+        const double si = s * innov;
+        acc.chi2 += innov * si;
+        if (last) break;
+        // state: x <- rho o (x + g innov)      (kfilter.cpp:191-194, 200-201)
+        x = cmul(rho, Cx{x.re + u.re * si, x.im + u.im * si});
+        Cx w0, w1;                                   // two accumulators: halves the dependent chain
 #pragma unroll
         for (int j = 0; j < P; j++) {
-            const Cx uj = {o[j].x, o[j].y}, rj = {o[j].z, o[j].w};
-            // d = D_rj - ut_r conj(ut_j)                  kfilter.cpp:197
-            Cx d;
-            d.re = fma(-ut.re, uj.re, fma(-ut.im, uj.im, D[j].re));
-            d.im = fma(-ut.im, uj.re, fma(ut.re, uj.im, D[j].im));
-            Cx R = cmulc(rho, rj);                       // rho_r conj(rho_j)
+            const Cx uj = {o[j].x, o[j].y};
+            const Cx t = cmulc(u, uj);                   // u_r conj(u_j)           (independent of s)
+            const Cx R = cmulc(rho, rj[j]);              // rho_r conj(rho_j)       (independent of s)
+            const Cx d = {fma(-t.re, s, D[j].re), fma(-t.im, s, D[j].im)};      // kfilter.cpp:197
             D[j] = cmul(R, d);                           // kfilter.cpp:204 (minus V on both sides)
-            // w += D_rj conj(b_j)                        (D b^H)_r
-            if (j == 0) {
+            // w += D_rj conj(b_j)                       (D b^H)_r
+            Cx& w = (j & 1) ? w1 : w0;
+            if (j < 2) {
                 w.re = fma(D[j].re, ball[j].re, D[j].im * ball[j].im);
                 w.im = fma(D[j].im, ball[j].re, -(D[j].re * ball[j].im));
             } else {
@@ -378,23 +440,32 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
                 w.im = fma(D[j].im, ball[j].re, fma(-D[j].re, ball[j].im, w.im));
             }
         }
+        const Cx w = (P > 1) ? cadd(w0, w1) : w0;
         u = cadd(w, c_own);
-        double pv = b_msk.re * w.re - b_msk.im * w.im;   // Re(b_r w_r)
-        double pm = b_msk.re * x.re - b_msk.im * x.im;   // Re(b_r x_r)
-        pv = g.sum(pv);
-        pm = g.sum(pm);
-        mean = pm;                                  // kfilter.cpp:207
-        var = s0 + pv + rec.z * m.scale;            // kfilter.cpp:209-210
-        innov = (rec.y - m.mu) - mean;              // kfilter.cpp:213
-        acc.add_var(var);
-        if (WRITE_MV && r == 0) {
-            mean_out[k] = mean;
-            var_out[k] = var;
-        }
+        // b_msk is zero in the idle lanes of a group, so their partial sums vanish
+        pvr = b_msk.re * w.re - b_msk.im * w.im;     // Re(b_r w_r)
+        pmr = b_msk.re * x.re - b_msk.im * x.im;     // Re(b_r x_r)
+        rprev = rcur;
+        rcur = rnxt;
+        rnxt = rnn;
     }
-    acc.chi2 += innov * innov / var;
-    *singular = sing;
     return acc.total();
+}
+
+// Kalman filter of one evaluation (Reset + n-1 Updates) -> log-likelihood sum (no prior).
+// y is centred with m.mu and yerr^2 scaled with m.scale on the fly (carpack.hpp:150-153).
+// If WRITE_MV, lane 0 of the group also stores the one-step means/variances.
+// *singular is set when the Vandermonde solve hits an exactly zero pivot (arma::solve throws).
+template <int P, int G, bool WRITE_MV, class GrpT>
+CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __restrict__ series, int n,
+                            double* mean_out, double* var_out, bool* singular)
+{
+    FilterConsts<P> fc;
+    filter_reset<P, G>(g, m, fc);
+    RhoInline<P, GrpT> src{g, m.w, Cx{1.0, 0.0}};
+    double ll = filter_loop<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
+    *singular = fc.sing;
+    return ll;
 }
 
 // log prior (carpack.hpp:118-126)

@@ -16,6 +16,7 @@
 
 #include "grp_device.h"
 #include "carma_core.h"
+#include "carma_ring.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -31,12 +32,41 @@ __global__ __launch_bounds__(64 * WAVES) void k_logdens_carma(const double* __re
                                                              int ignore_prior, double* __restrict__ out)
 {
     __shared__ double4 xch[64 * WAVES];
+    __shared__ double2 xch2[64 * WAVES];
     const int tid = threadIdx.x;
-    Grp<G> g{xch + (tid & ~63), tid & 63};
+    Grp<G> g{xch + (tid & ~63), tid & 63, xch2 + (tid & ~63)};
     long e = ((long)blockIdx.x * (64 * WAVES) + tid) / G;
     const bool live = e < B;
     if (!live) e = B - 1;
     double ll = logdensity_carma<P, G>(g, theta + e * d, q, series, n, pr, ignore_prior);
+    if (live && g.lane() == 0) out[e] = ll;
+}
+
+// Latency-regime variant (carma_ring.h): 128-thread workgroup = consumer wave + rho-producer wave
+// for the same 64/G evaluations.
+template <int P, int G>
+__global__ __launch_bounds__(128) void k_logdens_carma_pc(const double* __restrict__ theta, int B, int d, int q,
+                                                          const double4* __restrict__ series, int n, Prior pr,
+                                                          int ignore_prior, double* __restrict__ out)
+{
+    extern __shared__ double4 smem4[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane64 = tid & 63;
+    Grp<G> g{smem4 + wave * 64, lane64, nullptr};
+    Cx* ring = reinterpret_cast<Cx*>(smem4 + 128);
+    long e = ((long)blockIdx.x * 64 + lane64) / G;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    Model<P> m;
+    model_from_theta<P, G>(g, theta + e * d, q, pr, ignore_prior, m);
+    if (wave == 1) {
+        ring_produce<P, G>(g, m.w, series, n, ring);
+        return;
+    }
+    bool sing;
+    double ll = ring_consume<P, G>(g, m, series, n, ring, &sing);
+    ll += log_prior(m.scale, pr.measerr_dof);
+    const double ninf = -1.0 / 0.0;
+    if (sing || !m.valid) ll = ninf;
     if (live && g.lane() == 0) out[e] = ll;
 }
 
@@ -55,8 +85,9 @@ __global__ __launch_bounds__(64) void k_kfilter_carma(const double* __restrict__
                                                       int* __restrict__ singular)
 {
     __shared__ double4 xch[64];
+    __shared__ double2 xch2[64];
     const int tid = threadIdx.x;
-    Grp<G> g{xch, tid & 63};
+    Grp<G> g{xch, tid & 63, xch2};
     Model<P> m;
     const int r = g.lane() < P ? g.lane() : P - 1;
     m.w = {om_re_im[2 * r], om_re_im[2 * r + 1]};
@@ -91,7 +122,20 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     // Latency-bound path: spread waves over as many CUs as possible (1 wave/block) until the
     // chip is covered, then pack 4 waves per block.
     const long waves = ((long)B + EPW - 1) / EPW;
-    if (waves <= 2048) {
+    if (waves <= 512 && n >= 8) {
+        // few evaluations in flight: one wave's instruction stream is the run time, so split it
+        // (consumer + rho producer, carma_ring.h).  At most 2 workgroups per CU.
+        const size_t lds = 128 * sizeof(double4) + RingGeom<P>::BYTES;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_pc<P, G>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_logdens_carma_pc<P, G>), dim3((unsigned)waves), dim3(128), lds, st, theta, B, d, q, series,
+                           n, pr, ignore_prior, out);
+    } else if (waves <= 2048) {
         hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n,
                            pr, ignore_prior, out);
     } else {

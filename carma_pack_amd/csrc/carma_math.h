@@ -114,21 +114,75 @@ static inline SinCos sincos_slow(double x)
     return r;
 }
 
-// rho = exp((a + i b) dt) -> (re, im)
+// rho = exp((a + i b) dt) -> (re, im).  The four polynomial chains (even/odd halves of the exp
+// polynomial, sin, cos) are advanced in lock-step so that a single in-order wave always has
+// independent FMAs to issue between the members of each dependent chain.
 CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im)
 {
-    const double e = exp_neg(a * dt);
+    const double x = a * dt;
     const double ph = b * dt;
-    double sn, cs;
-    if (fabs(ph) < 1048576.0) {
-        sincos_cw(ph, &sn, &cs);
-    } else {
-        SinCos sc = sincos_slow(ph);   // rare: library reduction for huge arguments (NaN also lands here)
-        sn = sc.s;
-        cs = sc.c;
+    if (!(fabs(ph) < 1048576.0)) {
+        // rare: library reduction for huge phases (NaN also lands here)
+        const double e = exp_neg(x);
+        SinCos sc = sincos_slow(ph);
+        *re = e * sc.c;
+        *im = e * sc.s;
+        return;
     }
-    *re = e * cs;
-    *im = e * sn;
+    // --- argument reductions
+    const double n1 = rint(x * 1.4426950408889634074);
+    const double n2 = rint(ph * 6.36619772367581382433e-01);
+    double r = fma3(-n1, 6.93147180369123816490e-01, x);
+    double t = fma3(-n2, 1.57079632673412561417e+00, ph);
+    r = fma3(-n1, 1.90821492927058770002e-10, r);
+    t = fma3(-n2, 6.07710050630396597660e-11, t);
+    t = fma3(-n2, 2.02226624871116645580e-21, t);
+    t = fma3(-n2, 8.47842766036889956997e-32, t);
+    const double r2 = r * r;
+    const double z = t * t;
+    // --- exp(r) = E(r^2) + r O(r^2) (Taylor to r^13), sin(t) = t + t^3 S(z), cos(t) = 1 + z C(z)
+    double pe = 1.0 / 479001600.0;          // r^12
+    double po = 1.0 / 6227020800.0;         // r^13
+    double ps = 1.58969099521155010221e-10;
+    double pc = -1.13596475577881948265e-11;
+    pe = fma3(pe, r2, 1.0 / 3628800.0);
+    po = fma3(po, r2, 1.0 / 39916800.0);
+    ps = fma3(ps, z, -2.50507602534068634195e-08);
+    pc = fma3(pc, z, 2.08757232129817482790e-09);
+    pe = fma3(pe, r2, 1.0 / 40320.0);
+    po = fma3(po, r2, 1.0 / 362880.0);
+    ps = fma3(ps, z, 2.75573137070700676789e-06);
+    pc = fma3(pc, z, -2.75573143513906633035e-07);
+    pe = fma3(pe, r2, 1.0 / 720.0);
+    po = fma3(po, r2, 1.0 / 5040.0);
+    ps = fma3(ps, z, -1.98412698298579493134e-04);
+    pc = fma3(pc, z, 2.48015872894767294178e-05);
+    pe = fma3(pe, r2, 1.0 / 24.0);
+    po = fma3(po, r2, 1.0 / 120.0);
+    ps = fma3(ps, z, 8.33333333332248946124e-03);
+    pc = fma3(pc, z, -1.38888888888741095749e-03);
+    pe = fma3(pe, r2, 0.5);
+    po = fma3(po, r2, 1.0 / 6.0);
+    ps = fma3(ps, z, -1.66666666666666324348e-01);
+    pc = fma3(pc, z, 4.16666666666666019037e-02);
+    pe = fma3(pe, r2, 1.0);
+    po = fma3(po, r2, 1.0);
+    const double tz = t * z;
+    pc = fma3(pc, z, -0.5);
+    const double ep = fma3(po, r, pe);
+    const double sn = fma3(tz, ps, t);
+    const double cs = fma3(pc, z, 1.0);
+    const double nc = fmin(fmax(n1, -2200.0), 2200.0);
+    const double e = ldexp(ep, (int)nc);
+    // --- quadrant
+    const int q = (int)n2;
+    const bool swap = q & 1;
+    double so = swap ? cs : sn;
+    double co = swap ? sn : cs;
+    so = (q & 2) ? -so : so;
+    co = ((q + 1) & 2) ? -co : co;
+    *re = e * co;
+    *im = e * so;
 }
 
 }  // namespace carma

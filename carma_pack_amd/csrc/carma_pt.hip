@@ -37,7 +37,8 @@ __global__ __launch_bounds__(MAXT) void k_pt(PtLaunch L, const double4* __restri
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int d = L.d, T = L.T, per = 4 * d + d * d;
     double4* xch = smem4;                                   // one exchange slot per lane
-    double* base = reinterpret_cast<double*>(smem4 + nthr); // per chain: th, thn, z, v, R
+    double2* xch2 = reinterpret_cast<double2*>(smem4 + nthr);   // second exchange array (rho)
+    double* base = reinterpret_cast<double*>(smem4 + nthr + nthr / 2); // per chain: th, thn, z, v, R
     double* s_lp = base + (size_t)T * per;
     double* s_temps = s_lp + T;
     unsigned* s_nswap = reinterpret_cast<unsigned*>(s_temps + T);
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(MAXT) void k_pt(PtLaunch L, const double4* __restri
     }
     __syncthreads();
 
-    Grp<G> g{xch + (tid & ~63), tid & 63};
+    Grp<G> g{xch + (tid & ~63), tid & 63, xch2 + (tid & ~63)};
     const int c = tid / G;
     const bool active = c < T;
     const int cc = active ? c : 0;
@@ -105,7 +106,7 @@ size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out)
     int nthr = ((T * G + 63) / 64) * 64;
     if (nthreads_out) *nthreads_out = nthr;
     size_t per = 4 * (size_t)d + (size_t)d * d;
-    return (size_t)nthr * 32 + ((size_t)T * per + 2 * (size_t)T) * 8 + (size_t)T * 4 + 16;
+    return (size_t)nthr * 48 + ((size_t)T * per + 2 * (size_t)T) * 8 + (size_t)T * 4 + 16;
 }
 
 template <int P>

@@ -8,6 +8,10 @@ struct Prior {
     double max_stdev, max_freq, min_freq, measerr_dof;
 };
 
+struct Cx {
+    double re, im;
+};
+
 // Arguments of one launch of the persistent PT kernel.
 struct PtLaunch {
     int d, q, n;                 // parameter dimension, MA order, series length

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "carma_types.h"
+
 #define CARMA_DEV __device__ __forceinline__
 
 namespace carma {
@@ -42,6 +44,7 @@ struct Grp {
     // scratch for the per-step all-gather: one 32-byte slot per lane, in LDS
     double4* xch;      // points at this WAVE's 64 slots
     int lane64;        // lane id inside the wave
+    double2* xch2;     // second exchange array (16 B per lane), this WAVE's 64 slots
 
     CARMA_DEV int lane() const { return lane64 & (G - 1); }
     CARMA_DEV int gbase() const { return lane64 & ~(G - 1); }
@@ -78,6 +81,17 @@ struct Grp {
         __builtin_amdgcn_wave_barrier();
     }
     CARMA_DEV double4 peek(int j) const { return xch[gbase() + j]; }
+    CARMA_DEV void publish2(double a, double b) const
+    {
+        xch2[lane64] = make_double2(a, b);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    CARMA_DEV Cx peek2(int j) const
+    {
+        double2 v = xch2[gbase() + j];
+        return Cx{v.x, v.y};
+    }
     CARMA_DEV void done_reading() const { __builtin_amdgcn_wave_barrier(); }
 
     // Make this wave's earlier LDS/global stores visible to its later loads (other lanes of the

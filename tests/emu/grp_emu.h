@@ -33,6 +33,8 @@ using std::sqrt;
 using std::sin;
 using std::cos;
 
+#include "../../carma_pack_amd/csrc/carma_types.h"
+
 namespace carma {
 
 struct SpinBarrier {
@@ -59,6 +61,7 @@ struct EmuShared {
     double slot[16];
     int islot[16];
     double4 xch[16];
+    double xch2[16][2];
 };
 
 template <int G>
@@ -98,6 +101,13 @@ struct Grp {
         sh->bar.wait();
     }
     double4 peek(int j) const { return sh->xch[j]; }
+    void publish2(double a, double b) const
+    {
+        sh->xch2[r][0] = a;
+        sh->xch2[r][1] = b;
+        sh->bar.wait();
+    }
+    Cx peek2(int j) const { return Cx{sh->xch2[j][0], sh->xch2[j][1]}; }
     void done_reading() const { sh->bar.wait(); }
     void sync() const { sh->bar.wait(); }
 };

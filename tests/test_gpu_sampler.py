@@ -62,7 +62,12 @@ def test_carma53_tempered_sampler(cpa, golden_dir):
     flat = samples[:, ::37].reshape(-1, 11)
     np.testing.assert_allclose(lp[:, ::37].reshape(-1), m.logdensity_batch(flat), rtol=1e-10)
     th, l2 = ctx.pt_get_chains()
-    np.testing.assert_allclose(l2.reshape(-1), m.logdensity_batch(th.reshape(-1, 11)), rtol=1e-10)
+    # hot chains roam into ill-conditioned corners of the prior: arbitrate those against 50 digits
+    from helpers import assert_parity
+    from mp_truth import loglik_truth
+    flat_th = th.reshape(-1, 11)
+    assert_parity(l2.reshape(-1), m.logdensity_batch(flat_th), 1e-10, "chain states",
+                  arbiter=lambda i: loglik_truth(t, y, yerr, flat_th[i], 5, 3)[0])
     acc, swp = ctx.pt_stats()
     assert np.all(acc > 0.03) and np.all(acc < 0.6), acc
     assert swp[:, 1:].mean() > 0.02, swp
