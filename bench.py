@@ -151,6 +151,15 @@ def main():
         bytes_per_eval = 24 * n + 8 * d + 8
         flops_per_eval = (n - 1) * (42 * p * p + 22 * p + 9)
         achieved_gbs = bytes_per_eval * B / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/r01: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB per dispatch; gfx950
+        # FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound)
+        traffic_gbs_bytes, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_k_logdens_carma_pc_5_8_v2.json")
+        if B == 1024 and os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            traffic_gbs_bytes = (2.0 * pj["FETCH_SIZE"]["mean"] + pj["WRITE_SIZE"]["mean"]) * 1024.0
+            traffic_src = "profiles/r01/pmc_k_logdens_carma_pc_5_8_v2.json (rocprofv3 --pmc, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch"
         res = {
             "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
             "value": value,
@@ -175,8 +184,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "k_logdens_carma<5,8,1>",
+                "traffic": traffic_gbs_bytes,
+                "traffic_source": traffic_src,
+                "kernel": "k_logdens_carma_pc<5,8>" if B <= 4096 else "k_logdens_carma<5,8,W>",
                 "kernel_avg_us": 1e3 * kernel_ms,
                 "kernel_min_us": 1e3 * float(kdur_ms.min()),
                 "launch_period_us": 1e3 * dev_ms / args.steps,
