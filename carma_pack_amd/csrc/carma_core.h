@@ -78,6 +78,15 @@ struct Model {
     bool valid;      // prior bounds satisfied (or ignored)
 };
 
+// Root omega_rr of the AR polynomial encoded in theta (carpack.cpp:137-172), rr < P.
+template <int P>
+CARMA_DEV Cx own_ar_root(const double* theta, int rr)
+{
+    if ((P & 1) && rr == P - 1) return Cx{-exp(theta[3 + P - 1]), 0.0};
+    const int pair = rr >> 1;
+    return quad_root(theta[3 + 2 * pair], theta[3 + 2 * pair + 1], rr & 1);
+}
+
 // theta -> Model  (ARRoots, ExtractMA, ExtractSigsqr, CheckPriorBounds)
 template <int P, int G, class GrpT>
 CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const Prior& pr, int ignore_prior,
@@ -86,13 +95,7 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
     const int r = g.lane();
     const int rr = r < P ? r : P - 1;
     // --- own AR root (carpack.cpp:137-172)
-    if ((P & 1) && rr == P - 1) {
-        m.w.re = -exp(theta[3 + P - 1]);
-        m.w.im = 0.0;
-    } else {
-        int pair = rr >> 1;
-        m.w = quad_root(theta[3 + 2 * pair], theta[3 + 2 * pair + 1], rr & 1);
-    }
+    m.w = own_ar_root<P>(theta, rr);
 #pragma unroll
     for (int j = 0; j < P; j++) {
         m.wall[j].re = g.bcast(m.w.re, j);

@@ -19,6 +19,6 @@ hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* serie
 hipError_t launch_pt(int p, const PtLaunch& L, const double4* series, const Prior& pr, const double* temps,
                      double* theta, double* logpost, double* chol, unsigned* naccept, unsigned* nswap, double* samples,
                      double* sample_lp, hipStream_t st);
-size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out);
+size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out, int* pc_out);
 
 }  // namespace carma

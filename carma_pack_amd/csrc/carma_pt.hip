@@ -18,6 +18,7 @@
 
 #include "grp_device.h"
 #include "carma_pt_core.h"
+#include "carma_ring.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -27,7 +28,10 @@ struct PtGroupOf {
     static constexpr int value = P <= 1 ? 4 : (P <= 2 ? 2 : (P <= 4 ? 4 : 8));
 };
 
-template <int P, int G, int MAXT>
+// PC = true: latency-regime variant.  The workgroup carries one rho-producer wave per consumer wave
+// (carma_ring.h): threads [0, nthr/2) are the chains, threads [nthr/2, nthr) compute the transition
+// factors of the same chains' proposals into per-wave LDS rings.
+template <int P, int G, int MAXT, bool PC>
 __global__ __launch_bounds__(MAXT) void k_pt(PtLaunch L, const double4* __restrict__ series, Prior pr, const double* __restrict__ temps,
                      double* __restrict__ theta, double* __restrict__ logpost, double* __restrict__ chol,
                      unsigned* __restrict__ naccept, unsigned* __restrict__ nswap, double* __restrict__ samples,
@@ -35,13 +39,20 @@ __global__ __launch_bounds__(MAXT) void k_pt(PtLaunch L, const double4* __restri
 {
     extern __shared__ double4 smem4[];
     const int tid = threadIdx.x, nthr = blockDim.x;
+    const int nthr_c = PC ? nthr / 2 : nthr;                // consumer (chain) threads
     const int d = L.d, T = L.T, per = 4 * d + d * d;
-    double4* xch = smem4;                                   // one exchange slot per lane
-    double2* xch2 = reinterpret_cast<double2*>(smem4 + nthr);   // second exchange array (rho)
-    double* base = reinterpret_cast<double*>(smem4 + nthr + nthr / 2); // per chain: th, thn, z, v, R
+    double4* xch = smem4;                                   // one exchange slot per chain lane
+    double2* xch2 = reinterpret_cast<double2*>(smem4 + nthr_c);   // second exchange array (rho)
+    Cx* rings = reinterpret_cast<Cx*>(smem4 + nthr_c + nthr_c / 2);   // PC: one ring per consumer wave
+    const size_t ring_entries = PC ? (size_t)(nthr_c / 64) * RingGeom<P>::ENTRIES : 0;
+    double* base = reinterpret_cast<double*>(rings + ring_entries);    // per chain: th, thn, z, v, R
     double* s_lp = base + (size_t)T * per;
     double* s_temps = s_lp + T;
-    unsigned* s_nswap = reinterpret_cast<unsigned*>(s_temps + T);
+    double* s_dbeta = s_temps + T;                           // 1/T_i - 1/T_{i-1}
+    double* s_logu = s_dbeta + T;                            // log of the swap uniform of pair (i, i-1)
+    double* s_stage = s_logu + T;                            // [T][d] theta staging for the swap
+    unsigned* s_nswap = reinterpret_cast<unsigned*>(s_stage + (size_t)T * d);
+    int* s_src = reinterpret_cast<int*>(s_nswap + T);
     const long b = blockIdx.x;
 
     for (int i = tid; i < T * d; i += nthr) base[(i / d) * per + (i % d)] = theta[b * T * d + i];
@@ -49,12 +60,16 @@ __global__ __launch_bounds__(MAXT) void k_pt(PtLaunch L, const double4* __restri
     for (int i = tid; i < T; i += nthr) {
         s_lp[i] = logpost[b * T + i];
         s_temps[i] = temps[i];
+        s_dbeta[i] = i > 0 ? 1.0 / temps[i] - 1.0 / temps[i - 1] : 0.0;
         s_nswap[i] = 0;
     }
     __syncthreads();
 
-    Grp<G> g{xch + (tid & ~63), tid & 63, xch2 + (tid & ~63)};
-    const int c = tid / G;
+    const bool producer = PC && tid >= nthr_c;
+    const int ctid = producer ? tid - nthr_c : tid;         // lane of the chain this thread serves
+    Grp<G> g{xch + (ctid & ~63), ctid & 63, xch2 + (ctid & ~63)};
+    Cx* ring = rings + (size_t)(ctid >> 6) * RingGeom<P>::ENTRIES;
+    const int c = ctid / G;
     const bool active = c < T;
     const int cc = active ? c : 0;
     ChainScratch cs;
@@ -71,15 +86,51 @@ __global__ __launch_bounds__(MAXT) void k_pt(PtLaunch L, const double4* __restri
 
     for (int it = 0; it < L.niter; it++) {
         const uint64_t iter = L.iter0 + (uint64_t)it;
-        if (active) {
+        if constexpr (PC) {
+            // every wave passes: barrier A (proposals visible), then one barrier per ring chunk
+            // (a chain wave always holds at least one active group, so wrapping the chain work in
+            // `active` never lets a whole wave skip a barrier)
+            double znorm2 = 0.0;
+            if (!producer && active) znorm2 = ram_propose<G>(g, cs, d, iter, key);
+            __syncthreads();
+            if (producer) {
+                const int rr = g.lane() < P ? g.lane() : P - 1;
+                ring_produce<P, G>(g, own_ar_root<P>(cs.thn, rr), series, L.n, ring);
+            } else if (active) {
+                Model<P> m;
+                model_from_theta<P, G>(g, cs.thn, L.q, pr, 0, m);
+                bool sing;
+                double ll = ring_consume<P, G>(g, m, series, L.n, ring, &sing);
+                ll += log_prior(m.scale, pr.measerr_dof);
+                if (sing || !m.valid) ll = -1.0 / 0.0;
+                if (ram_finish<G>(g, cs, d, temperature, iter, L.maxiter, key, ll, znorm2, &lp)) nacc++;
+                if (g.lane() == 0) s_lp[c] = lp;
+            }
+        } else if (active) {
             if (ram_step<P, G>(g, cs, d, L.q, temperature, iter, L.maxiter, key, series, L.n, pr, &lp)) nacc++;
             if (g.lane() == 0) s_lp[c] = lp;
         }
         if (L.do_exchange && T > 1) {
+            // ExchangeStep sweep (steps.hpp:318-362): parallel draws + staging, serial decisions on
+            // the log-posteriors only, parallel theta moves.
+            if (active && !producer) {
+                for (int j = g.lane(); j < d; j += G) s_stage[c * d + j] = cs.th[j];
+                if (g.lane() == 0) {
+                    RngKey k2 = key;                      // keyed by the hotter chain's global slot
+                    s_logu[c] = c > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+                    s_src[c] = c;
+                }
+            }
             __syncthreads();
-            if (tid == 0) exchange_sweep(T, d, per, base, s_lp, s_temps, key, chain_base, iter, s_nswap);
+            if (tid == 0) exchange_decide(T, s_lp, s_dbeta, s_logu, s_src, s_nswap);
             __syncthreads();
-            if (active) lp = s_lp[c];
+            if (active && !producer) {
+                const int from = s_src[c];
+                if (from != c)
+                    for (int j = g.lane(); j < d; j += G) cs.th[j] = s_stage[from * d + j];
+                lp = s_lp[c];
+            }
+            __syncthreads();
         }
         if (L.save_thin > 0 && ((it + 1) % L.save_thin) == 0 && tid < G) {
             // coldest chain of this replica (Sampler::SaveValues, src/samplers.cpp:118-124)
@@ -97,16 +148,40 @@ __global__ __launch_bounds__(MAXT) void k_pt(PtLaunch L, const double4* __restri
         logpost[b * T + i] = s_lp[i];
         nswap[b * T + i] += s_nswap[i];
     }
-    if (active && g.lane() == 0) naccept[b * T + c] += nacc;
+    if (active && !producer && g.lane() == 0) naccept[b * T + c] += nacc;
 }
 
-size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out)
+// LDS bytes and threads of one workgroup; *pc_out tells whether the producer/consumer variant fits
+// (and pays: it needs p >= 2 and a series long enough to amortise the chunk barriers).
+size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out, int* pc_out)
 {
     const int G = P <= 1 ? 4 : (P <= 2 ? 2 : (P <= 4 ? 4 : 8));
-    int nthr = ((T * G + 63) / 64) * 64;
-    if (nthreads_out) *nthreads_out = nthr;
-    size_t per = 4 * (size_t)d + (size_t)d * d;
-    return (size_t)nthr * 48 + ((size_t)T * per + 2 * (size_t)T) * 8 + (size_t)T * 4 + 16;
+    const int nthr_c = ((T * G + 63) / 64) * 64;
+    const size_t per = 4 * (size_t)d + (size_t)d * d;
+    const size_t state = ((size_t)T * per + 4 * (size_t)T + (size_t)T * d) * 8 + (size_t)T * 8 + 16;
+    const size_t plain = (size_t)nthr_c * 48 + state;
+    const size_t with_ring = plain + (size_t)(nthr_c / 64) * 32768;
+    const bool pc = P >= 2 && 2 * nthr_c <= 1024 && with_ring <= 150 * 1024;
+    if (pc_out) *pc_out = pc ? 1 : 0;
+    if (nthreads_out) *nthreads_out = pc ? 2 * nthr_c : nthr_c;
+    return pc ? with_ring : plain;
+}
+
+template <int P, int G, int MAXT, bool PC>
+static hipError_t launch_pt_k(const PtLaunch& L, int nthr, size_t lds, const double4* series, const Prior& pr,
+                              const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
+                              unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt<P, G, MAXT, PC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_pt<P, G, MAXT, PC>), dim3((unsigned)L.R), dim3((unsigned)nthr), lds, st, L, series, pr, temps,
+                       theta, logpost, chol, naccept, nswap, samples, sample_lp);
+    return hipGetLastError();
 }
 
 template <int P>
@@ -115,25 +190,25 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
                               double* samples, double* sample_lp, hipStream_t st)
 {
     constexpr int G = PtGroupOf<P>::value;
-    int nthr = 0;
-    size_t lds = pt_lds_bytes(P, L.d, L.T, &nthr);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt<P, G, 256>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt<P, G, 1024>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    int nthr = 0, pc = 0;
+    const size_t lds = pt_lds_bytes(P, L.d, L.T, &nthr, &pc);
+    if constexpr (P >= 2) {
+        if (pc && L.n >= 32) {
+            if (nthr <= 256)
+                return launch_pt_k<P, G, 256, true>(L, nthr, lds, series, pr, temps, theta, logpost, chol, naccept, nswap,
+                                                    samples, sample_lp, st);
+            return launch_pt_k<P, G, 1024, true>(L, nthr, lds, series, pr, temps, theta, logpost, chol, naccept, nswap,
+                                                 samples, sample_lp, st);
+        }
     }
-    if (nthr <= 256)
-        hipLaunchKernelGGL((k_pt<P, G, 256>), dim3((unsigned)L.R), dim3((unsigned)nthr), lds, st, L, series, pr, temps,
-                           theta, logpost, chol, naccept, nswap, samples, sample_lp);
-    else
-        hipLaunchKernelGGL((k_pt<P, G, 1024>), dim3((unsigned)L.R), dim3((unsigned)nthr), lds, st, L, series, pr, temps,
-                           theta, logpost, chol, naccept, nswap, samples, sample_lp);
-    return hipGetLastError();
+    // plain variant: every chain wave computes its own rho
+    int nthr_plain = pc ? nthr / 2 : nthr;
+    const size_t lds_plain = pc ? lds - (size_t)(nthr_plain / 64) * 32768 : lds;
+    if (nthr_plain <= 256)
+        return launch_pt_k<P, G, 256, false>(L, nthr_plain, lds_plain, series, pr, temps, theta, logpost, chol, naccept,
+                                             nswap, samples, sample_lp, st);
+    return launch_pt_k<P, G, 1024, false>(L, nthr_plain, lds_plain, series, pr, temps, theta, logpost, chol, naccept,
+                                          nswap, samples, sample_lp, st);
 }
 
 hipError_t launch_pt(int p, const PtLaunch& L, const double4* series, const Prior& pr, const double* temps,

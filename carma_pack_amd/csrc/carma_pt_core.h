@@ -46,18 +46,14 @@ CARMA_DEV void chol_update_r1(const GrpT& g, int d, double* R, double* v, bool d
     }
 }
 
-// One RAM step (steps.cpp:60-107).  lp = stored log-posterior of the chain (updated on accept).
-// Returns true when the proposal was accepted.
-template <int P, int G, class GrpT>
-CARMA_DEV bool ram_step(const GrpT& g, const ChainScratch& cs, int d, int q, double temperature, uint64_t iter,
-                        int maxiter, const RngKey& key, const double4* __restrict__ series, int n, const Prior& pr,
-                        double* lp)
+// First half of a RAM step (steps.cpp:60-73): draw the unit proposal z ~ t_8^d and form
+// thn = th + R^T z.  Returns |z|^2.
+template <int G, class GrpT>
+CARMA_DEV double ram_propose(const GrpT& g, const ChainScratch& cs, int d, uint64_t iter, const RngKey& key)
 {
     const int r = g.lane();
-    // unit proposal z_k ~ t_8 (steps.cpp:65-69)
     for (int k = r; k < d; k += G) cs.z[k] = rng_student_t8(key, iter, (uint32_t)k);
     g.sync();
-    // scaled = R^T z ; new = old + scaled (steps.cpp:72-73)
     double znorm2 = 0.0;
     for (int k = 0; k < d; k++) znorm2 += cs.z[k] * cs.z[k];
     for (int j = r; j < d; j += G) {
@@ -67,12 +63,16 @@ CARMA_DEV bool ram_step(const GrpT& g, const ChainScratch& cs, int d, int q, dou
         cs.thn[j] = cs.th[j] + acc;
     }
     g.sync();
-    // Accept (steps.cpp:36-56): one Kalman log-density of the proposal, tempered
-    double ll;
-    if constexpr (P == 1)
-        ll = logdensity_car1(cs.thn, series, n, pr);
-    else
-        ll = logdensity_carma<P, G>(g, cs.thn, q, series, n, pr, 0);
+    return znorm2;
+}
+
+// Second half (steps.cpp:36-56, 77-99): Metropolis accept with the tempered ratio, then the RAM
+// rank-1 update of the proposal factor.  ll = log-density of the proposal.
+template <int G, class GrpT>
+CARMA_DEV bool ram_finish(const GrpT& g, const ChainScratch& cs, int d, double temperature, uint64_t iter, int maxiter,
+                          const RngKey& key, double ll, double znorm2, double* lp)
+{
+    const int r = g.lane();
     double alpha = (ll - *lp) / temperature;
     bool accept = false;
     const bool fin = (alpha - alpha) == 0.0;   // finite
@@ -97,6 +97,23 @@ CARMA_DEV bool ram_step(const GrpT& g, const ChainScratch& cs, int d, int q, dou
     }
     g.sync();
     return accept;
+}
+
+// One RAM step (steps.cpp:60-107).  lp = stored log-posterior of the chain (updated on accept).
+// Returns true when the proposal was accepted.
+template <int P, int G, class GrpT>
+CARMA_DEV bool ram_step(const GrpT& g, const ChainScratch& cs, int d, int q, double temperature, uint64_t iter,
+                        int maxiter, const RngKey& key, const double4* __restrict__ series, int n, const Prior& pr,
+                        double* lp)
+{
+    const double znorm2 = ram_propose<G>(g, cs, d, iter, key);
+    // Accept (steps.cpp:36-56): one Kalman log-density of the proposal
+    double ll;
+    if constexpr (P == 1)
+        ll = logdensity_car1(cs.thn, series, n, pr);
+    else
+        ll = logdensity_carma<P, G>(g, cs.thn, q, series, n, pr, 0);
+    return ram_finish<G>(g, cs, d, temperature, iter, maxiter, key, ll, znorm2, lp);
 }
 
 // ExchangeStep sweep hot -> cold over the T chains of one replica (steps.hpp:318-362), executed by
@@ -125,6 +142,36 @@ CARMA_DEV void exchange_sweep(int T, int d, int stride, double* th, double* lp, 
             nswap[i]++;
         }
     }
+}
+
+// The same sweep split for the GPU: the uniforms (as log u_i) are drawn in parallel by the chains
+// before the sweep and theta is NOT moved during it -- the sweep only needs the stored
+// log-posteriors, so one lane walks hot -> cold over lp[], records the resulting permutation in
+// src[] (src[i] = which chain's theta ends up at temperature i) and the chains copy their new theta
+// afterwards, in parallel.  u < min(exp(a), 1)  <=>  log u < a  (a NaN -> reject, as steps.hpp:336-338).
+// dbeta[i] = 1/T_i - 1/T_{i-1}, so a = (lp[i-1] - lp[i]) * dbeta[i]   (steps.hpp:331-332).
+CARMA_DEV void exchange_decide(int T, double* lp, const double* dbeta, const double* logu, int* src, unsigned* nswap)
+{
+    double hot = lp[T - 1];
+    int hot_src = src[T - 1];
+    for (int i = T - 1; i > 0; i--) {
+        const double cold = lp[i - 1];
+        const int cold_src = src[i - 1];
+        const double a = (cold - hot) * dbeta[i];
+        if (logu[i] < a) {
+            lp[i] = cold;            // temperature i now holds the colder chain's state
+            src[i] = cold_src;
+            nswap[i]++;
+            // `hot` (the state that moved down) is what temperature i-1 now holds
+        } else {
+            lp[i] = hot;
+            src[i] = hot_src;
+            hot = cold;
+            hot_src = cold_src;
+        }
+    }
+    lp[0] = hot;
+    src[0] = hot_src;
 }
 
 }  // namespace carma

@@ -189,7 +189,7 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     }
     Ctx* c = reinterpret_cast<Ctx*>(h);
     int nthr = 0;
-    const size_t lds = pt_lds_bytes(c->p, c->d, ntemps, &nthr);
+    const size_t lds = pt_lds_bytes(c->p, c->d, ntemps, &nthr, nullptr);
     if (nthr > 1024 || lds > 160 * 1024) {
         set_error("carma_pt_create: %d temperatures do not fit one workgroup (threads %d, LDS %zu B)", ntemps, nthr, lds);
         return CARMA_EINVAL;
