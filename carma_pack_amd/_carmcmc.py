@@ -180,10 +180,28 @@ class _KalmanBase(object):
         return vecD(self._var.tolist())
 
     def Predict(self, time):
-        raise NotImplementedError("KalmanFilter.Predict is not on the device yet (SURVEY.md §8f rank 1)")
+        """(mean, variance) of the process at `time` given the series (kfilter.hpp:122) -> pairD."""
+        m, v = self.PredictBatch([time])
+        return pairD(float(m[0]), float(v[0]))
 
     def Simulate(self, time):
-        raise NotImplementedError("KalmanFilter.Simulate is not on the device yet (SURVEY.md §8f rank 1)")
+        """Draw the process at `time` conditional on the series (KalmanFilter::Simulate,
+        kfilter.hpp:135-184): times are visited in ascending order, every drawn value is inserted
+        into the series with zero measurement error before the next time is predicted."""
+        times = np.sort(_arr(time))
+        t0, y0, e0 = self._t, self._y, self._e
+        out = np.empty(times.size)
+        try:
+            for i, tp in enumerate(times):
+                m, v = self.PredictBatch([tp])
+                out[i] = np.random.normal(m[0], np.sqrt(v[0]))
+                k = int(np.searchsorted(self._t, tp, side="left"))
+                self._t = np.insert(self._t, k, tp)
+                self._y = np.insert(self._y, k, out[i])
+                self._e = np.insert(self._e, k, 0.0)
+        finally:
+            self._t, self._y, self._e = t0, y0, e0
+        return vecD(out.tolist())
 
 
 class KalmanFilter1(_KalmanBase):
@@ -197,6 +215,10 @@ class KalmanFilter1(_KalmanBase):
         if self._sigsqr is None or self._omega is None:
             raise RuntimeError("KalmanFilter1: sigsqr and omega are not set")
         self._mean, self._var = _lib.kfilter_car1(self._t, self._y, self._e, self._sigsqr, self._omega)
+
+    def PredictBatch(self, times):
+        """Extension: all times in one launch (carma_predict_car1)."""
+        return _lib.predict_car1(self._t, self._y, self._e, self._sigsqr, self._omega, _arr(times))
 
 
 class KalmanFilterp(_KalmanBase):
@@ -213,3 +235,7 @@ class KalmanFilterp(_KalmanBase):
         if self._sigsqr is None or self._omega is None or self._ma is None:
             raise RuntimeError("KalmanFilterp: sigsqr, omega and ma_coefs are not set")
         self._mean, self._var = _lib.kfilter_carma(self._t, self._y, self._e, self._sigsqr, self._omega, self._ma)
+
+    def PredictBatch(self, times):
+        """Extension: all times in one launch (carma_predict_carma)."""
+        return _lib.predict_carma(self._t, self._y, self._e, self._sigsqr, self._omega, self._ma, _arr(times))

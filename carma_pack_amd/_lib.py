@@ -52,6 +52,9 @@ def _load():
     L.carma_kfilter_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp,
                                       _ip, C.c_int]
     L.carma_kfilter_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _ip, C.c_int]
+    L.carma_predict_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, C.c_int,
+                                      _dp, _dp, C.c_int]
+    L.carma_predict_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp, C.c_int]
     L.carma_pt_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64,
                                _dp, _dp]
     L.carma_pt_create.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64]
@@ -75,7 +78,7 @@ EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
     "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logprior", "carma_kfilter_carma",
-    "carma_kfilter_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
+    "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done",
 ]
@@ -266,3 +269,30 @@ def kfilter_car1(time, y, yerr, sigsqr, omega, device=None):
                                 ptr(var), C.byref(nout), default_device() if device is None else device)
     check(rc, "carma_kfilter_car1")
     return mean[:nout.value], var[:nout.value]
+
+
+def predict_carma(time, y, yerr, sigsqr, omega, ma, tpred, device=None):
+    """KalmanFilterp::Predict for all `tpred` in one launch -> (mean[M], var[M])."""
+    time, y, yerr = as_f64(time), as_f64(y), as_f64(yerr)
+    omega = np.asarray(omega, dtype=complex)
+    om = as_f64(np.c_[omega.real, omega.imag])
+    ma = as_f64(ma)
+    tp = as_f64(np.atleast_1d(tpred))
+    pm, pv = np.empty(tp.size), np.empty(tp.size)
+    rc = lib.carma_predict_carma(ptr(time), ptr(y), ptr(yerr), time.size, omega.size, float(sigsqr), ptr(om), ptr(ma),
+                                 ma.size, ptr(tp), tp.size, ptr(pm), ptr(pv),
+                                 default_device() if device is None else device)
+    if rc == 1:
+        raise CarmaError("KalmanFilterp: singular eigenvector matrix (solve failed)")
+    check(rc, "carma_predict_carma")
+    return pm, pv
+
+
+def predict_car1(time, y, yerr, sigsqr, omega, tpred, device=None):
+    time, y, yerr = as_f64(time), as_f64(y), as_f64(yerr)
+    tp = as_f64(np.atleast_1d(tpred))
+    pm, pv = np.empty(tp.size), np.empty(tp.size)
+    check(lib.carma_predict_car1(ptr(time), ptr(y), ptr(yerr), time.size, float(sigsqr), float(omega), ptr(tp), tp.size,
+                                 ptr(pm), ptr(pv), default_device() if device is None else device),
+          "carma_predict_car1")
+    return pm, pv

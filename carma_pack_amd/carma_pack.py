@@ -5,8 +5,8 @@ Same public names and call signatures -- ``CarmaModel`` (``run_mcmc``, ``get_mle
 ``get_ar_roots``, ``power_spectrum``, ``carma_variance``, ``car1_process``, ``carma_process`` -- but a
 fresh implementation: derived quantities are vectorised numpy, every log-density goes through one
 batched launch, the sampler runs on the GPU, and ``run_mcmc``/``get_mle`` can use many independent
-replicas at once (``nreplicas``).  Plotting bodies and ``predict``/``simulate``/``assess_fit`` (which
-need the device Predict kernel) are not part of the hot path.
+replicas at once (``nreplicas``).  ``predict``/``simulate``/``assess_fit`` use the batched device
+Predict kernel (one launch for all requested times); plotting bodies are not part of the hot path.
 """
 import numpy as np
 from scipy.optimize import minimize
@@ -303,9 +303,32 @@ class CarmaSample(MCMCSample):
         return kf, mu
 
     def predict(self, time, bestfit="map"):
-        raise NotImplementedError("needs the device Predict kernel (SURVEY.md §8f rank 1)")
+        """Expected value and variance of the series at `time` given the data and a point estimate of
+        the parameters (reference :755-805).  All times go to the GPU in one batched launch instead of
+        one full re-filter per time.  Returns (yhat, yhat_var)."""
+        scalar = np.isscalar(time)
+        kf, mu = self.makeKalmanFilter(bestfit)
+        m, v = kf.PredictBatch(np.atleast_1d(time))
+        return (m[0] + mu, v[0]) if scalar else (m + mu, v)
 
-    simulate = assess_fit = predict
+    def simulate(self, time, bestfit="map"):
+        """Random draw of the process at `time` conditional on the data (reference :807-837)."""
+        kf, mu = self.makeKalmanFilter(bestfit)
+        return np.array(kf.Simulate(np.atleast_1d(time))) + mu
+
+    def assess_fit(self, bestfit="map", nplot=256, doShow=False):
+        """Numerical part of assess_fit (reference :687-753): the interpolated path on `nplot` times,
+        the standardised residuals of the one-step predictions and their autocorrelation function.
+        Plotting is outside the hot path."""
+        kf, mu = self.makeKalmanFilter(bestfit)
+        kf.Filter()
+        kmean, kvar = np.array(kf.GetMean()), np.array(kf.GetVar())
+        resid = (self.y - mu - kmean) / np.sqrt(kvar)
+        tgrid = np.linspace(self.time.min(), self.time.max(), nplot)
+        pm, pv = kf.PredictBatch(tgrid)
+        r0 = resid - resid.mean()
+        acf = np.correlate(r0, r0, mode="full")[r0.size - 1:] / np.sum(r0 * r0)
+        return dict(time=tgrid, mean=pm + mu, var=pv, std_resid=resid, resid_acf=acf)
 
 
 class Car1Sample(CarmaSample):

@@ -354,4 +354,72 @@ int carma_kfilter_car1(const double* time, const double* y, const double* yerr, 
     return kfilter_common(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, mean, var, n_out, device);
 }
 
+// KalmanFilter*::Predict for M times in one launch.
+static int predict_common(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
+                          const double* omega_re_im, const double* ma, int nma, double car1_omega, const double* tpred,
+                          int M, double* pmean, double* pvar, int device)
+{
+    if (!time || !y || !yerr || !tpred || !pmean || !pvar || n < 1 || M < 0) {
+        set_error("carma_predict: bad argument");
+        return CARMA_EINVAL;
+    }
+    if (M == 0) return CARMA_OK;
+    int rc = select_device(device);
+    if (rc != CARMA_OK) return rc;
+    std::vector<double> t(time, time + n), yy(y, y + n), ee(yerr, yerr + n);
+    if (n >= 2) sort_dedup(t, yy, ee);
+    const int m = (int)t.size();
+    std::vector<double> s = pack_series(t, yy, ee);
+    std::vector<double> par(2 * CARMA_PMAX + CARMA_PMAX, 0.0);
+    if (p > 1) {
+        for (int i = 0; i < 2 * p; i++) par[i] = omega_re_im[i];
+        for (int i = 0; i < p && i < nma; i++) par[2 * CARMA_PMAX + i] = ma[i];
+    }
+    double *d_s = nullptr, *d_par = nullptr, *d_io = nullptr;
+    int* d_sing = nullptr;
+    hipError_t e = hipMalloc(&d_s, sizeof(double) * s.size());
+    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = hipMalloc(&d_io, sizeof(double) * 3 * (size_t)M);
+    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_io, tpred, sizeof(double) * M, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_sing, 0, sizeof(int));
+    if (e == hipSuccess) {
+        if (p == 1)
+            e = launch_predict_car1(sigsqr, car1_omega, reinterpret_cast<const double4*>(d_s), m, d_io, M, d_io + M,
+                                    d_io + 2 * (size_t)M, nullptr);
+        else
+            e = launch_predict_carma(p, d_par, d_par + 2 * CARMA_PMAX, sigsqr, reinterpret_cast<const double4*>(d_s), m,
+                                     d_io, M, d_io + M, d_io + 2 * (size_t)M, d_sing, nullptr);
+    }
+    int sing = 0;
+    if (e == hipSuccess) e = hipMemcpy(pmean, d_io + M, sizeof(double) * M, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pvar, d_io + 2 * (size_t)M, sizeof(double) * M, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&sing, d_sing, sizeof(int), hipMemcpyDeviceToHost);
+    if (d_s) (void)hipFree(d_s);
+    if (d_par) (void)hipFree(d_par);
+    if (d_io) (void)hipFree(d_io);
+    if (d_sing) (void)hipFree(d_sing);
+    if (e != hipSuccess) return hip_fail(e, "carma_predict");
+    return sing ? 1 : CARMA_OK;
+}
+
+int carma_predict_carma(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
+                        const double* omega_re_im, const double* ma, int nma, const double* tpred, int M, double* pmean,
+                        double* pvar, int device)
+{
+    if (p < 2 || p > CARMA_PMAX || !omega_re_im || !ma || nma < 1) {
+        set_error("carma_predict_carma: need 2 <= p <= %d, omega and ma", CARMA_PMAX);
+        return CARMA_EINVAL;
+    }
+    return predict_common(time, y, yerr, n, p, sigsqr, omega_re_im, ma, nma, 0.0, tpred, M, pmean, pvar, device);
+}
+
+int carma_predict_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr, double omega,
+                       const double* tpred, int M, double* pmean, double* pvar, int device)
+{
+    return predict_common(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, tpred, M, pmean, pvar, device);
+}
+
 }  // extern "C"

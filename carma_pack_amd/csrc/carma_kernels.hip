@@ -17,6 +17,7 @@
 #include "grp_device.h"
 #include "carma_core.h"
 #include "carma_ring.h"
+#include "carma_predict.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -112,6 +113,50 @@ __global__ __launch_bounds__(64) void k_kfilter_car1(double sigsqr, double omega
     if (threadIdx.x == 0) car1_filter(sigsqr, omega, 0.0, 1.0, series, n, true, mean, var);
 }
 
+// KalmanFilterp::Predict for M times at once: one lane group per prediction time.
+template <int P, int G>
+__global__ __launch_bounds__(64) void k_predict_carma(const double* __restrict__ om_re_im, const double* __restrict__ ma,
+                                                      double sigsqr, const double4* __restrict__ series, int n,
+                                                      const double* __restrict__ tpred, int M, double* __restrict__ pmean,
+                                                      double* __restrict__ pvar, int* __restrict__ singular)
+{
+    __shared__ double4 xch[64];
+    __shared__ double2 xch2[64];
+    const int tid = threadIdx.x;
+    Grp<G> g{xch, tid & 63, xch2};
+    long e = ((long)blockIdx.x * 64 + tid) / G;
+    const bool live = e < M;
+    if (!live) e = M - 1;
+    Model<P> m;
+    const int r = g.lane() < P ? g.lane() : P - 1;
+    m.w = {om_re_im[2 * r], om_re_im[2 * r + 1]};
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        m.wall[j] = {om_re_im[2 * j], om_re_im[2 * j + 1]};
+        m.beta[j] = ma[j];
+    }
+    m.sigsqr = sigsqr;
+    m.mu = 0.0;
+    m.scale = 1.0;
+    m.valid = true;
+    double pm, pv;
+    bool sing;
+    predict_run<P, G>(g, m, series, n, tpred[e], &pm, &pv, &sing);
+    if (live && g.lane() == 0) {
+        pmean[e] = pm;
+        pvar[e] = pv;
+        if (sing) *singular = 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_predict_car1(double sigsqr, double omega, const double4* __restrict__ series, int n,
+                                                     const double* __restrict__ tpred, int M, double* __restrict__ pmean,
+                                                     double* __restrict__ pvar)
+{
+    const long e = (long)blockIdx.x * 64 + threadIdx.x;
+    if (e < M) predict_car1(sigsqr, omega, series, n, tpred[e], pmean + e, pvar + e);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int P>
 static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, const double4* series, int n,
@@ -189,6 +234,39 @@ hipError_t launch_kfilter_carma(int p, const double* om, const double* ma, doubl
         case 7: return launch_kfilter_p<7>(om, ma, sigsqr, series, n, mean, var, singular, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <int P>
+static hipError_t launch_predict_p(const double* om, const double* ma, double sigsqr, const double4* series, int n,
+                                   const double* tpred, int M, double* pmean, double* pvar, int* singular, hipStream_t st)
+{
+    constexpr int G = GroupOf<P>::value;
+    const unsigned blocks = (unsigned)(((long)M * G + 63) / 64);
+    hipLaunchKernelGGL((k_predict_carma<P, G>), dim3(blocks), dim3(64), 0, st, om, ma, sigsqr, series, n, tpred, M, pmean,
+                       pvar, singular);
+    return hipGetLastError();
+}
+
+hipError_t launch_predict_carma(int p, const double* om, const double* ma, double sigsqr, const double4* series, int n,
+                                const double* tpred, int M, double* pmean, double* pvar, int* singular, hipStream_t st)
+{
+    switch (p) {
+        case 2: return launch_predict_p<2>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
+        case 3: return launch_predict_p<3>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
+        case 4: return launch_predict_p<4>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
+        case 5: return launch_predict_p<5>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
+        case 6: return launch_predict_p<6>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
+        case 7: return launch_predict_p<7>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_predict_car1(double sigsqr, double omega, const double4* series, int n, const double* tpred, int M,
+                               double* pmean, double* pvar, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)(((long)M + 63) / 64);
+    hipLaunchKernelGGL(k_predict_car1, dim3(blocks), dim3(64), 0, st, sigsqr, omega, series, n, tpred, M, pmean, pvar);
+    return hipGetLastError();
 }
 
 hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* series, int n, double* mean, double* var,

@@ -15,6 +15,12 @@ hipError_t launch_kfilter_carma(int p, const double* om_re_im, const double* ma,
 hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* series, int n, double* mean, double* var,
                                hipStream_t st);
 
+hipError_t launch_predict_carma(int p, const double* om_re_im, const double* ma, double sigsqr, const double4* series,
+                                int n, const double* tpred, int M, double* pmean, double* pvar, int* singular,
+                                hipStream_t st);
+hipError_t launch_predict_car1(double sigsqr, double omega, const double4* series, int n, const double* tpred, int M,
+                               double* pmean, double* pvar, hipStream_t st);
+
 // one chunk of the persistent PT sampler kernel (carma_pt.hip)
 hipError_t launch_pt(int p, const PtLaunch& L, const double4* series, const Prior& pr, const double* temps,
                      double* theta, double* logpost, double* chol, unsigned* naccept, unsigned* nswap, double* samples,

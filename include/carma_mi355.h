@@ -94,6 +94,20 @@ int carma_kfilter_car1(const double* time, const double* y, const double* yerr, 
                        int device);
 
 /*
+ * KalmanFilterp::Predict / KalmanFilter1::Predict (src/kfilter.cpp:218-337, 72-135, 51-69; wrapper
+ * :87,98) for M times in ONE launch: conditional mean and variance of the (noise-free) process at
+ * tpred[i] given the whole measured series -- interpolation, forecast (tpred > max time) and
+ * backcast (tpred < min time).  The reference re-filters the series once per requested time; here
+ * every time is one lane group.  Inputs as for carma_kfilter_*; pmean/pvar = [M].  Returns 1 on a
+ * singular eigenvector system.
+ */
+int carma_predict_carma(const double* time, const double* y, const double* yerr, int n, int p,
+                        double sigsqr, const double* omega_re_im, const double* ma, int nma,
+                        const double* tpred, int M, double* pmean, double* pvar, int device);
+int carma_predict_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr,
+                       double omega, const double* tpred, int M, double* pmean, double* pvar, int device);
+
+/*
  * Parallel-tempered Robust-Adaptive-Metropolis sampler == RunCarmaSampler / RunCar1Sampler
  * (src/carmcmc.cpp:30-177; bindings run_mcmc_car1 / run_mcmc_carma, boost_python_wrapper.cpp:76-77)
  * with every chain advanced on the GPU by one persistent kernel (carma_pt.hip).

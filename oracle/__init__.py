@@ -13,6 +13,8 @@ from .oracle import (  # noqa: F401
     lib,
     ma_coefs,
     max_threads,
+    predict_car1,
+    predict_carma,
     sort_dedup,
     variance,
 )

@@ -524,3 +524,180 @@ void orc_chol_update_r1(int d, double *L, double *v, int downdate)
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Prediction (interpolation / forecast / backcast) -- SURVEY.md §8(f) rank 1.
+ * src/kfilter.cpp:218-286 KalmanFilterp::Predict with :290-337 InitializeCoefs / UpdateCoefs.
+ * y centred, yerr as given.  Returns 0, or -1 on a singular Vandermonde solve.                    */
+int orc_predict_carma(int n, const double *t, const double *y, const double *yerr, int p, double sigsqr,
+                      const double *om_re, const double *om_im, const double *ma, double time,
+                      double *pmean, double *pvar)
+{
+    cplx omega[ORC_PMAX], E[ORC_PMAX * ORC_PMAX], Ework[ORC_PMAX * ORC_PMAX], J[ORC_PMAX], b[ORC_PMAX];
+    cplx V[ORC_PMAX * ORC_PMAX], P[ORC_PMAX * ORC_PMAX], x[ORC_PMAX], g[ORC_PMAX], rho[ORC_PMAX];
+    cplx sconst[ORC_PMAX], sslope[ORC_PMAX];
+    double *var = malloc(sizeof(double) * n), *mean = malloc(sizeof(double) * n);
+    int rc = 0;
+    for (int i = 0; i < p; i++) omega[i] = om_re[i] + om_im[i] * I;
+    int ipredict = 0;                                        /* :221-229 */
+    while (time > t[ipredict]) { ipredict++; if (ipredict == n) break; }
+    /* Reset (:138-186) */
+    for (int j = 0; j < p; j++) { cplx pw = 1.0; for (int i = 0; i < p; i++) { E[i * p + j] = pw; pw *= omega[j]; } }
+    for (int i = 0; i < p; i++) J[i] = 0.0;
+    J[p - 1] = 1.0;
+    memcpy(Ework, E, sizeof(cplx) * p * p);
+    if (zgesv_small(p, Ework, J) != 0) { rc = -1; goto done; }
+    for (int j = 0; j < p; j++) { cplx s = 0.0; for (int i = 0; i < p; i++) s += ma[i] * E[i * p + j]; b[j] = s; }
+    for (int i = 0; i < p; i++)
+        for (int j = i; j < p; j++) {
+            V[i * p + j] = -sigsqr * J[i] * conj(J[j]) / (omega[i] + conj(omega[j]));
+            V[j * p + i] = conj(V[i * p + j]);
+        }
+    memcpy(P, V, sizeof(cplx) * p * p);
+    for (int i = 0; i < p; i++) x[i] = 0.0;
+#define BPB(OUT) do { cplx acc_ = 0.0; for (int j_ = 0; j_ < p; j_++) { cplx s_ = 0.0; \
+        for (int i_ = 0; i_ < p; i_++) s_ += b[i_] * P[i_ * p + j_]; acc_ += s_ * conj(b[j_]); } (OUT) = creal(acc_); } while (0)
+#define GAIN(DEN) do { for (int i_ = 0; i_ < p; i_++) { cplx s_ = 0.0; \
+        for (int j_ = 0; j_ < p; j_++) s_ += P[i_ * p + j_] * conj(b[j_]); g[i_] = s_ / (DEN); } } while (0)
+#define DOWNDATE(DEN) do { for (int i_ = 0; i_ < p; i_++) for (int j_ = 0; j_ < p; j_++) \
+        P[i_ * p + j_] -= (DEN) * (g[i_] * conj(g[j_])); } while (0)
+#define TIMEUPD(DT) do { for (int i_ = 0; i_ < p; i_++) rho[i_] = cexp(omega[i_] * (DT)); \
+        for (int i_ = 0; i_ < p; i_++) for (int j_ = 0; j_ < p; j_++) \
+            P[i_ * p + j_] = (rho[i_] * conj(rho[j_])) * (P[i_ * p + j_] - V[i_ * p + j_]) + V[i_ * p + j_]; } while (0)
+    mean[0] = 0.0;
+    BPB(var[0]);
+    var[0] += yerr[0] * yerr[0];
+    double innovation = y[0];
+    for (int k = 1; k < ipredict; k++) {                      /* Update x (ipredict-1)  (:231-234) */
+        GAIN(var[k - 1]);
+        for (int i = 0; i < p; i++) x[i] += g[i] * innovation;
+        DOWNDATE(var[k - 1]);
+        TIMEUPD(t[k] - t[k - 1]);
+        for (int i = 0; i < p; i++) x[i] = rho[i] * x[i];
+        cplx m = 0.0;
+        for (int i = 0; i < p; i++) m += b[i] * x[i];
+        mean[k] = creal(m);
+        BPB(var[k]);
+        var[k] += yerr[k] * yerr[k];
+        innovation = y[k] - mean[k];
+    }
+    double ypredict_mean, ypredict_var, yprecision;
+    if (ipredict == 0) {                                      /* backcast (:238-241) */
+        ypredict_mean = 0.0;
+        BPB(ypredict_var);                                    /* P == V here */
+    } else {                                                  /* :242-255 */
+        GAIN(var[ipredict - 1]);
+        for (int i = 0; i < p; i++) x[i] += g[i] * innovation;
+        DOWNDATE(var[ipredict - 1]);
+        double dt = fabs(time - t[ipredict - 1]);
+        TIMEUPD(dt);
+        for (int i = 0; i < p; i++) x[i] = rho[i] * x[i];
+        cplx m = 0.0;
+        for (int i = 0; i < p; i++) m += b[i] * x[i];
+        ypredict_mean = creal(m);
+        BPB(ypredict_var);
+    }
+    if (ipredict == n) { *pmean = ypredict_mean; *pvar = ypredict_var; goto done; }   /* forecast (:257-261) */
+    yprecision = 1.0 / ypredict_var;
+    ypredict_mean *= yprecision;
+    {   /* InitializeCoefs(time, ipredict, ypredict_mean / yprecision, ypredict_var)  (:290-314) */
+        double ymean = ypredict_mean / yprecision, yvar = ypredict_var;
+        GAIN(yvar);
+        for (int i = 0; i < p; i++) { sconst[i] = x[i] - g[i] * ymean; sslope[i] = g[i]; }
+        DOWNDATE(yvar);
+        double dt = fabs(t[ipredict] - time);
+        TIMEUPD(dt);
+        for (int i = 0; i < p; i++) { sconst[i] = rho[i] * sconst[i]; sslope[i] = rho[i] * sslope[i]; }
+    }
+    double yconst, yslope;
+    {
+        cplx a = 0.0, c = 0.0;
+        for (int i = 0; i < p; i++) { a += b[i] * sconst[i]; c += b[i] * sslope[i]; }
+        yconst = creal(a); yslope = creal(c);
+        BPB(var[ipredict]);
+        var[ipredict] += yerr[ipredict] * yerr[ipredict];
+    }
+    yprecision += yslope * yslope / var[ipredict];                              /* :272-273 */
+    ypredict_mean += yslope * (y[ipredict] - yconst) / var[ipredict];
+    for (int k = ipredict + 1; k < n; k++) {                                     /* UpdateCoefs (:318-337) */
+        GAIN(var[k - 1]);
+        for (int i = 0; i < p; i++) { sconst[i] += g[i] * (y[k - 1] - yconst); sslope[i] -= g[i] * yslope; }
+        DOWNDATE(var[k - 1]);
+        TIMEUPD(t[k] - t[k - 1]);
+        for (int i = 0; i < p; i++) { sconst[i] = rho[i] * sconst[i]; sslope[i] = rho[i] * sslope[i]; }
+        cplx a = 0.0, c = 0.0;
+        for (int i = 0; i < p; i++) { a += b[i] * sconst[i]; c += b[i] * sslope[i]; }
+        yconst = creal(a); yslope = creal(c);
+        BPB(var[k]);
+        var[k] += yerr[k] * yerr[k];
+        yprecision += yslope * yslope / var[k];
+        ypredict_mean += yslope * (y[k] - yconst) / var[k];
+    }
+    ypredict_var = 1.0 / yprecision;
+    ypredict_mean *= ypredict_var;
+    *pmean = ypredict_mean;
+    *pvar = ypredict_var;
+done:
+    free(var); free(mean);
+    return rc;
+#undef BPB
+#undef GAIN
+#undef DOWNDATE
+#undef TIMEUPD
+}
+
+/* src/kfilter.cpp:72-135 KalmanFilter1::Predict with :51-69 InitializeCoefs / UpdateCoefs. */
+void orc_predict_car1(int n, const double *t, const double *y, const double *yerr, double sigsqr, double omega,
+                      double time, double *pmean, double *pvar)
+{
+    double *mean = malloc(sizeof(double) * n), *var = malloc(sizeof(double) * n);
+    int ipredict = 0;
+    while (time > t[ipredict]) { ipredict++; if (ipredict == n) break; }
+    mean[0] = 0.0;
+    var[0] = sigsqr / (2.0 * omega) + yerr[0] * yerr[0];
+    for (int k = 1; k < ipredict; k++) {
+        double rho = exp(-1.0 * omega * (t[k] - t[k - 1]));
+        double previous_var = var[k - 1] - yerr[k - 1] * yerr[k - 1];
+        double var_ratio = previous_var / var[k - 1];
+        mean[k] = rho * mean[k - 1] + rho * var_ratio * (y[k - 1] - mean[k - 1]);
+        var[k] = sigsqr / (2.0 * omega) * (1.0 - rho * rho) + rho * rho * previous_var * (1.0 - var_ratio);
+        var[k] += yerr[k] * yerr[k];
+    }
+    double ypredict_mean, ypredict_var;
+    if (ipredict == 0) {
+        ypredict_mean = 0.0;
+        ypredict_var = sigsqr / (2.0 * omega);
+    } else {
+        double dt = time - t[ipredict - 1];
+        double rho = exp(-dt * omega);
+        double previous_var = var[ipredict - 1] - yerr[ipredict - 1] * yerr[ipredict - 1];
+        double var_ratio = previous_var / var[ipredict - 1];
+        ypredict_mean = rho * mean[ipredict - 1] + rho * var_ratio * (y[ipredict - 1] - mean[ipredict - 1]);
+        ypredict_var = sigsqr / (2.0 * omega) * (1.0 - rho * rho) + rho * rho * previous_var * (1.0 - var_ratio);
+    }
+    if (ipredict == n) { *pmean = ypredict_mean; *pvar = ypredict_var; free(mean); free(var); return; }
+    double yprecision = 1.0 / ypredict_var;
+    ypredict_mean *= yprecision;
+    /* InitializeCoefs(time, ipredict, 0, 0) (:51-56) */
+    double yconst = 0.0;
+    double yslope = exp(-fabs(t[ipredict] - time) * omega);
+    var[ipredict] = sigsqr / (2.0 * omega) * (1.0 - yslope * yslope) + yerr[ipredict] * yerr[ipredict];
+    yprecision += yslope * yslope / var[ipredict];
+    ypredict_mean += yslope * (y[ipredict] - yconst) / var[ipredict];
+    for (int k = ipredict + 1; k < n; k++) {                 /* UpdateCoefs (:59-69) */
+        double rho = exp(-1.0 * (t[k] - t[k - 1]) * omega);
+        double previous_var = var[k - 1] - yerr[k - 1] * yerr[k - 1];
+        double var_ratio = previous_var / var[k - 1];
+        yslope *= rho * (1.0 - var_ratio);
+        yconst = yconst * rho * (1.0 - var_ratio) + rho * var_ratio * y[k - 1];
+        var[k] = sigsqr / (2.0 * omega) * (1.0 - rho * rho) + rho * rho * previous_var * (1.0 - var_ratio) +
+                 yerr[k] * yerr[k];
+        yprecision += yslope * yslope / var[k];
+        ypredict_mean += yslope * (y[k] - yconst) / var[k];
+    }
+    ypredict_var = 1.0 / yprecision;
+    ypredict_mean *= ypredict_var;
+    *pmean = ypredict_mean;
+    *pvar = ypredict_var;
+    free(mean); free(var);
+}

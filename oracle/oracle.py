@@ -60,6 +60,9 @@ def lib():
         L.orc_sort_dedup.restype = C.c_int
         L.orc_chol_update_r1.argtypes = [C.c_int, _dp, _dp, C.c_int]
         L.orc_max_threads.restype = C.c_int
+        L.orc_predict_carma.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, _dp, _dp, _dp, C.c_double, _dp, _dp]
+        L.orc_predict_carma.restype = C.c_int
+        L.orc_predict_car1.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         _lib = L
     return _lib
 
@@ -125,6 +128,37 @@ def kfilter_car1(t, y, yerr, sigsqr, omega):
     t, y, yerr = _a(t), _a(y), _a(yerr)
     mean, var = np.empty(t.size), np.empty(t.size)
     lib().orc_kfilter_car1(t.size, _p(t), _p(y), _p(yerr), float(sigsqr), float(omega), _p(mean), _p(var))
+    return mean, var
+
+
+def predict_carma(t, y, yerr, sigsqr, roots, ma, times):
+    """KalmanFilterp::Predict for each time in `times` (y centred)."""
+    t, y, yerr = _a(t), _a(y), _a(yerr)
+    roots = np.asarray(roots, dtype=complex)
+    p = roots.size
+    re, im = _a(roots.real), _a(roots.imag)
+    mav = np.zeros(p)
+    mav[: len(ma)] = ma
+    times = np.atleast_1d(np.asarray(times, dtype=float))
+    mean, var = np.empty(times.size), np.empty(times.size)
+    m1, v1 = np.empty(1), np.empty(1)
+    for i, tp in enumerate(times):
+        rc = lib().orc_predict_carma(t.size, _p(t), _p(y), _p(yerr), p, float(sigsqr), _p(re), _p(im), _p(mav),
+                                     float(tp), _p(m1), _p(v1))
+        if rc != 0:
+            raise RuntimeError("singular EigenMat solve")
+        mean[i], var[i] = m1[0], v1[0]
+    return mean, var
+
+
+def predict_car1(t, y, yerr, sigsqr, omega, times):
+    t, y, yerr = _a(t), _a(y), _a(yerr)
+    times = np.atleast_1d(np.asarray(times, dtype=float))
+    mean, var = np.empty(times.size), np.empty(times.size)
+    m1, v1 = np.empty(1), np.empty(1)
+    for i, tp in enumerate(times):
+        lib().orc_predict_car1(t.size, _p(t), _p(y), _p(yerr), float(sigsqr), float(omega), float(tp), _p(m1), _p(v1))
+        mean[i], var[i] = m1[0], v1[0]
     return mean, var
 
 

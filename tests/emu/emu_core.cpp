@@ -187,3 +187,59 @@ extern "C" void emu_rng_draws(unsigned seed0, unsigned seed1, unsigned chain, lo
         u[i] = rng_uniform(key, (uint64_t)i, RNG_ACCEPT, 0);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Predict (carma_predict.h)
+#include "../../carma_pack_amd/csrc/carma_predict.h"
+
+template <int P>
+static void predict_one(const double* om_re, const double* om_im, const double* ma, double sigsqr, const double4* series,
+                        int n, double tp, double* pm, double* pv)
+{
+    constexpr int G = GroupOf<P>::value;
+    run_group<G>([&](const Grp<G>& g) {
+        Model<P> m;
+        int r = g.lane() < P ? g.lane() : P - 1;
+        m.w = {om_re[r], om_im[r]};
+        for (int j = 0; j < P; j++) {
+            m.wall[j] = {om_re[j], om_im[j]};
+            m.beta[j] = ma[j];
+        }
+        m.sigsqr = sigsqr;
+        m.mu = 0.0;
+        m.scale = 1.0;
+        m.valid = true;
+        double a, b;
+        bool s;
+        predict_run<P, G>(g, m, series, n, tp, &a, &b, &s);
+        if (g.lane() == 0) {
+            *pm = a;
+            *pv = b;
+        }
+    });
+}
+
+extern "C" int emu_predict_carma(int p, const double* om_re, const double* om_im, const double* ma, double sigsqr,
+                                 const double* series, int n, const double* tpred, int M, double* pmean, double* pvar)
+{
+    const double4* s4 = reinterpret_cast<const double4*>(series);
+    for (int i = 0; i < M; i++) {
+        switch (p) {
+            case 2: predict_one<2>(om_re, om_im, ma, sigsqr, s4, n, tpred[i], pmean + i, pvar + i); break;
+            case 3: predict_one<3>(om_re, om_im, ma, sigsqr, s4, n, tpred[i], pmean + i, pvar + i); break;
+            case 4: predict_one<4>(om_re, om_im, ma, sigsqr, s4, n, tpred[i], pmean + i, pvar + i); break;
+            case 5: predict_one<5>(om_re, om_im, ma, sigsqr, s4, n, tpred[i], pmean + i, pvar + i); break;
+            case 6: predict_one<6>(om_re, om_im, ma, sigsqr, s4, n, tpred[i], pmean + i, pvar + i); break;
+            case 7: predict_one<7>(om_re, om_im, ma, sigsqr, s4, n, tpred[i], pmean + i, pvar + i); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+extern "C" void emu_predict_car1(double sigsqr, double omega, const double* series, int n, const double* tpred, int M,
+                                 double* pmean, double* pvar)
+{
+    const double4* s4 = reinterpret_cast<const double4*>(series);
+    for (int i = 0; i < M; i++) predict_car1(sigsqr, omega, s4, n, tpred[i], pmean + i, pvar + i);
+}

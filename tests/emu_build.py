@@ -100,3 +100,29 @@ def rng_draws(seed, chain, n):
     L.emu_rng_draws.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_long, _dp, _dp]
     L.emu_rng_draws(seed & 0xffffffff, seed >> 32, chain, n, _p(t8), _p(u))
     return t8, u
+
+
+def predict_carma(t, y, yerr, sigsqr, omega, ma, times):
+    s = pack_series(t, y, yerr)
+    omega = np.asarray(omega, dtype=complex)
+    p = omega.size
+    re, im = np.ascontiguousarray(omega.real), np.ascontiguousarray(omega.imag)
+    mav = np.zeros(p)
+    mav[:len(ma)] = ma
+    times = np.ascontiguousarray(np.atleast_1d(times), dtype=float)
+    pm, pv = np.empty(times.size), np.empty(times.size)
+    L = lib()
+    L.emu_predict_carma.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int, _dp, C.c_int, _dp, _dp]
+    rc = L.emu_predict_carma(p, _p(re), _p(im), _p(mav), float(sigsqr), _p(s), t.size, _p(times), times.size, _p(pm), _p(pv))
+    assert rc == 0
+    return pm, pv
+
+
+def predict_car1(t, y, yerr, sigsqr, omega, times):
+    s = pack_series(t, y, yerr)
+    times = np.ascontiguousarray(np.atleast_1d(times), dtype=float)
+    pm, pv = np.empty(times.size), np.empty(times.size)
+    L = lib()
+    L.emu_predict_car1.argtypes = [C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int, _dp, _dp]
+    L.emu_predict_car1(float(sigsqr), float(omega), _p(s), t.size, _p(times), times.size, _p(pm), _p(pv))
+    return pm, pv

@@ -66,3 +66,42 @@ def test_emu_singular_and_bounds(golden_dir):
     th = g["theta"][0].copy()
     th[1] = 2.5
     assert emu.logdensity_carma(t, y, yerr, 5, 3, th, pr)[0] == -np.inf
+
+
+def test_emu_predict_vs_oracle_and_golden(golden_dir):
+    """carma_predict.h (uniform n+1-point walk with per-group phase selection) vs the literal
+    restatement of KalmanFilterp::Predict and the reference-Python golden vectors."""
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    pr = np.load(os.path.join(golden_dir, "predict.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    times = np.r_[pr["times"], pr["back"], t[0], t[5]]
+    for tag in ("true", "th17"):
+        mu, scale = float(pr[tag + "_mu"]), float(pr[tag + "_scale"])
+        args = (t, y - mu, np.sqrt(scale) * yerr, float(pr[tag + "_sigsqr"]), pr[tag + "_omega"], pr[tag + "_ma"])
+        em, ev = emu.predict_carma(*args, times)
+        om, ov = orc.predict_carma(*args, times)
+        np.testing.assert_allclose(em, om, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(ev, ov, rtol=1e-9)
+        k = pr["times"].size
+        np.testing.assert_allclose(em[:k], pr[tag + "_pmean"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(ev[:k + 2], pr[tag + "_dvar"], rtol=1e-6)
+    c = np.load(os.path.join(golden_dir, "car1_n100.npz"))
+    th = pr["car1_theta"]
+    w = np.exp(th[3])
+    em, ev = emu.predict_car1(c["t"], c["y"] - th[2], np.sqrt(th[1]) * c["yerr"], 2 * th[0] ** 2 * w, w, pr["car1_times"])
+    np.testing.assert_allclose(em, pr["car1_dmean"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(ev, pr["car1_dvar"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("p,q", [(2, 1), (3, 0), (4, 2), (6, 3), (7, 6)])
+def test_emu_predict_orders(p, q):
+    t, y, yerr = irregular_series(60, seed=p + q)
+    rng = np.random.default_rng(p * 7 + q)
+    th = prior_like_theta(rng, p, q, t, y)
+    om, ma = orc.ar_roots(th, p), orc.ma_coefs(th, p, q)
+    sig = th[0] ** 2 / orc.variance(om, ma)
+    times = np.r_[t[0] - 1.0, rng.uniform(t[0], t[-1], 5), t[-1] + 2.0]
+    a = emu.predict_carma(t, y - th[2], yerr, sig, om, ma, times)
+    b = orc.predict_carma(t, y - th[2], yerr, sig, om, ma, times)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-8)

@@ -114,8 +114,17 @@ def test_kalman_filters(cm, data):
     kf2, mu = ps.makeKalmanFilter("map")
     kf2.Filter()
     assert len(kf2.GetMean()) == 10
-    with pytest.raises(NotImplementedError):
-        kfp.Predict(11.0)
+    # testKalmanp / testKalman1: extrapolation is less certain than the prediction at a datum
+    pred0, predN = kfp.Predict(d["xv"][0]), kfp.Predict(d["xv"][-1] + 1)
+    assert predN.second > pred0.second
+    p1a, p1b = kf.Predict(d["xv"][0]), kf.Predict(d["xv"][-1] + 1)
+    assert p1b.second > p1a.second
+    sim = kfp.Simulate(cm.vecD([2.5, 11.0, 4.5]))
+    assert len(sim) == 3 and np.all(np.isfinite(sim))
+    yhat, yvar = ps.predict(np.array([3.3, 12.0]))
+    assert yhat.shape == (2,) and np.all(yvar > 0)
+    fit = ps.assess_fit(nplot=32)
+    assert fit["mean"].shape == (32,) and fit["std_resid"].shape == (10,)
 
 
 def test_carma_model_mcmc_and_mle(cm, golden_dir):

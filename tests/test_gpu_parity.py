@@ -225,3 +225,62 @@ def test_long_series_vs_oracle(cpa, p, q, n):
     want = m.logdensity_batch(th, ignore_prior=True, nthreads=8)
     worst = assert_parity(got, want, RTOL, "p=%d q=%d n=%d" % (p, q, n), arbiter=arb, max_arbitrated=3)
     print("p=%d q=%d n=%d worst rel err %.2e" % (p, q, n, worst))
+
+
+def test_predict_golden_and_oracle(cpa, readme, golden_dir):
+    """Device Predict (one launch for all times) vs reference-Python golden vectors, the dense GP
+    conditional (carma_unit_tests.cpp:505-649: rel 1e-6, incl. backcasts) and the oracle."""
+    g = readme
+    pr = np.load(os.path.join(golden_dir, "predict.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    times, back = pr["times"], pr["back"]
+    from carma_pack_amd import _lib
+    for tag in ("true", "th3", "th17"):
+        mu, scale = float(pr[tag + "_mu"]), float(pr[tag + "_scale"])
+        args = (t, y - mu, np.sqrt(scale) * yerr, float(pr[tag + "_sigsqr"]), pr[tag + "_omega"], pr[tag + "_ma"])
+        allt = np.r_[times, back, t[0], t[7], t[-1]]
+        m, v = _lib.predict_carma(*args, allt)
+        k = times.size
+        np.testing.assert_allclose(m[:k], pr[tag + "_pmean"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(v[:k], pr[tag + "_pvar"], rtol=1e-8)
+        np.testing.assert_allclose(m[:k + 2], pr[tag + "_dmean"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(v[:k + 2], pr[tag + "_dvar"], rtol=1e-6)
+        om, ov = orc.predict_carma(*args, allt)
+        np.testing.assert_allclose(m, om, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(v, ov, rtol=1e-9)
+    # a big ragged batch (assess_fit-like): 1000 times incl. unsorted input series
+    rng = np.random.default_rng(0)
+    tt = rng.uniform(t[0] - 20, t[-1] + 50, 1000)
+    perm = rng.permutation(t.size)
+    m, v = _lib.predict_carma(t[perm], (y - 17.0)[perm], yerr[perm], float(g["true_sigsqr"]), g["true_omega"],
+                              g["true_ma"], tt)
+    om, ov = orc.predict_carma(t, y - 17.0, yerr, float(g["true_sigsqr"]), g["true_omega"], g["true_ma"], tt[::25])
+    np.testing.assert_allclose(m[::25], om, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(v[::25], ov, rtol=1e-9)
+    assert np.all(v > 0)
+
+
+def test_predict_car1(cpa, golden_dir):
+    c = np.load(os.path.join(golden_dir, "car1_n100.npz"))
+    pr = np.load(os.path.join(golden_dir, "predict.npz"))
+    th = pr["car1_theta"]
+    w = np.exp(th[3])
+    from carma_pack_amd import _lib
+    m, v = _lib.predict_car1(c["t"], c["y"] - th[2], np.sqrt(th[1]) * c["yerr"], 2 * th[0] ** 2 * w, w, pr["car1_times"])
+    np.testing.assert_allclose(m, pr["car1_dmean"], rtol=1e-8, atol=1e-10)      # carma_unit_tests.cpp:277-385
+    np.testing.assert_allclose(v, pr["car1_dvar"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("p,q", [(2, 1), (3, 0), (4, 3), (6, 2), (7, 6)])
+def test_predict_orders(cpa, p, q):
+    from carma_pack_amd import _lib
+    t, y, yerr = irregular_series(150, seed=p + q)
+    rng = np.random.default_rng(p * 7 + q)
+    th = prior_like_theta(rng, p, q, t, y)
+    om, ma = orc.ar_roots(th, p), orc.ma_coefs(th, p, q)
+    sig = th[0] ** 2 / orc.variance(om, ma)
+    times = np.r_[t[0] - 1.0, rng.uniform(t[0], t[-1], 40), t[-1] + 2.0]
+    a = _lib.predict_carma(t, y - th[2], yerr, sig, om, ma, times)
+    b = orc.predict_carma(t, y - th[2], yerr, sig, om, ma, times)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-8)

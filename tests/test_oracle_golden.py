@@ -200,3 +200,36 @@ def test_batch_threads_agree(golden_dir):
     np.testing.assert_array_equal(a, b)
     for i in range(4):
         assert a[i] == m.logdensity(g["theta"][i])
+
+
+def test_predict_matches_reference_python_and_dense_gp(golden_dir):
+    """KalmanFilterp::Predict restatement vs KalmanFilterDeprecated.predict (interpolation, at a
+    datum, forecast) and vs the dense GP conditional incl. backcasts (carma_unit_tests.cpp:505-649:
+    rel 1e-6)."""
+    g = _load(golden_dir, "carma53_readme.npz")
+    pr = _load(golden_dir, "predict.npz")
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    times, back = pr["times"], pr["back"]
+    for tag in ("true", "th3", "th17"):
+        mu, scale = float(pr[tag + "_mu"]), float(pr[tag + "_scale"])
+        args = (t, y - mu, np.sqrt(scale) * yerr, float(pr[tag + "_sigsqr"]), pr[tag + "_omega"], pr[tag + "_ma"])
+        m, v = orc.predict_carma(*args, times)
+        np.testing.assert_allclose(m, pr[tag + "_pmean"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(v, pr[tag + "_pvar"], rtol=1e-9)
+        m2, v2 = orc.predict_carma(*args, np.r_[times, back])
+        np.testing.assert_allclose(m2, pr[tag + "_dmean"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(v2, pr[tag + "_dvar"], rtol=1e-6)
+        # forecast variance grows towards the stationary variance
+        assert v[-1] > v[-2] > v[-3]
+
+
+def test_predict_car1_matches_dense_gp(golden_dir):
+    """carma_unit_tests.cpp:277-385 (rel 1e-8)."""
+    c = _load(golden_dir, "car1_n100.npz")
+    pr = _load(golden_dir, "predict.npz")
+    th = pr["car1_theta"]
+    omega = np.exp(th[3])
+    m, v = orc.predict_car1(c["t"], c["y"] - th[2], np.sqrt(th[1]) * c["yerr"], 2 * th[0] ** 2 * omega, omega,
+                            pr["car1_times"])
+    np.testing.assert_allclose(m, pr["car1_dmean"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(v, pr["car1_dvar"], rtol=1e-8)
