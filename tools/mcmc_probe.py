@@ -1,8 +1,8 @@
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import carma_pack_amd as cpa
-g = np.load('tests/golden/carma53_readme.npz')
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/carma53_readme.npz'))
 t, y, yerr = g['t'], g['y'], g['yerr']
 ms = 10*np.sqrt(np.mean(y*y)-np.mean(y)**2)
 ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms)
