@@ -344,6 +344,8 @@ CARMA_DEV double recip(double v)
 // second exchange array.  (carma_ring.h has the variant fed by a producer wave.)
 template <int P, class GrpT>
 struct RhoInline {
+    static constexpr bool kRing = false;
+    CARMA_DEV double4 record(int) const { return double4{}; }
     const GrpT& g;
     Cx w;            // own root
     Cx rho_next;     // factor of the upcoming step
@@ -455,6 +457,150 @@ CARMA_DEV double filter_loop(const GrpT& g, const Model<P>& m, const FilterConst
     return acc.total();
 }
 
+// Diagnostic build only (-DCARMA_STAMPS): where a step spends its cycles (shares, not run time).
+#if defined(CARMA_STAMPS) && defined(__HIPCC__)
+#define CARMA_STAMP(var)                                                        \
+    do {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+    } while (0)
+#define CARMA_STAMP_DECL unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sa = 0, sb = 0, sc = 0, sd = 0
+#define CARMA_STAMP_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define CARMA_STAMP(var) do { } while (0)
+#define CARMA_STAMP_DECL do { } while (0)
+#define CARMA_STAMP_ACC(acc, a, b) do { } while (0)
+#endif
+
+// The same update loop in REAL modal coordinates (the default).
+//
+// The data are real, so the rotated state of a conjugate root pair (2k, 2k+1) is a conjugate pair
+// itself, x_{2k+1} = conj(x_{2k}), and the p complex coordinates carry only p real degrees of
+// freedom: z_{2k} = Re x_{2k}, z_{2k+1} = Im x_{2k} for a complex pair, z_r = x_r for a real root.
+// In these coordinates (lane r <-> coordinate r, row r of the real symmetric D = Cov(z) - V_z):
+//     y      = h.z,  h_{2k} = 2 Re b_{2k}, h_{2k+1} = -2 Im b_{2k}   (real root: h_r = b_r)
+//     k      = Cov(z, y) = D h^T + c,   c_{2k} = Re (V b^H)_{2k}, c_{2k+1} = Im (V b^H)_{2k}
+//     var    = s0 + h D h^T + e,        mean = h.z
+//     z     <- Phi (z + k s innov),     D <- Phi (D - k k^T s) Phi^T
+// where Phi is block diagonal: a rotation-scaling [[c,-s],[s,c]], c + i s = rho_{2k}, per complex pair
+// and the scalar rho_r per real root.  With every lane holding its OWN rho_r = (c_r, s_r) (the odd
+// member of a pair holds the conjugate, s_{2k+1} = -s_{2k}) both members use the same formulas
+//     (d Phi^T)_{r,j} = d_{r,j} c_j - d_{r,j^1} s_j ,     (Phi m)_{r,j} = c_r m_{r,j} - s_r m_{r^1,j}
+// and a real root (s = 0) needs no special case.  Same model, same likelihood as kfilter.cpp:189-215
+// -- ~45 FP64 instructions per step for the covariance instead of ~120 in complex arithmetic, the
+// partner row comes from the neighbouring lane by DPP (quad_perm xor 1).
+template <int P, int G, bool WRITE_MV, class GrpT, class RhoSrc>
+CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const FilterConsts<P>& fc, RhoSrc& src,
+                                  const double4* __restrict__ series, int n, double* mean_out, double* var_out)
+{
+    const int r = g.lane();
+    const bool act = r < P;
+    const bool cpx = (m.w.im != 0.0) && (r < (P & ~1));     // member of a complex-conjugate pair
+    const bool odd = r & 1;
+    // observation row h and gain offset c in real coordinates
+    const double c_im_partner = g.partner(fc.c_own.im);       // Im (V b^H) of the even member
+    const double h_own = !act ? 0.0 : (cpx ? (odd ? 2.0 * fc.b_own.im : 2.0 * fc.b_own.re) : fc.b_own.re);
+    const double c_own = cpx ? (odd ? c_im_partner : fc.c_own.re) : fc.c_own.re;
+    double hall[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) hall[j] = g.bcast(h_own, j);
+    const double s0 = fc.s0;
+
+    double D[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) D[j] = 0.0;
+    double z = 0.0;
+    double k = c_own;
+    double pvr = 0.0, pmr = 0.0;
+    LogLikAcc acc;
+    acc.init();
+    double4 rprev = series[0];
+    double4 rcur = series[n > 1 ? 1 : 0];
+    double4 rnxt = series[n > 2 ? 2 : n - 1];
+    src.begin(1, rcur.x);
+    double var = 0.0, innov = 0.0;
+    CARMA_STAMP_DECL;
+    for (int kk = 1; kk <= n; kk++) {
+        const bool last = (kk == n);
+        CARMA_STAMP(st0);
+        double4 rnn = rnxt;
+        if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
+        g.publish(k, pvr, pmr, 0.0);
+        if (!last) src.publish(kk);
+        double4 o[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) o[j] = g.peek(j);
+        if constexpr (RhoSrc::kRing) rprev = src.record(kk);     // series record kk-1 from the ring
+        Cx rho, rj[P];
+        if (!last) src.fetch(kk, rho, rj);
+        g.done_reading();
+        if (!last) src.prepare(kk + 1, rnxt.x);
+        CARMA_STAMP(st1);
+        double pv = o[0].y, pm = o[0].z;
+#pragma unroll
+        for (int j = 1; j < P; j++) {
+            pv += o[j].y;
+            pm += o[j].z;
+        }
+        var = s0 + pv + rprev.z * m.scale;           // kfilter.cpp:180-182, 209-210
+        innov = (rprev.y - m.mu) - pm;               // kfilter.cpp:184, 207, 213
+        acc.add_var(var);
+        if (WRITE_MV && r == 0) {
+            mean_out[kk - 1] = pm;
+            var_out[kk - 1] = var;
+        }
+        const double s = recip(var);
+        const double si = s * innov;
+        acc.chi2 += innov * si;
+        if (last) break;
+        CARMA_STAMP(st2);
+        // state (kfilter.cpp:191-194, 200-201)
+        z = fma(k, si, z);
+        const double zp = g.partner(z);
+        z = rho.re * z - rho.im * zp;
+        // covariance (kfilter.cpp:197, 204)
+        const double t = k * s;
+        double d[P], mm[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) d[j] = fma(-t, o[j].x, D[j]);
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            if (j < (P & ~1))
+                mm[j] = d[j] * rj[j].re - d[j ^ 1] * rj[j].im;
+            else
+                mm[j] = d[j] * rj[j].re;
+        }
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const double mp = g.partner(mm[j]);
+            D[j] = rho.re * mm[j] - rho.im * mp;
+            if (j & 1)
+                w1 = fma(D[j], hall[j], w1);
+            else
+                w0 = fma(D[j], hall[j], w0);
+        }
+        const double w = w0 + w1;                    // (D h^T)_r
+        k = w + c_own;
+        pvr = h_own * w;
+        pmr = h_own * z;
+        rprev = rcur;
+        rcur = rnxt;
+        rnxt = rnn;
+        CARMA_STAMP(st3);
+        CARMA_STAMP_ACC(sa, st0, st1);
+        CARMA_STAMP_ACC(sb, st1, st2);
+        CARMA_STAMP_ACC(sc, st2, st3);
+    }
+#if defined(CARMA_STAMPS) && defined(__HIPCC__)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("stamps per step: exchange+wait %.1f  reduce+rcp %.1f  update %.1f cycles (n=%d)\n", (double)sa / (n - 1),
+               (double)sb / (n - 1), (double)sc / (n - 1), n);
+#endif
+    return acc.total();
+}
+
 // Kalman filter of one evaluation (Reset + n-1 Updates) -> log-likelihood sum (no prior).
 // y is centred with m.mu and yerr^2 scaled with m.scale on the fly (carpack.hpp:150-153).
 // If WRITE_MV, lane 0 of the group also stores the one-step means/variances.
@@ -466,7 +612,11 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
     FilterConsts<P> fc;
     filter_reset<P, G>(g, m, fc);
     RhoInline<P, GrpT> src{g, m.w, Cx{1.0, 0.0}};
+#ifdef CARMA_COMPLEX_LOOP
     double ll = filter_loop<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
+#else
+    double ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
+#endif
     *singular = fc.sing;
     return ll;
 }

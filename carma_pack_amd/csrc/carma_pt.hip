@@ -160,7 +160,8 @@ size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out, int* pc_out)
     const size_t per = 4 * (size_t)d + (size_t)d * d;
     const size_t state = ((size_t)T * per + 4 * (size_t)T + (size_t)T * d) * 8 + (size_t)T * 8 + 16;
     const size_t plain = (size_t)nthr_c * 48 + state;
-    const size_t with_ring = plain + (size_t)(nthr_c / 64) * 32768;
+    const size_t ring_bytes = RingGeom<2>::BYTES;            // same for every P
+    const size_t with_ring = plain + (size_t)(nthr_c / 64) * ring_bytes;
     const bool pc = P >= 2 && 2 * nthr_c <= 1024 && with_ring <= 150 * 1024;
     if (pc_out) *pc_out = pc ? 1 : 0;
     if (nthreads_out) *nthreads_out = pc ? 2 * nthr_c : nthr_c;
@@ -203,7 +204,7 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
     }
     // plain variant: every chain wave computes its own rho
     int nthr_plain = pc ? nthr / 2 : nthr;
-    const size_t lds_plain = pc ? lds - (size_t)(nthr_plain / 64) * 32768 : lds;
+    const size_t lds_plain = pc ? lds - (size_t)(nthr_plain / 64) * RingGeom<2>::BYTES : lds;
     if (nthr_plain <= 256)
         return launch_pt_k<P, G, 256, false>(L, nthr_plain, lds_plain, series, pr, temps, theta, logpost, chol, naccept,
                                              nswap, samples, sample_lp, st);

@@ -28,29 +28,52 @@ namespace carma {
 
 template <int P>
 struct RingGeom {
-    static constexpr int C = 16;                                    // steps per chunk
-    static constexpr int SLOT = 64;                                 // Cx entries per step (one per lane)
-    static constexpr int ENTRIES = 2 * C * SLOT;                    // Cx entries in the ring
-    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 32 KiB
+    static constexpr int C = 16;                                    // passes per chunk
+    static constexpr int SLOT = 64;                                 // Cx entries per pass (one per lane)
+    static constexpr int ENTRIES = 2 * C * SLOT + 2 * C * 2;        // Cx-sized entries: rho ring + series records
+    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 33 KiB
+    static constexpr int REC_OFF = 2 * C * SLOT;                    // series records: double4[2][C]
 };
 
-// Producer: all n-1 steps of the 64/G evaluations of this workgroup.
+// The loop of filter_loop_real makes n passes kk = 1..n; pass kk needs the series record kk-1
+// (y, yerr^2 for var_{kk-1}) and, for kk < n, the factors rho(dt_kk).  The producer stages both, so
+// the consumer loop has no scalar loads at all (scalar loads share the LDS wait counter and return
+// out of order, which would force every LDS wait of the consumer to also cover an L2 round trip).
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_uniform);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_uniform);
+    return __hiloint2double(hi, lo);
+}
+
 template <int P, int G>
 __device__ __forceinline__ void ring_produce(const Grp<G>& g, const Cx w, const double4* __restrict__ series, int n,
                                              Cx* __restrict__ ring)
 {
     constexpr int C = RingGeom<P>::C;
     const int lane = g.lane64;
-    const int nsteps = n - 1;
-    const int nchunks = (nsteps + C - 1) / C;
+    const int nchunks = (n + C - 1) / C;
+    double4* recs = reinterpret_cast<double4*>(ring + RingGeom<P>::REC_OFF);
+    // lane s (< C) fetches what pass s of a chunk needs -- record kk-1 and dt_kk -- with vector loads
+    // one chunk ahead, so no load latency sits in front of the exp/sincos stream
+    const int ls = lane < C ? lane : C - 1;
+    auto clampi = [n](int i) { return i < n ? i : n - 1; };
+    double4 rec_n = series[clampi(ls)];
+    double dt_n = series[clampi(1 + ls)].x;
     for (int c = 0; c < nchunks; c++) {
         Cx* buf = ring + (size_t)(c & 1) * C * RingGeom<P>::SLOT;
+        const double4 rec_c = rec_n;
+        const double dt_c = dt_n;
+        const int kk0 = 1 + c * C;
+        rec_n = series[clampi(kk0 + C + ls - 1)];
+        dt_n = series[clampi(kk0 + C + ls)].x;
+        if (lane < C && kk0 + lane <= n) recs[(c & 1) * C + lane] = rec_c;
 #pragma unroll 1
         for (int s = 0; s < C; s++) {
-            const int k = 1 + c * C + s;
-            if (k < n) {
+            const double dt = readlane_f64(dt_c, s);
+            if (kk0 + s < n) {
                 Cx rho;
-                cexp_step(w.re, w.im, series[k].x, &rho.re, &rho.im);
+                cexp_step(w.re, w.im, dt, &rho.re, &rho.im);
                 buf[(size_t)s * RingGeom<P>::SLOT + lane] = rho;
             }
         }
@@ -62,15 +85,24 @@ __device__ __forceinline__ void ring_produce(const Grp<G>& g, const Cx w, const 
 // (Reading the entries one step ahead was measured slower: 141 vs 127 us per 1024-eval launch.)
 template <int P, int G>
 struct RhoRing {
+    static constexpr bool kRing = true;
     const Grp<G>& g;
     const Cx* ring;
     CARMA_DEV void begin(int, double) {}
     CARMA_DEV void publish(int) const {}
-    CARMA_DEV void fetch(int k, Cx& rho, Cx (&rj)[P]) const
+    // series record kk-1; first ring access of pass kk, so the chunk barrier lives here
+    CARMA_DEV double4 record(int kk) const
     {
         constexpr int C = RingGeom<P>::C;
-        const int c = (k - 1) / C, s = (k - 1) % C;
+        const int c = (kk - 1) / C, s = (kk - 1) % C;
         if (s == 0) __syncthreads();                       // chunk c is in the ring
+        const double4* recs = reinterpret_cast<const double4*>(ring + RingGeom<P>::REC_OFF);
+        return recs[(c & 1) * C + s];
+    }
+    CARMA_DEV void fetch(int kk, Cx& rho, Cx (&rj)[P]) const
+    {
+        constexpr int C = RingGeom<P>::C;
+        const int c = (kk - 1) / C, s = (kk - 1) % C;
         const Cx* slot = ring + ((size_t)(c & 1) * C + s) * RingGeom<P>::SLOT + g.gbase();
         rho = slot[g.lane()];
 #pragma unroll
@@ -86,7 +118,7 @@ __device__ __forceinline__ double ring_consume(const Grp<G>& g, const Model<P>& 
     FilterConsts<P> fc;
     filter_reset<P, G>(g, m, fc);
     RhoRing<P, G> src{g, ring};
-    double ll = filter_loop<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
+    double ll = filter_loop_real<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
     *singular = fc.sing;
     return ll;
 }

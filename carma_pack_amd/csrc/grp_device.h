@@ -66,6 +66,8 @@ struct Grp {
         if (G >= 16) v = fmax(v, dpp_mirror(v));
         return v;
     }
+    // value held by the neighbouring lane (lane ^ 1): the other member of a root pair
+    CARMA_DEV static double partner(double v) { return dpp_xor1(v); }
     // value of v held by lane j of this group (j identical in every lane of the group)
     CARMA_DEV double bcast(double v, int j) const { return __shfl(v, gbase() + j, 64); }
     CARMA_DEV int bcast_i(int v, int j) const { return __shfl(v, gbase() + j, 64); }

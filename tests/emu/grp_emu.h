@@ -87,6 +87,7 @@ struct Grp {
         return v;
     }
     double bcast(double v, int j) const { return xchg(v, j); }
+    double partner(double v) const { return xchg(v, r ^ 1); }
     int bcast_i(int v, int j) const
     {
         sh->islot[r] = v;
