@@ -167,9 +167,9 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     // Latency-bound path: spread waves over as many CUs as possible (1 wave/block) until the
     // chip is covered, then pack 4 waves per block.
     const long waves = ((long)B + EPW - 1) / EPW;
-    if (waves <= 512 && n >= 8) {
+    if (waves <= 1024 && n >= 8) {
         // few evaluations in flight: one wave's instruction stream is the run time, so split it
-        // (consumer + rho producer, carma_ring.h).  At most 2 workgroups per CU.
+        // (consumer + rho producer, carma_ring.h).  At most 4 workgroups (37 KiB of LDS each) per CU.
         const size_t lds = 128 * sizeof(double4) + RingGeom<P>::BYTES;
         static bool attr_set = false;
         if (!attr_set) {
