@@ -1,0 +1,151 @@
+"""Lock-step bounded quasi-Newton minimiser for MANY independent starts.
+
+carma_pack's ``get_mle`` runs ``ntrials`` separate ``scipy.optimize.minimize(..., "L-BFGS-B")``
+searches and crosses the FFI once per function evaluation (reference carma_pack.py:92-129,195-260).
+On the GPU one log-density costs the same as a thousand, so all starts are advanced together: per
+iteration ONE batched launch evaluates the central-difference stencils of every active start
+(B x (2d+1) points) and every backtracking round is one more launch.  The update is a projected
+L-BFGS step (two-loop recursion per start, vectorised over starts; variables sitting on a bound with
+the gradient pointing outwards are frozen) with an Armijo backtracking line search; stopping rules
+mirror L-BFGS-B's defaults (relative decrease <= 1e7*eps or projected gradient <= 1e-5).
+"""
+import numpy as np
+
+
+class BatchResult(object):
+    """scipy.optimize.OptimizeResult look-alike for one start."""
+
+    def __init__(self, x, fun, nit, nfev, success, message):
+        self.x, self.fun, self.nit, self.nfev, self.success, self.message = x, fun, nit, nfev, success, message
+
+    def __repr__(self):
+        return "BatchResult(fun=%r, nit=%d, success=%r)" % (self.fun, self.nit, self.success)
+
+
+def _project(x, lo, hi):
+    return np.minimum(np.maximum(x, lo), hi)
+
+
+def minimize_batched(fun_batch, x0, bounds, maxiter=300, m=8, ftol=2.220446049250313e-09, gtol=1e-5, fd_step=1e-6):
+    """Minimise f independently from every row of x0.
+
+    fun_batch : callable mapping an array [N, d] to [N] function values (non-finite = infeasible)
+    x0        : [B, d] starting points;  bounds : list of (lo, hi) with None for unbounded
+    Returns a list of B BatchResult."""
+    x = np.array(x0, dtype=float)
+    B, d = x.shape
+    lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=float)
+    hi = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
+    x = _project(x, lo, hi)
+    BIG = 1e300
+    nfev = np.zeros(B, dtype=int)
+
+    def f_and_g(xs, idx):
+        n = xs.shape[0]
+        h = fd_step * np.maximum(1.0, np.abs(xs))
+        up = np.minimum(xs + h, hi)                       # one-sided at a bound
+        dn = np.maximum(xs - h, lo)
+        pts = np.empty((n, 2 * d + 1, d))
+        pts[:] = xs[:, None, :]
+        ar = np.arange(d)
+        pts[:, 1 + ar, ar] = up
+        pts[:, 1 + d + ar, ar] = dn
+        f = np.asarray(fun_batch(pts.reshape(-1, d)), dtype=float).reshape(n, 2 * d + 1)
+        f = np.where(np.isfinite(f), f, BIG)
+        g = (f[:, 1:d + 1] - f[:, d + 1:]) / np.maximum(up - dn, 1e-300)
+        g[(f[:, 1:d + 1] >= BIG) | (f[:, d + 1:] >= BIG)] = 0.0
+        nfev[idx] += 2 * d + 1
+        return f[:, 0], g
+
+    f, g = f_and_g(x, np.arange(B))
+    S = np.zeros((B, m, d))
+    Y = np.zeros((B, m, d))
+    rho = np.zeros((B, m))
+    nhist = np.zeros(B, dtype=int)
+    active = np.ones(B, dtype=bool)
+    nit = np.zeros(B, dtype=int)
+    msg = ["maximum number of iterations reached"] * B
+    for _ in range(maxiter):
+        idx = np.flatnonzero(active)
+        if idx.size == 0:
+            break
+        xa, fa, ga = x[idx], f[idx], g[idx]
+        # variables pinned at a bound with the gradient pushing outwards are frozen
+        frozen = ((xa <= lo) & (ga > 0)) | ((xa >= hi) & (ga < 0))
+        pg = np.where(frozen, 0.0, ga)
+        done = np.max(np.abs(pg), axis=1) <= gtol
+        for i in idx[done]:
+            msg[i] = "converged: projected gradient <= gtol"
+        active[idx[done]] = False
+        keep = ~done
+        idx, xa, fa, ga, pg, frozen = idx[keep], xa[keep], fa[keep], ga[keep], pg[keep], frozen[keep]
+        if idx.size == 0:
+            break
+        # two-loop recursion, vectorised over the starts (history slots beyond nhist are zero)
+        q = pg.copy()
+        nh = nhist[idx]
+        alpha = np.zeros((idx.size, m))
+        for k in range(m - 1, -1, -1):
+            use = (k < nh)
+            a = rho[idx, k] * np.einsum("ij,ij->i", S[idx, k], q)
+            a = np.where(use, a, 0.0)
+            alpha[:, k] = a
+            q -= a[:, None] * Y[idx, k]
+        last = np.maximum(nh - 1, 0)
+        ys = np.einsum("ij,ij->i", S[idx, last], Y[idx, last])
+        yy = np.einsum("ij,ij->i", Y[idx, last], Y[idx, last])
+        gamma = np.where((nh > 0) & (yy > 0), ys / np.maximum(yy, 1e-300), 1.0 / np.maximum(np.linalg.norm(pg, axis=1), 1e-12))
+        r = gamma[:, None] * q
+        for k in range(m):
+            use = (k < nh)
+            b = rho[idx, k] * np.einsum("ij,ij->i", Y[idx, k], r)
+            r += np.where(use, alpha[:, k] - b, 0.0)[:, None] * S[idx, k]
+        direction = -np.where(frozen, 0.0, r)
+        slope = np.einsum("ij,ij->i", direction, pg)
+        bad = ~(slope < 0)                                  # not a descent direction: steepest descent
+        direction[bad] = -pg[bad] * gamma[bad, None]
+        slope[bad] = -np.einsum("ij,ij->i", pg[bad], pg[bad]) * gamma[bad]
+        # Armijo backtracking on the projected path, all starts in one launch per round
+        t = np.ones(idx.size)
+        xn, fn = xa.copy(), fa.copy()
+        need = np.ones(idx.size, dtype=bool)
+        for _ls in range(30):
+            j = np.flatnonzero(need)
+            if j.size == 0:
+                break
+            cand = _project(xa[j] + t[j, None] * direction[j], lo, hi)
+            fc = np.asarray(fun_batch(cand), dtype=float)
+            fc = np.where(np.isfinite(fc), fc, BIG)
+            nfev[idx[j]] += 1
+            ok = fc <= fa[j] + 1e-4 * np.einsum("ij,ij->i", cand - xa[j], pg[j])
+            xn[j[ok]], fn[j[ok]] = cand[ok], fc[ok]
+            need[j[ok]] = False
+            t[j[~ok]] *= 0.5
+        stuck = need
+        for i in idx[stuck]:
+            msg[i] = "line search failed"
+        active[idx[stuck]] = False
+        mv = ~stuck
+        if not mv.any():
+            continue
+        im = idx[mv]
+        fnew, gnew = f_and_g(xn[mv], im)
+        s_vec, y_vec = xn[mv] - xa[mv], gnew - ga[mv]
+        sy = np.einsum("ij,ij->i", s_vec, y_vec)
+        good = sy > 1e-10 * np.einsum("ij,ij->i", y_vec, y_vec)
+        for loc, i in enumerate(im):                       # history shift (cheap: B small vectors)
+            if good[loc]:
+                if nhist[i] == m:
+                    S[i, :-1], Y[i, :-1], rho[i, :-1] = S[i, 1:].copy(), Y[i, 1:].copy(), rho[i, 1:].copy()
+                    nhist[i] = m - 1
+                S[i, nhist[i]], Y[i, nhist[i]], rho[i, nhist[i]] = s_vec[loc], y_vec[loc], 1.0 / sy[loc]
+                nhist[i] += 1
+        rel = (fa[mv] - fnew) / np.maximum(np.maximum(np.abs(fa[mv]), np.abs(fnew)), 1.0)
+        x[im], f[im], g[im] = xn[mv], fnew, gnew
+        nit[im] += 1
+        conv = rel <= ftol
+        for i in im[conv]:
+            msg[i] = "converged: relative reduction of f <= ftol"
+        active[im[conv]] = False
+    return [BatchResult(x[i].copy(), float(f[i]), int(nit[i]), int(nfev[i]), not msg[i].startswith(("maximum", "line")), msg[i])
+            for i in range(B)]

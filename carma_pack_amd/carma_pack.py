@@ -414,12 +414,15 @@ class CarmaModel(object):
             bnds += [(lo, hi)] * p + [(None, None)] * q
         return bnds
 
-    def get_mle(self, p, q, ntrials=100, njobs=1, seed=None):
-        """Best of `ntrials` bounded L-BFGS-B fits started from short tempered MCMC runs
+    def get_mle(self, p, q, ntrials=100, njobs=1, seed=None, method="batched"):
+        """Best of `ntrials` bounded quasi-Newton fits started from short tempered MCMC runs
         (reference :92-129,195-260).  The reference launches ntrials separate 26-iteration samplers
         and calls the C++ log-density once per function evaluation; here ONE sampler call with
-        `ntrials` independent replicas provides all starting points and each gradient is one
-        batched launch of 2d central-difference points.  `njobs` is accepted for compatibility."""
+        `ntrials` independent replicas provides all starting points, and with method="batched" all
+        starts are optimised in lock-step (carma_pack_amd.batched_opt): one launch evaluates the
+        finite-difference stencils of every start.  method="scipy" runs scipy's L-BFGS-B per start
+        with a batched gradient.  `njobs` is accepted for compatibility.  Returns an object with
+        .x, .fun (= -loglik), .message like scipy's OptimizeResult."""
         if p == 1:
             proc = carmcmcLib.run_mcmc_car1(1, 25, self._time, self._y, self._ysig, 1, nreplicas=ntrials, seed=seed)
         else:
@@ -430,6 +433,17 @@ class CarmaModel(object):
         bnds = self._mle_bounds(p, q)
         rng = np.random.default_rng(seed)
         d = starts.shape[1]
+        starts[:, 1] = 1.0                                   # initial guess for the error scale (:217)
+        for j, (lo, hi) in enumerate(bnds):
+            if lo is not None:
+                out = (starts[:, j] < lo) | (starts[:, j] > hi)
+                starts[out, j] = rng.uniform(lo, hi, int(out.sum()))
+
+        if method == "batched":
+            from .batched_opt import minimize_batched
+            results = minimize_batched(lambda pts: -np.asarray(proc.getLogDensityBatch(pts)), starts, bnds)
+            results = [r for r in results if np.isfinite(r.fun) and r.fun < 1e299] or results
+            return min(results, key=lambda r: r.fun)
 
         def fun_and_grad(x):
             h = 1e-6 * np.maximum(1.0, np.abs(x))
@@ -443,17 +457,12 @@ class CarmaModel(object):
 
         best = None
         for x0 in starts:
-            x0 = x0.copy()
-            x0[1] = 1.0
-            for j, (lo, hi) in enumerate(bnds):
-                if lo is not None and not (lo <= x0[j] <= hi):
-                    x0[j] = rng.uniform(lo, hi)
             res = minimize(fun_and_grad, x0, jac=True, method="L-BFGS-B", bounds=bnds)
             if best is None or res.fun < best.fun:
                 best = res
         return best
 
-    def choose_order(self, pmax, qmax=None, pqlist=None, njobs=1, ntrials=100, seed=None):
+    def choose_order(self, pmax, qmax=None, pqlist=None, njobs=1, ntrials=100, seed=None, method="batched"):
         """Minimise AICc over a (p,q) grid (reference :131-192); sets self.p, self.q."""
         if pmax < 1:
             raise ValueError("Order of AR polynomial must be at least 1.")
@@ -461,7 +470,7 @@ class CarmaModel(object):
             qmax = pmax - 1
         if pqlist is None:
             pqlist = [(p, q) for p in range(1, pmax + 1) for q in range(min(p, qmax + 1))]
-        MLEs = [self.get_mle(p, q, ntrials=ntrials, njobs=njobs, seed=seed) for p, q in pqlist]
+        MLEs = [self.get_mle(p, q, ntrials=ntrials, njobs=njobs, seed=seed, method=method) for p, q in pqlist]
         AICc, best, best_aicc = [], MLEs[0], 1e300
         n = self.time.size
         for mle, (p, q) in zip(MLEs, pqlist):

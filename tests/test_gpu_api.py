@@ -140,6 +140,12 @@ def test_carma_model_mcmc_and_mle(cm, golden_dir):
     assert all_s.shape == (4, 300, 7)
     mle = model.get_mle(2, 0, ntrials=8, seed=6)
     assert np.isfinite(mle.fun) and mle.x.size == 5
+    # lock-step batched optimiser vs scipy L-BFGS-B from the same starts: same optimum (or better)
+    ref = model.get_mle(2, 0, ntrials=8, seed=6, method="scipy")
+    assert mle.fun <= ref.fun + 1e-3 * max(1.0, abs(ref.fun))
+    m31 = model.get_mle(3, 1, ntrials=16, seed=9)
+    r31 = model.get_mle(3, 1, ntrials=16, seed=9, method="scipy")
+    assert m31.fun <= r31.fun + 0.5, (m31.fun, r31.fun)
     best, pqlist, aicc = model.choose_order(2, ntrials=4, seed=7)
     assert pqlist == [(1, 0), (2, 0), (2, 1)] and len(aicc) == 3 and (model.p, model.q) in pqlist
     sample.add_mle(mle) if sample.p == 2 else None

@@ -82,11 +82,11 @@ for k in ctxs:
 dt5 = time.perf_counter() - t0
 model = cpa.CarmaModel(to, yo, eo)
 t0 = time.perf_counter()
-best, pqlist, aicc = model.choose_order(4, ntrials=16, seed=1)
+best, pqlist, aicc = model.choose_order(7, ntrials=100, seed=1)
 dt_co = time.perf_counter() - t0
 out["config5_ogle_grid"] = {
     "pairs": len(ctxs), "evals": 100 * len(ctxs), "seconds": dt5, "evals_per_s": 100 * len(ctxs) / dt5, "finite": nfin,
-    "choose_order_pmax4_ntrials16_seconds": dt_co, "chosen_pq": [model.p, model.q],
+    "choose_order_pmax7_ntrials100_seconds": dt_co, "chosen_pq": [model.p, model.q],
     "aicc": dict(("%d,%d" % pq, a) for pq, a in zip(pqlist, aicc)),
 }
 print(json.dumps(out, indent=1))
