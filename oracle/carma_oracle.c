@@ -701,3 +701,110 @@ void orc_predict_car1(int n, const double *t, const double *y, const double *yer
     *pvar = ypredict_var;
     free(mean); free(var);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Literal restatement of the reference's sampler for DISTRIBUTIONAL checks of the GPU sampler.
+ * RunCarmaSampler (src/carmcmc.cpp:79-177) + Sampler::Run/Iterate (src/samplers.cpp:37-115):
+ * per iteration, for i = T-1 .. 1: AdaptiveMetro(chain i) (src/steps.cpp:60-107), ExchangeStep(i, i-1)
+ * (src/include/steps.hpp:318-362); then AdaptiveMetro(chain 0).  Serial hot -> cold sweep exactly as
+ * the reference orders its step stack.  RNG: xoshiro256** (the reference's mt19937 is time-seeded, so
+ * its streams are unpinned anyway); Student-t(8) = N(0,1)/sqrt(chi2_8/8).
+ * start = [T][d] finite starting values (the caller draws them); p==1 runs the single CAR(1) chain of
+ * RunCar1Sampler (T must be 1).                                                                    */
+typedef struct { uint64_t s[4]; } orc_rng;
+static uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t rng_next(orc_rng *r)
+{
+    uint64_t *s = r->s, result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl64(s[3], 45);
+    return result;
+}
+static double rng_u01(orc_rng *r) { return ((double)(rng_next(r) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+static double rng_normal(orc_rng *r)
+{
+    double u1 = rng_u01(r), u2 = rng_u01(r);
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+static double rng_t8(orc_rng *r)
+{
+    double z = rng_normal(r), chi2 = 0.0;
+    for (int i = 0; i < 8; i++) { double w = rng_normal(r); chi2 += w * w; }
+    return z / sqrt(chi2 / 8.0);
+}
+
+int orc_sampler_run(const orc_model *m, int T, int sample_size, int burnin, int thin, uint64_t seed,
+                    const double *start, double *samples, double *logposts, double *accept_rate, double *swap_rate)
+{
+    const int d = (m->p == 1) ? 4 : 3 + m->p + m->q;
+    orc_rng rng;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 4; i++) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; rng.s[i] = z; z += 0x9E3779B97F4A7C15ull; }
+    double *work = malloc(sizeof(double) * 4 * m->n);
+    double *theta = malloc(sizeof(double) * T * d), *lp = malloc(sizeof(double) * T), *temps = malloc(sizeof(double) * T);
+    double *chol = calloc((size_t)T * d * d, sizeof(double));
+    double *unit = malloc(sizeof(double) * d), *scaled = malloc(sizeof(double) * d), *newv = malloc(sizeof(double) * d);
+    long *nacc = calloc(T, sizeof(long)), *nswap = calloc(T, sizeof(long));
+    /* temperature ladder and initial proposal covariance (carmcmc.cpp:92-95, 132-136) */
+    double sum = 0, sq = 0;
+    for (int i = 0; i < m->n; i++) { sum += m->y[i]; sq += m->y[i] * m->y[i]; }
+    double mean = sum / m->n, var = sq / m->n - mean * mean;
+    for (int i = 0; i < T; i++) {
+        temps[i] = (T == 1) ? 1.0 : exp(log(100.0) * (double)i / (double)(T - 1));
+        for (int k = 0; k < d; k++) chol[(size_t)i * d * d + k * d + k] = 0.01;
+        chol[(size_t)i * d * d + 0] = sqrt(2.0 * var * var / m->n);
+        chol[(size_t)i * d * d + 2 * d + 2] = sqrt(var / m->n);
+        memcpy(theta + i * d, start + i * d, sizeof(double) * d);
+        lp[i] = (m->p == 1) ? orc_logdensity_car1(m, theta + i * d, work) : orc_logdensity_carma(m, theta + i * d, 0, work);
+    }
+    const long total = (long)burnin + (long)thin * sample_size;
+    for (long it = 0; it < total; it++) {
+        for (int i = T - 1; i >= 0; i--) {
+            /* AdaptiveMetro::DoStep (steps.cpp:60-107); niter_ == it for every chain */
+            double *R = chol + (size_t)i * d * d, *old = theta + i * d;
+            for (int k = 0; k < d; k++) unit[k] = rng_t8(&rng);
+            for (int j = 0; j < d; j++) {
+                double acc = 0.0;
+                for (int k = 0; k <= j; k++) acc += R[k * d + j] * unit[k];
+                scaled[j] = acc;
+                newv[j] = old[j] + acc;
+            }
+            double lnew = (m->p == 1) ? orc_logdensity_car1(m, newv, work) : orc_logdensity_carma(m, newv, 0, work);
+            double alpha = (lnew - lp[i]) / temps[i];
+            if (!isfinite(alpha)) {
+                alpha = 0.0;
+            } else {
+                double u = rng_u01(&rng);
+                alpha = fmin(exp(alpha), 1.0);
+                if (u < alpha) { memcpy(old, newv, sizeof(double) * d); lp[i] = lnew; nacc[i]++; }
+            }
+            if (it < burnin) {
+                double step = fmin(1.0, (double)d / pow((double)it, 2.0 / 3.0));
+                double nrm = 0.0;
+                for (int k = 0; k < d; k++) nrm += unit[k] * unit[k];
+                double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(nrm);
+                for (int k = 0; k < d; k++) scaled[k] *= fac;
+                orc_chol_update_r1(d, R, scaled, alpha < 0.25);
+            }
+            if (i > 0) {
+                /* ExchangeStep::DoStep for (i, i-1) (steps.hpp:318-362) */
+                double a = 1.0 / temps[i] * (lp[i - 1] - lp[i]) + 1.0 / temps[i - 1] * (lp[i] - lp[i - 1]);
+                double u = rng_u01(&rng);
+                a = fmin(exp(a), 1.0);
+                if (!isfinite(a)) a = 0.0;
+                if (u < a) {
+                    for (int k = 0; k < d; k++) { double tmp = theta[i * d + k]; theta[i * d + k] = theta[(i - 1) * d + k]; theta[(i - 1) * d + k] = tmp; }
+                    double tl = lp[i]; lp[i] = lp[i - 1]; lp[i - 1] = tl;
+                    nswap[i]++;
+                }
+            }
+        }
+        if (it >= burnin && ((it - burnin + 1) % thin) == 0) {         /* SaveValues (samplers.cpp:118-124) */
+            long s = (it - burnin + 1) / thin - 1;
+            memcpy(samples + s * d, theta, sizeof(double) * d);
+            logposts[s] = lp[0];
+        }
+    }
+    for (int i = 0; i < T; i++) { if (accept_rate) accept_rate[i] = (double)nacc[i] / total; if (swap_rate) swap_rate[i] = (double)nswap[i] / total; }
+    free(work); free(theta); free(lp); free(temps); free(chol); free(unit); free(scaled); free(newv); free(nacc); free(nswap);
+    return 0;
+}

@@ -63,6 +63,7 @@ def lib():
         L.orc_predict_carma.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, _dp, _dp, _dp, C.c_double, _dp, _dp]
         L.orc_predict_carma.restype = C.c_int
         L.orc_predict_car1.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.orc_sampler_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -213,6 +214,16 @@ class OracleModel:
         if self.p == 1:
             return lib().orc_logdensity_car1(self._h, _p(theta), None)
         return lib().orc_logdensity_carma(self._h, _p(theta), int(ignore_prior), None)
+
+    def sampler_run(self, ntemps, sample_size, burnin, thin, seed, start):
+        """Literal restatement of RunCarmaSampler/RunCar1Sampler (serial hot->cold sweep), own RNG.
+        start = [ntemps][d].  Returns dict(samples[S][d], logpost[S], accept_rate[T], swap_rate[T])."""
+        start = _a(start).reshape(ntemps, self.d)
+        samples, lp = np.empty((sample_size, self.d)), np.empty(sample_size)
+        acc, swp = np.empty(ntemps), np.empty(ntemps)
+        lib().orc_sampler_run(self._h, int(ntemps), int(sample_size), int(burnin), int(thin), C.c_uint64(int(seed)),
+                              _p(start), _p(samples), _p(lp), _p(acc), _p(swp))
+        return dict(samples=samples, logpost=lp, accept_rate=acc, swap_rate=swp)
 
     def logdensity_batch(self, thetas, ignore_prior=False, nthreads=1):
         thetas = _a(thetas).reshape(-1, self.d)

@@ -233,3 +233,19 @@ def test_predict_car1_matches_dense_gp(golden_dir):
                             pr["car1_times"])
     np.testing.assert_allclose(m, pr["car1_dmean"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(v, pr["car1_dvar"], rtol=1e-8)
+
+
+def test_literal_sampler_restatement_car1(golden_dir):
+    """The oracle's restatement of RunCar1Sampler recovers the truth of the CAR(1) fixture
+    (carma_unit_tests.cpp:1319-1376 criterion: posterior mean within 3 sigma) and keeps the
+    stored-logpost invariant (carma_unit_tests.cpp:783-845)."""
+    g = _load(golden_dir, "car1_n100.npz")
+    m = orc.OracleModel(g["t"], g["y"], g["yerr"], 1)
+    out = m.sampler_run(1, 6000, 6000, 1, 5, g["theta"][0])
+    S = out["samples"]
+    truth = np.array([2.3, 1.0, 0.0, np.log(0.01)])
+    zs = np.abs(S.mean(0) - truth) / S.std(0)
+    assert np.all(zs[[0, 2, 3]] < 3.0), zs
+    idx = np.arange(0, 6000, 500)
+    np.testing.assert_allclose(out["logpost"][idx], m.logdensity_batch(S[idx]), rtol=1e-12)
+    assert 0.15 < out["accept_rate"][0] < 0.40
