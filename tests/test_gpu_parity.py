@@ -284,3 +284,40 @@ def test_predict_orders(cpa, p, q):
     b = orc.predict_carma(t, y - th[2], yerr, sig, om, ma, times)
     np.testing.assert_allclose(a[0], b[0], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(a[1], b[1], rtol=1e-8)
+
+
+def test_edge_cases_nan_inf_tiny_series(cpa, readme):
+    """Degenerate inputs must come back in band (NaN / -inf), never hang or crash: NaN and +-inf
+    parameters, enormous frequencies (library sincos fallback path), and the smallest series."""
+    g = readme
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_var_stdev(y))
+    m = orc.OracleModel(t, y, yerr, 5, 3)
+    th0 = g["theta"][0]
+    cases = np.tile(th0, (8, 1))
+    cases[0, 0] = np.nan
+    cases[1, 3] = np.inf
+    cases[2, 4] = -np.inf
+    cases[3, 7] = np.nan
+    cases[4, 3] = 60.0            # |Im omega| ~ e^30: phases far beyond 2^20 -> out-of-line sincos
+    cases[5, 9] = 700.0           # MA quadratic term overflows
+    cases[6, 2] = 1e300
+    for ign in (False, True):
+        got = ctx.logdensity(cases, ignore_prior=ign)
+        want = m.logdensity_batch(cases, ignore_prior=ign)
+        assert np.isfinite(got[7]) and abs(got[7] - want[7]) <= 1e-10 * abs(want[7])
+        assert not np.any(np.isfinite(got[:4])) and not np.any(np.isfinite(want[:4]))
+        # where the oracle is finite the GPU agrees; where it is not, the GPU is not finite either
+        fin = np.isfinite(want)
+        assert np.all(~np.isfinite(got[~fin]))
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9)
+    # two-point series and a series that dedups down to two points
+    c2 = cpa.Context(t[:2], y[:2], yerr[:2], 2, 1, max_stdev=10.0)
+    m2 = orc.OracleModel(t[:2], y[:2], yerr[:2], 2, 1, max_stdev=10.0)
+    th = np.array([1.0, 1.0, y[:2].mean(), np.log(0.5), np.log(1.2), np.log(2.0)])
+    a, b = c2.logdensity(th, ignore_prior=True), m2.logdensity(th, ignore_prior=True)
+    assert abs(a - b) <= 1e-10 * abs(b)
+    c3 = cpa.Context(np.r_[t[:2], t[1]], np.r_[y[:2], 5.0], np.r_[yerr[:2], 1.0], 2, 1, max_stdev=10.0)
+    assert c3.n == 2 and c3.logdensity(th, ignore_prior=True) == a
+    with pytest.raises(ValueError):
+        cpa.Context(t[:1], y[:1], yerr[:1], 2, 1)
