@@ -345,6 +345,8 @@ CARMA_DEV double recip(double v)
 template <int P, class GrpT>
 struct RhoInline {
     static constexpr bool kRing = false;
+    static constexpr int kChunk = 1 << 30;
+    CARMA_DEV void chunk_begin(int) const {}
     CARMA_DEV double4 record(int) const { return double4{}; }
     const GrpT& g;
     Cx w;            // own root
@@ -519,79 +521,94 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
     double4 rcur = series[n > 1 ? 1 : 0];
     double4 rnxt = series[n > 2 ? 2 : n - 1];
     src.begin(1, rcur.x);
-    double var = 0.0, innov = 0.0;
     CARMA_STAMP_DECL;
-    for (int kk = 1; kk <= n; kk++) {
-        const bool last = (kk == n);
-        CARMA_STAMP(st0);
-        double4 rnn = rnxt;
-        if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
-        g.publish(k, pvr, pmr, 0.0);
-        if (!last) src.publish(kk);
-        double4 o[P];
+    // n-1 passes; pass kk closes var_{kk-1}, mean_{kk-1} and applies Update kk.  The body is one
+    // basic block (no branch on the pass index), so the var/mean butterflies and the reciprocal are
+    // scheduled under the LDS round trip of the gain.  Passes come in chunks of RhoSrc::kChunk
+    // (the ring's barrier period; one chunk for RhoInline).
+    for (int kk0 = 1; kk0 < n; kk0 += RhoSrc::kChunk) {
+        src.chunk_begin(kk0);
+        const int kend = (n - kk0 < RhoSrc::kChunk) ? n : kk0 + RhoSrc::kChunk;
+#pragma unroll 1
+        for (int kk = kk0; kk < kend; kk++) {
+            CARMA_STAMP(st0);
+            double4 rnn = rnxt;
+            if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
+            // the gain goes through LDS (8 B per lane, read back as pairs)
+            double kj[(P + 1) & ~1];
+            Cx rho, rj[P];
+            if constexpr (RhoSrc::kRing) rprev = src.record(kk);     // series record kk-1 from the ring
+            g.publishk(k);
+            src.publish(kk);
 #pragma unroll
-        for (int j = 0; j < P; j++) o[j] = g.peek(j);
-        if constexpr (RhoSrc::kRing) rprev = src.record(kk);     // series record kk-1 from the ring
-        Cx rho, rj[P];
-        if (!last) src.fetch(kk, rho, rj);
-        g.done_reading();
-        if (!last) src.prepare(kk + 1, rnxt.x);
-        CARMA_STAMP(st1);
-        double pv = o[0].y, pm = o[0].z;
+            for (int i = 0; i < (P + 1) / 2; i++) g.peekk2(i, kj[2 * i], kj[2 * i + 1]);
+            src.fetch(kk, rho, rj);
+            g.done_reading();
+            src.prepare(kk + 1, rnxt.x);
+            CARMA_STAMP(st1);
+            // var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z: DPP butterflies, bit-identical in the group
+            const double pv = g.sum(pvr), pm = g.sum(pmr);
+            const double var = s0 + pv + rprev.z * m.scale;      // kfilter.cpp:180-182, 209-210
+            const double innov = (rprev.y - m.mu) - pm;          // kfilter.cpp:184, 207, 213
+            acc.add_var(var);
+            if (WRITE_MV && r == 0) {
+                mean_out[kk - 1] = pm;
+                var_out[kk - 1] = var;
+            }
+            const double s = recip(var);
+            const double si = s * innov;
+            acc.chi2 += innov * si;
+            CARMA_STAMP(st2);
+            // state (kfilter.cpp:191-194, 200-201)
+            z = fma(k, si, z);
+            const double zp = g.partner(z);
+            z = rho.re * z - rho.im * zp;
+            // covariance (kfilter.cpp:197, 204)
+            const double t = k * s;
+            double d[P], mm[P];
 #pragma unroll
-        for (int j = 1; j < P; j++) {
-            pv += o[j].y;
-            pm += o[j].z;
+            for (int j = 0; j < P; j++) d[j] = fma(-t, kj[j], D[j]);
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                if (j < (P & ~1))
+                    mm[j] = d[j] * rj[j].re - d[j ^ 1] * rj[j].im;
+                else
+                    mm[j] = d[j] * rj[j].re;
+            }
+            double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                const double mp = g.partner(mm[j]);
+                D[j] = rho.re * mm[j] - rho.im * mp;
+                if (j & 1)
+                    w1 = fma(D[j], hall[j], w1);
+                else
+                    w0 = fma(D[j], hall[j], w0);
+            }
+            const double w = w0 + w1;                    // (D h^T)_r
+            k = w + c_own;
+            pvr = h_own * w;
+            pmr = h_own * z;
+            rprev = rcur;
+            rcur = rnxt;
+            rnxt = rnn;
+            CARMA_STAMP(st3);
+            CARMA_STAMP_ACC(sa, st0, st1);
+            CARMA_STAMP_ACC(sb, st1, st2);
+            CARMA_STAMP_ACC(sc, st2, st3);
         }
-        var = s0 + pv + rprev.z * m.scale;           // kfilter.cpp:180-182, 209-210
-        innov = (rprev.y - m.mu) - pm;               // kfilter.cpp:184, 207, 213
+    }
+    {   // last point: var_{n-1}, mean_{n-1}
+        if constexpr (RhoSrc::kRing) rprev = series[n - 1];
+        const double pv = g.sum(pvr), pm = g.sum(pmr);
+        const double var = s0 + pv + rprev.z * m.scale;
+        const double innov = (rprev.y - m.mu) - pm;
         acc.add_var(var);
         if (WRITE_MV && r == 0) {
-            mean_out[kk - 1] = pm;
-            var_out[kk - 1] = var;
+            mean_out[n - 1] = pm;
+            var_out[n - 1] = var;
         }
-        const double s = recip(var);
-        const double si = s * innov;
-        acc.chi2 += innov * si;
-        if (last) break;
-        CARMA_STAMP(st2);
-        // state (kfilter.cpp:191-194, 200-201)
-        z = fma(k, si, z);
-        const double zp = g.partner(z);
-        z = rho.re * z - rho.im * zp;
-        // covariance (kfilter.cpp:197, 204)
-        const double t = k * s;
-        double d[P], mm[P];
-#pragma unroll
-        for (int j = 0; j < P; j++) d[j] = fma(-t, o[j].x, D[j]);
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-            if (j < (P & ~1))
-                mm[j] = d[j] * rj[j].re - d[j ^ 1] * rj[j].im;
-            else
-                mm[j] = d[j] * rj[j].re;
-        }
-        double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-            const double mp = g.partner(mm[j]);
-            D[j] = rho.re * mm[j] - rho.im * mp;
-            if (j & 1)
-                w1 = fma(D[j], hall[j], w1);
-            else
-                w0 = fma(D[j], hall[j], w0);
-        }
-        const double w = w0 + w1;                    // (D h^T)_r
-        k = w + c_own;
-        pvr = h_own * w;
-        pmr = h_own * z;
-        rprev = rcur;
-        rcur = rnxt;
-        rnxt = rnn;
-        CARMA_STAMP(st3);
-        CARMA_STAMP_ACC(sa, st0, st1);
-        CARMA_STAMP_ACC(sb, st1, st2);
-        CARMA_STAMP_ACC(sc, st2, st3);
+        acc.chi2 += innov * (recip(var) * innov);
     }
 #if defined(CARMA_STAMPS) && defined(__HIPCC__)
     if (blockIdx.x == 0 && threadIdx.x == 0)

@@ -30,9 +30,9 @@ template <int P>
 struct RingGeom {
     static constexpr int C = 16;                                    // passes per chunk
     static constexpr int SLOT = 64;                                 // Cx entries per pass (one per lane)
-    static constexpr int ENTRIES = 2 * C * SLOT + 2 * C * 2;        // Cx-sized entries: rho ring + series records
-    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 33 KiB
-    static constexpr int REC_OFF = 2 * C * SLOT;                    // series records: double4[2][C]
+    static constexpr int ENTRIES = 2 * C * SLOT + 2 * C;            // Cx-sized entries: rho ring + series records
+    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 32.5 KiB
+    static constexpr int REC_OFF = 2 * C * SLOT;                    // series records {y, yerr^2}: double2[2][C]
 };
 
 // The loop of filter_loop_real makes n passes kk = 1..n; pass kk needs the series record kk-1
@@ -52,8 +52,8 @@ __device__ __forceinline__ void ring_produce(const Grp<G>& g, const Cx w, const 
 {
     constexpr int C = RingGeom<P>::C;
     const int lane = g.lane64;
-    const int nchunks = (n + C - 1) / C;
-    double4* recs = reinterpret_cast<double4*>(ring + RingGeom<P>::REC_OFF);
+    const int nchunks = (n - 1 + C - 1) / C;                 // passes 1 .. n-1
+    double2* recs = reinterpret_cast<double2*>(ring + RingGeom<P>::REC_OFF);
     // lane s (< C) fetches what pass s of a chunk needs -- record kk-1 and dt_kk -- with vector loads
     // one chunk ahead, so no load latency sits in front of the exp/sincos stream
     const int ls = lane < C ? lane : C - 1;
@@ -67,7 +67,7 @@ __device__ __forceinline__ void ring_produce(const Grp<G>& g, const Cx w, const 
         const int kk0 = 1 + c * C;
         rec_n = series[clampi(kk0 + C + ls - 1)];
         dt_n = series[clampi(kk0 + C + ls)].x;
-        if (lane < C && kk0 + lane <= n) recs[(c & 1) * C + lane] = rec_c;
+        if (lane < C && kk0 + lane < n) recs[(c & 1) * C + lane] = make_double2(rec_c.y, rec_c.z);
 #pragma unroll 1
         for (int s = 0; s < C; s++) {
             const double dt = readlane_f64(dt_c, s);
@@ -86,18 +86,20 @@ __device__ __forceinline__ void ring_produce(const Grp<G>& g, const Cx w, const 
 template <int P, int G>
 struct RhoRing {
     static constexpr bool kRing = true;
+    static constexpr int kChunk = RingGeom<P>::C;
+    // barrier c: the producer has written chunk c (passes kk0 .. kk0+C-1)
+    CARMA_DEV void chunk_begin(int) const { __syncthreads(); }
     const Grp<G>& g;
     const Cx* ring;
     CARMA_DEV void begin(int, double) {}
     CARMA_DEV void publish(int) const {}
-    // series record kk-1; first ring access of pass kk, so the chunk barrier lives here
+    // series record kk-1
     CARMA_DEV double4 record(int kk) const
     {
         constexpr int C = RingGeom<P>::C;
         const int c = (kk - 1) / C, s = (kk - 1) % C;
-        if (s == 0) __syncthreads();                       // chunk c is in the ring
-        const double4* recs = reinterpret_cast<const double4*>(ring + RingGeom<P>::REC_OFF);
-        return recs[(c & 1) * C + s];
+        const double2 v = reinterpret_cast<const double2*>(ring + RingGeom<P>::REC_OFF)[(c & 1) * C + s];
+        return double4{0.0, v.x, v.y, 0.0};
     }
     CARMA_DEV void fetch(int kk, Cx& rho, Cx (&rj)[P]) const
     {

@@ -83,6 +83,21 @@ struct Grp {
         __builtin_amdgcn_wave_barrier();
     }
     CARMA_DEV double4 peek(int j) const { return xch[gbase() + j]; }
+    // Slim exchange: one double per lane (same storage), read back two lanes at a time.
+    CARMA_DEV void publishk(double a) const
+    {
+        static_assert(G >= 2, "pairs");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        reinterpret_cast<double*>(xch)[lane64] = a;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    CARMA_DEV void peekk2(int i, double& a, double& b) const
+    {
+        const double2 v = reinterpret_cast<const double2*>(xch)[(gbase() >> 1) + i];
+        a = v.x;
+        b = v.y;
+    }
     CARMA_DEV void publish2(double a, double b) const
     {
         xch2[lane64] = make_double2(a, b);

@@ -62,6 +62,7 @@ struct EmuShared {
     int islot[16];
     double4 xch[16];
     double xch2[16][2];
+    double xk[16];
 };
 
 template <int G>
@@ -102,6 +103,16 @@ struct Grp {
         sh->bar.wait();
     }
     double4 peek(int j) const { return sh->xch[j]; }
+    void publishk(double a) const
+    {
+        sh->xk[r] = a;
+        sh->bar.wait();
+    }
+    void peekk2(int i, double& a, double& b) const
+    {
+        a = sh->xk[2 * i];
+        b = sh->xk[2 * i + 1];
+    }
     void publish2(double a, double b) const
     {
         sh->xch2[r][0] = a;
