@@ -194,17 +194,18 @@ struct LogLikAcc {
     double prod;   // running product of the variances, renormalised to [0.5,1) every step
     int esum;      // binary exponent taken out of prod so far
     double chi2;
-    bool bad;      // some var was <= 0 or NaN  (reference: log(var) = NaN -> NaN total)
+    double vmin;   // smallest var so far: var <= 0 -> NaN total (reference: log(var) = NaN); a NaN var
+                   // slips through fmin but turns prod into NaN by itself
     CARMA_DEV void init()
     {
         prod = 0.5;
         esum = 1;
         chi2 = 0.0;
-        bad = false;
+        vmin = 1.0;
     }
     CARMA_DEV void add_var(double var)
     {
-        bad = bad || !(var > 0.0);
+        vmin = fmin(vmin, var);
         int e;
         prod = frexp(prod * var, &e);      // v_frexp_mant_f64 + v_frexp_exp_i32_f64
         esum += e;
@@ -212,7 +213,7 @@ struct LogLikAcc {
     CARMA_DEV double total() const
     {
         double nan_ = 0.0;
-        if (bad) nan_ = (prod - prod) / (prod - prod);
+        if (!(vmin > 0.0)) nan_ = (vmin - vmin) / (vmin - vmin);
         return -0.5 * (log(prod) + (double)esum * LN2) - 0.5 * chi2 + nan_;
     }
 };
@@ -526,76 +527,83 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
     // basic block (no branch on the pass index), so the var/mean butterflies and the reciprocal are
     // scheduled under the LDS round trip of the gain.  Passes come in chunks of RhoSrc::kChunk
     // (the ring's barrier period; one chunk for RhoInline).
+    auto pass = [&](const int kk) __attribute__((always_inline)) {
+        CARMA_STAMP(st0);
+        double4 rnn = rnxt;
+        if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
+        // the gain goes through LDS (8 B per lane, read back as pairs)
+        double kj[(P + 1) & ~1];
+        Cx rho, rj[P];
+        if constexpr (RhoSrc::kRing) rprev = src.record(kk);     // series record kk-1 from the ring
+        g.publishk(k);
+        src.publish(kk);
+#pragma unroll
+        for (int i = 0; i < (P + 1) / 2; i++) g.peekk2(i, kj[2 * i], kj[2 * i + 1]);
+        src.fetch(kk, rho, rj);
+        g.done_reading();
+        src.prepare(kk + 1, rnxt.x);
+        CARMA_STAMP(st1);
+        // var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z: DPP butterflies, bit-identical in the group
+        const double pv = g.sum(pvr), pm = g.sum(pmr);
+        const double var = s0 + pv + rprev.z * m.scale;      // kfilter.cpp:180-182, 209-210
+        const double innov = (rprev.y - m.mu) - pm;          // kfilter.cpp:184, 207, 213
+        acc.add_var(var);
+        if (WRITE_MV && r == 0) {
+            mean_out[kk - 1] = pm;
+            var_out[kk - 1] = var;
+        }
+        const double s = recip(var);
+        const double si = s * innov;
+        acc.chi2 += innov * si;
+        CARMA_STAMP(st2);
+        // state (kfilter.cpp:191-194, 200-201)
+        z = fma(k, si, z);
+        const double zp = g.partner(z);
+        z = rho.re * z - rho.im * zp;
+        // covariance (kfilter.cpp:197, 204)
+        const double t = k * s;
+        double d[P], mm[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) d[j] = fma(-t, kj[j], D[j]);
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            if (j < (P & ~1))
+                mm[j] = d[j] * rj[j].re - d[j ^ 1] * rj[j].im;
+            else
+                mm[j] = d[j] * rj[j].re;
+        }
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const double mp = g.partner(mm[j]);
+            D[j] = rho.re * mm[j] - rho.im * mp;
+            if (j & 1)
+                w1 = fma(D[j], hall[j], w1);
+            else
+                w0 = fma(D[j], hall[j], w0);
+        }
+        const double w = w0 + w1;                    // (D h^T)_r
+        k = w + c_own;
+        pvr = h_own * w;
+        pmr = h_own * z;
+        rprev = rcur;
+        rcur = rnxt;
+        rnxt = rnn;
+        CARMA_STAMP(st3);
+        CARMA_STAMP_ACC(sa, st0, st1);
+        CARMA_STAMP_ACC(sb, st1, st2);
+        CARMA_STAMP_ACC(sc, st2, st3);
+    };
     for (int kk0 = 1; kk0 < n; kk0 += RhoSrc::kChunk) {
         src.chunk_begin(kk0);
-        const int kend = (n - kk0 < RhoSrc::kChunk) ? n : kk0 + RhoSrc::kChunk;
+        if (RhoSrc::kRing && n - kk0 >= RhoSrc::kChunk) {
+            // full chunk: constant trip count, unrolled so that ring offsets become immediates
+#pragma unroll 4
+            for (int s = 0; s < (RhoSrc::kRing ? RhoSrc::kChunk : 1); s++) pass(kk0 + s);
+        } else {
+            const int kend = (n - kk0 < RhoSrc::kChunk) ? n : kk0 + RhoSrc::kChunk;
 #pragma unroll 1
-        for (int kk = kk0; kk < kend; kk++) {
-            CARMA_STAMP(st0);
-            double4 rnn = rnxt;
-            if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
-            // the gain goes through LDS (8 B per lane, read back as pairs)
-            double kj[(P + 1) & ~1];
-            Cx rho, rj[P];
-            if constexpr (RhoSrc::kRing) rprev = src.record(kk);     // series record kk-1 from the ring
-            g.publishk(k);
-            src.publish(kk);
-#pragma unroll
-            for (int i = 0; i < (P + 1) / 2; i++) g.peekk2(i, kj[2 * i], kj[2 * i + 1]);
-            src.fetch(kk, rho, rj);
-            g.done_reading();
-            src.prepare(kk + 1, rnxt.x);
-            CARMA_STAMP(st1);
-            // var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z: DPP butterflies, bit-identical in the group
-            const double pv = g.sum(pvr), pm = g.sum(pmr);
-            const double var = s0 + pv + rprev.z * m.scale;      // kfilter.cpp:180-182, 209-210
-            const double innov = (rprev.y - m.mu) - pm;          // kfilter.cpp:184, 207, 213
-            acc.add_var(var);
-            if (WRITE_MV && r == 0) {
-                mean_out[kk - 1] = pm;
-                var_out[kk - 1] = var;
-            }
-            const double s = recip(var);
-            const double si = s * innov;
-            acc.chi2 += innov * si;
-            CARMA_STAMP(st2);
-            // state (kfilter.cpp:191-194, 200-201)
-            z = fma(k, si, z);
-            const double zp = g.partner(z);
-            z = rho.re * z - rho.im * zp;
-            // covariance (kfilter.cpp:197, 204)
-            const double t = k * s;
-            double d[P], mm[P];
-#pragma unroll
-            for (int j = 0; j < P; j++) d[j] = fma(-t, kj[j], D[j]);
-#pragma unroll
-            for (int j = 0; j < P; j++) {
-                if (j < (P & ~1))
-                    mm[j] = d[j] * rj[j].re - d[j ^ 1] * rj[j].im;
-                else
-                    mm[j] = d[j] * rj[j].re;
-            }
-            double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < P; j++) {
-                const double mp = g.partner(mm[j]);
-                D[j] = rho.re * mm[j] - rho.im * mp;
-                if (j & 1)
-                    w1 = fma(D[j], hall[j], w1);
-                else
-                    w0 = fma(D[j], hall[j], w0);
-            }
-            const double w = w0 + w1;                    // (D h^T)_r
-            k = w + c_own;
-            pvr = h_own * w;
-            pmr = h_own * z;
-            rprev = rcur;
-            rcur = rnxt;
-            rnxt = rnn;
-            CARMA_STAMP(st3);
-            CARMA_STAMP_ACC(sa, st0, st1);
-            CARMA_STAMP_ACC(sb, st1, st2);
-            CARMA_STAMP_ACC(sc, st2, st3);
+            for (int kk = kk0; kk < kend; kk++) pass(kk);
         }
     }
     {   // last point: var_{n-1}, mean_{n-1}

@@ -87,25 +87,32 @@ template <int P, int G>
 struct RhoRing {
     static constexpr bool kRing = true;
     static constexpr int kChunk = RingGeom<P>::C;
-    // barrier c: the producer has written chunk c (passes kk0 .. kk0+C-1)
-    CARMA_DEV void chunk_begin(int) const { __syncthreads(); }
     const Grp<G>& g;
     const Cx* ring;
+    const Cx* cbuf = nullptr;        // this group's entries of the current chunk
+    const double2* crec = nullptr;   // series records of the current chunk
+    int kk0 = 0;                     // first pass of the current chunk
     CARMA_DEV void begin(int, double) {}
     CARMA_DEV void publish(int) const {}
+    // barrier c: the producer has written chunk c (passes kk0 .. kk0+C-1)
+    CARMA_DEV void chunk_begin(int first)
+    {
+        constexpr int C = RingGeom<P>::C;
+        __syncthreads();
+        const int c = (first - 1) / C;
+        kk0 = first;
+        cbuf = ring + (size_t)(c & 1) * C * RingGeom<P>::SLOT + g.gbase();
+        crec = reinterpret_cast<const double2*>(ring + RingGeom<P>::REC_OFF) + (c & 1) * C;
+    }
     // series record kk-1
     CARMA_DEV double4 record(int kk) const
     {
-        constexpr int C = RingGeom<P>::C;
-        const int c = (kk - 1) / C, s = (kk - 1) % C;
-        const double2 v = reinterpret_cast<const double2*>(ring + RingGeom<P>::REC_OFF)[(c & 1) * C + s];
+        const double2 v = crec[kk - kk0];
         return double4{0.0, v.x, v.y, 0.0};
     }
     CARMA_DEV void fetch(int kk, Cx& rho, Cx (&rj)[P]) const
     {
-        constexpr int C = RingGeom<P>::C;
-        const int c = (kk - 1) / C, s = (kk - 1) % C;
-        const Cx* slot = ring + ((size_t)(c & 1) * C + s) * RingGeom<P>::SLOT + g.gbase();
+        const Cx* slot = cbuf + (size_t)(kk - kk0) * RingGeom<P>::SLOT;
         rho = slot[g.lane()];
 #pragma unroll
         for (int j = 0; j < P; j++) rj[j] = slot[j];

@@ -19,23 +19,16 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;   // [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane i <-> 7-i inside each 8 lanes
 constexpr int DPP_ROW_MIRROR = 0x140;        // lane i <-> 15-i inside each 16 lanes
 
-// One v_mov_b32_dpp per 32-bit half, written as asm so that the destination is a fresh register
-// (the builtin ties dst to an `old` operand and costs an extra v_mov per half).  The s_nop covers
-// the "VALU write -> DPP read" hazard, which the compiler does not track through inline asm.
-#define CARMA_DPP_MOV64(NAME, CTRLSTR)                                                          \
-    CARMA_DEV double NAME(double v)                                                             \
-    {                                                                                           \
-        int lo = __double2loint(v), hi = __double2hiint(v), olo, ohi;                           \
-        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 " CTRLSTR " row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_mov_b32_dpp %1, %3 " CTRLSTR " row_mask:0xf bank_mask:0xf"               \
-                     : "=&v"(olo), "=&v"(ohi)                                                   \
-                     : "v"(lo), "v"(hi));                                                       \
-        return __hiloint2double(ohi, olo);                                                      \
-    }
-CARMA_DPP_MOV64(dpp_xor1, "quad_perm:[1,0,3,2]")
-CARMA_DPP_MOV64(dpp_xor2, "quad_perm:[2,3,0,1]")
-CARMA_DPP_MOV64(dpp_half_mirror, "row_half_mirror")
-CARMA_DPP_MOV64(dpp_mirror, "row_mirror")
+// 64-bit DPP move (two v_mov_b32_dpp).  bound_ctrl with full row/bank masks makes the `old` operand
+// dead, so no extra v_mov is emitted, and the compiler owns the "VALU write -> DPP read" hazard: it
+// fills the two wait states with independent instructions instead of a fixed s_nop (8 cycles each
+// in a single-wave instruction stream -- measured, tools/ubench/ub3.hip).
+#define CARMA_DPP_MOV64(NAME, CTRL) \
+    CARMA_DEV double NAME(double v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true); }
+CARMA_DPP_MOV64(dpp_xor1, DPP_QUAD_XOR1)
+CARMA_DPP_MOV64(dpp_xor2, DPP_QUAD_XOR2)
+CARMA_DPP_MOV64(dpp_half_mirror, DPP_ROW_HALF_MIRROR)
+CARMA_DPP_MOV64(dpp_mirror, DPP_ROW_MIRROR)
 
 template <int G>
 struct Grp {
