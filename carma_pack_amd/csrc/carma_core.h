@@ -348,6 +348,8 @@ struct RhoInline {
     static constexpr bool kRing = false;
     static constexpr int kChunk = 1 << 30;
     CARMA_DEV void chunk_begin(int) const {}
+    CARMA_DEV double4 record_s(int) const { return double4{}; }
+    CARMA_DEV void fetch_s(int, Cx&, Cx (&)[P]) const {}
     CARMA_DEV double4 record(int) const { return double4{}; }
     const GrpT& g;
     Cx w;            // own root
@@ -527,20 +529,48 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
     // basic block (no branch on the pass index), so the var/mean butterflies and the reciprocal are
     // scheduled under the LDS round trip of the gain.  Passes come in chunks of RhoSrc::kChunk
     // (the ring's barrier period; one chunk for RhoInline).
-    auto pass = [&](const int kk) __attribute__((always_inline)) {
+    // RhoRing: the factors and the series record of pass kk+1 are read during pass kk (behind the
+    // gain reads in the in-order LDS queue), so only the gain's round trip is ever waited for.
+    Cx rho_n = {1.0, 0.0}, rj_n[P];
+    double4 rec_n = rprev;
+#pragma unroll
+    for (int j = 0; j < P; j++) rj_n[j] = Cx{1.0, 0.0};
+    if constexpr (RhoSrc::kRing) {
+        if (n > 1) {
+            src.chunk_begin(1);
+            src.fetch_s(0, rho_n, rj_n);
+            rec_n = src.record_s(0);
+        }
+    }
+    auto pass = [&](const int kk, const int s_in_chunk) __attribute__((always_inline)) {
         CARMA_STAMP(st0);
         double4 rnn = rnxt;
         if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
         // the gain goes through LDS (8 B per lane, read back as pairs)
         double kj[(P + 1) & ~1];
-        Cx rho, rj[P];
-        if constexpr (RhoSrc::kRing) rprev = src.record(kk);     // series record kk-1 from the ring
+        Cx rho = rho_n, rj[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) rj[j] = rj_n[j];
+        if constexpr (RhoSrc::kRing) rprev = rec_n;              // series record kk-1
         g.publishk(k);
         src.publish(kk);
 #pragma unroll
         for (int i = 0; i < (P + 1) / 2; i++) g.peekk2(i, kj[2 * i], kj[2 * i + 1]);
-        src.fetch(kk, rho, rj);
-        g.done_reading();
+        if constexpr (RhoSrc::kRing) {
+            if (s_in_chunk == RhoSrc::kChunk - 1) {              // next pass opens a new chunk
+                if (kk + 1 < n) {
+                    src.chunk_begin(kk + 1);
+                    src.fetch_s(0, rho_n, rj_n);
+                    rec_n = src.record_s(0);
+                }
+            } else {
+                src.fetch_s(s_in_chunk + 1, rho_n, rj_n);
+                rec_n = src.record_s(s_in_chunk + 1);
+            }
+        } else {
+            src.fetch(kk, rho, rj);
+        }
+        g.done_reading();                                        // pins the LDS issue order
         src.prepare(kk + 1, rnxt.x);
         CARMA_STAMP(st1);
         // var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z: DPP butterflies, bit-identical in the group
@@ -595,15 +625,14 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
         CARMA_STAMP_ACC(sc, st2, st3);
     };
     for (int kk0 = 1; kk0 < n; kk0 += RhoSrc::kChunk) {
-        src.chunk_begin(kk0);
         if (RhoSrc::kRing && n - kk0 >= RhoSrc::kChunk) {
             // full chunk: constant trip count, unrolled so that ring offsets become immediates
 #pragma unroll 4
-            for (int s = 0; s < (RhoSrc::kRing ? RhoSrc::kChunk : 1); s++) pass(kk0 + s);
+            for (int s = 0; s < (RhoSrc::kRing ? RhoSrc::kChunk : 1); s++) pass(kk0 + s, s);
         } else {
             const int kend = (n - kk0 < RhoSrc::kChunk) ? n : kk0 + RhoSrc::kChunk;
 #pragma unroll 1
-            for (int kk = kk0; kk < kend; kk++) pass(kk);
+            for (int kk = kk0; kk < kend; kk++) pass(kk, kk - kk0);
         }
     }
     {   // last point: var_{n-1}, mean_{n-1}

@@ -104,18 +104,25 @@ struct RhoRing {
         cbuf = ring + (size_t)(c & 1) * C * RingGeom<P>::SLOT + g.gbase();
         crec = reinterpret_cast<const double2*>(ring + RingGeom<P>::REC_OFF) + (c & 1) * C;
     }
-    // series record kk-1
-    CARMA_DEV double4 record(int kk) const
+    // series record of the pass in slot s of the current chunk (record kk-1 for pass kk)
+    CARMA_DEV double4 record_s(int s) const
     {
-        const double2 v = crec[kk - kk0];
+        const double2 v = crec[s];
         return double4{0.0, v.x, v.y, 0.0};
     }
-    CARMA_DEV void fetch(int kk, Cx& rho, Cx (&rj)[P]) const
+    CARMA_DEV double4 record(int) const { return double4{}; }
+    CARMA_DEV void fetch(int, Cx&, Cx (&)[P]) const {}
+    // factors of the pass in slot s of the current chunk
+    CARMA_DEV void fetch_s(int s, Cx& rho, Cx (&rj)[P]) const
     {
-        const Cx* slot = cbuf + (size_t)(kk - kk0) * RingGeom<P>::SLOT;
-        rho = slot[g.lane()];
+        const double2* slot = reinterpret_cast<const double2*>(cbuf + (size_t)s * RingGeom<P>::SLOT);
+        const double2 o = slot[g.lane()];
+        rho = Cx{o.x, o.y};
 #pragma unroll
-        for (int j = 0; j < P; j++) rj[j] = slot[j];
+        for (int j = 0; j < P; j++) {
+            const double2 v = slot[j];
+            rj[j] = Cx{v.x, v.y};
+        }
     }
     CARMA_DEV void prepare(int, double) {}
 };

@@ -102,7 +102,12 @@ struct Grp {
         double2 v = xch2[gbase() + j];
         return Cx{v.x, v.y};
     }
-    CARMA_DEV void done_reading() const { __builtin_amdgcn_wave_barrier(); }
+    // also a scheduling barrier: the LDS operations issued so far stay ahead of what follows
+    CARMA_DEV void done_reading() const
+    {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // Make this wave's earlier LDS/global stores visible to its later loads (other lanes of the
     // same wave).  Hardware executes one wave's memory instructions in order; this is only a
