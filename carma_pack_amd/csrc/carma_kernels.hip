@@ -167,7 +167,21 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     // Latency-bound path: spread waves over as many CUs as possible (1 wave/block) until the
     // chip is covered, then pack 4 waves per block.
     const long waves = ((long)B + EPW - 1) / EPW;
-    if (waves <= 1024 && n >= 8) {
+    const long rows = ((long)B + 3) / 4;      // waves with one evaluation per 16-lane DPP row
+    if (rows <= 512 && n >= 8) {
+        // very few evaluations in flight (BASELINE configs 2, 3: 1024): one evaluation per DPP row, the
+        // cross-lane traffic of a step folded into FP64 DPP operands (filter_loop_row), rho producer wave
+        const size_t lds = 128 * sizeof(double4) + RingGeom<P>::BYTES;
+        static bool attr16_set = false;
+        if (!attr16_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_pc<P, 16>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr16_set = true;
+        }
+        hipLaunchKernelGGL((k_logdens_carma_pc<P, 16>), dim3((unsigned)rows), dim3(128), lds, st, theta, B, d, q, series,
+                           n, pr, ignore_prior, out);
+    } else if (waves <= 1024 && n >= 8) {
         // few evaluations in flight: one wave's instruction stream is the run time, so split it
         // (consumer + rho producer, carma_ring.h).  At most 4 workgroups (37 KiB of LDS each) per CU.
         const size_t lds = 128 * sizeof(double4) + RingGeom<P>::BYTES;

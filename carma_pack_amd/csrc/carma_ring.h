@@ -112,6 +112,12 @@ struct RhoRing {
     }
     CARMA_DEV double4 record(int) const { return double4{}; }
     CARMA_DEV void fetch(int, Cx&, Cx (&)[P]) const {}
+    // own factor only (row variant: the others come by DPP)
+    CARMA_DEV void fetch_own_s(int s, Cx& rho) const
+    {
+        const double2 o = reinterpret_cast<const double2*>(cbuf + (size_t)s * RingGeom<P>::SLOT)[g.lane()];
+        rho = Cx{o.x, o.y};
+    }
     // factors of the pass in slot s of the current chunk
     CARMA_DEV void fetch_s(int s, Cx& rho, Cx (&rj)[P]) const
     {
@@ -134,7 +140,11 @@ __device__ __forceinline__ double ring_consume(const Grp<G>& g, const Model<P>& 
     FilterConsts<P> fc;
     filter_reset<P, G>(g, m, fc);
     RhoRing<P, G> src{g, ring};
-    double ll = filter_loop_real<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
+    double ll;
+    if constexpr (G == 16)
+        ll = filter_loop_row<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
+    else
+        ll = filter_loop_real<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
     *singular = fc.sing;
     return ll;
 }

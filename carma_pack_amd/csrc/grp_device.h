@@ -103,6 +103,28 @@ struct Grp {
         return Cx{v.x, v.y};
     }
     // also a scheduling barrier: the LDS operations issued so far stay ahead of what follows
+    // --- one evaluation per 16-lane DPP row (G = 16) -----------------------------------------
+    // acc += (v held by lane J of this row) * mul: DPP row broadcast folded into the FP64 fmac.
+    template <int J>
+    CARMA_DEV void fmac_row(double& acc, double v, double mul) const
+    {
+        static_assert(G == 16 && J >= 0 && J < 16, "row broadcast");
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(v), "v"(mul), "n"(J));
+    }
+    template <int J>
+    CARMA_DEV void fnmac_row(double& acc, double v, double mul) const
+    {
+        static_assert(G == 16 && J >= 0 && J < 16, "row broadcast");
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(v), "v"(mul), "n"(J));
+    }
+    // Two wait states between the VALU writes of a and b and the DPP reads that follow (the hazard
+    // recogniser does not see into inline asm); the operands tie the nop behind their producers.
+    CARMA_DEV void row_guard(double& a, double& b) const { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+
     CARMA_DEV void done_reading() const
     {
         __builtin_amdgcn_wave_barrier();

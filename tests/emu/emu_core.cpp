@@ -21,6 +21,17 @@ static void logdens_one(const double* theta, int q, const double4* series, int n
     });
 }
 
+// one evaluation per 16-lane row (filter_loop_row)
+template <int P>
+static void logdens_row_one(const double* theta, int q, const double4* series, int n, const Prior& pr, int ignore_prior,
+                            double* out)
+{
+    run_group<16>([&](const Grp<16>& g) {
+        double ll = logdensity_carma<P, 16>(g, theta, q, series, n, pr, ignore_prior);
+        if (g.lane() == 0) *out = ll;
+    });
+}
+
 template <int P>
 static void kfilter_one(const double* om_re, const double* om_im, const double* ma, double sigsqr,
                         const double4* series, int n, double* mean, double* var, double* ll, int* sing)
@@ -64,6 +75,27 @@ int emu_logdensity_carma(int p, int q, const double* theta, int B, const double*
             case 5: logdens_one<5>(th, q, s4, n, pr, ignore_prior, out + b); break;
             case 6: logdens_one<6>(th, q, s4, n, pr, ignore_prior, out + b); break;
             case 7: logdens_one<7>(th, q, s4, n, pr, ignore_prior, out + b); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+int emu_logdensity_carma_row(int p, int q, const double* theta, int B, const double* series, int n, const double* prior,
+                             int ignore_prior, double* out)
+{
+    Prior pr{prior[0], prior[1], prior[2], prior[3]};
+    const double4* s4 = reinterpret_cast<const double4*>(series);
+    int d = 3 + p + q;
+    for (int b = 0; b < B; b++) {
+        const double* th = theta + (size_t)b * d;
+        switch (p) {
+            case 2: logdens_row_one<2>(th, q, s4, n, pr, ignore_prior, out + b); break;
+            case 3: logdens_row_one<3>(th, q, s4, n, pr, ignore_prior, out + b); break;
+            case 4: logdens_row_one<4>(th, q, s4, n, pr, ignore_prior, out + b); break;
+            case 5: logdens_row_one<5>(th, q, s4, n, pr, ignore_prior, out + b); break;
+            case 6: logdens_row_one<6>(th, q, s4, n, pr, ignore_prior, out + b); break;
+            case 7: logdens_row_one<7>(th, q, s4, n, pr, ignore_prior, out + b); break;
             default: return -1;
         }
     }

@@ -120,6 +120,11 @@ struct Grp {
         sh->bar.wait();
     }
     Cx peek2(int j) const { return Cx{sh->xch2[j][0], sh->xch2[j][1]}; }
+    template <int J>
+    void fmac_row(double& acc, double v, double mul) const { acc = fma(xchg(v, J), mul, acc); }
+    template <int J>
+    void fnmac_row(double& acc, double v, double mul) const { acc = fma(-xchg(v, J), mul, acc); }
+    void row_guard(double&, double&) const {}
     void done_reading() const { sh->bar.wait(); }
     void sync() const { sh->bar.wait(); }
 };

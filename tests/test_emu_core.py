@@ -39,6 +39,29 @@ def test_emu_orders(p, q):
                       arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arbitrated=2)
 
 
+@pytest.mark.parametrize("p,q", [(2, 1), (3, 0), (4, 3), (5, 3), (6, 2), (7, 6)])
+def test_emu_row_loop(p, q, golden_dir):
+    """filter_loop_row (one evaluation per 16-lane DPP row, the latency-regime kernel) against the
+    oracle, and against the G = 8 loop it must agree with to rounding."""
+    if (p, q) == (5, 3):
+        g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+        t, y, yerr, th = g["t"], g["y"], g["yerr"], g["theta"]
+    else:
+        t, y, yerr = irregular_series(90, seed=p * 7 + q)
+        rng = np.random.default_rng(p * 31 + q)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(8)])
+    m = orc.OracleModel(t, y, yerr, p, q)
+    pr = (m.max_stdev, m.max_freq, m.min_freq)
+    from mp_truth import loglik_truth
+    got = emu.logdensity_carma_row(t, y, yerr, p, q, th, pr)
+    assert_parity(got, m.logdensity_batch(th), 1e-10, "emu row p=%d q=%d" % (p, q),
+                  arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arbitrated=2)
+    ref = emu.logdensity_carma(t, y, yerr, p, q, th, pr)
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(got))
+    assert np.allclose(got[fin], ref[fin], rtol=1e-9, atol=0)
+
+
 def test_emu_kfilter_mean_var(golden_dir):
     g = np.load(os.path.join(golden_dir, "cpp_carma_test300.npz"))
     mean, var, ll, rc = emu.kfilter_carma(g["t"], g["y"], g["yerr"], float(g["sigsqr"]), g["omega"], g["ma"])
