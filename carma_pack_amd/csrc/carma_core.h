@@ -740,14 +740,8 @@ CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterC
             src.prepare(kk + 1, rnxt.x);
         }
         // var_{kk-1} = s0 + e + h.w, innov_{kk-1} = (y - mu) - h.z     (kfilter.cpp:180-184, 207-213)
-        double var = fma(rprev.z, m.scale, s0);
-        double innov = rprev.y - m.mu;
-        g.row_guard(w, z);
-        static_for<0, P>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            g.template fmac_row<j>(var, w, hall[j]);
-            g.template fnmac_row<j>(innov, z, hall[j]);
-        });
+        double var, innov;
+        g.template row_sums<P>(var, innov, rprev.z, m.scale, s0, rprev.y, m.mu, w, z, hall);
         acc.add_var(var);
         if (WRITE_MV && r == 0) {
             mean_out[kk - 1] = (rprev.y - m.mu) - innov;
@@ -756,26 +750,15 @@ CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterC
         const double s = recip(var);
         const double si = s * innov;
         acc.chi2 += innov * si;
-        // state (kfilter.cpp:191-194, 200-201)
-        z = fma(k, si, z);
+        // gain: z += k si (kfilter.cpp:191-194); covariance d_j = D_j - (k s) k_j (:197)
+        double nt;
+        g.template row_gain<P>(nt, z, D, k, s, si);
+        // state transition (kfilter.cpp:200-201)
         const double zp = g.partner(z);
         z = rho.re * z - rho.im * zp;
-        // covariance (kfilter.cpp:197, 204)
-        double nt = -(k * s);
-        g.row_guard(k, nt);
-        static_for<0, P>([&](auto jc) {                                  // d_j = D_j - t k_j
-            constexpr int j = decltype(jc)::value;
-            g.template fmac_row<j>(D[j], k, nt);
-        });
+        // transition of the covariance (kfilter.cpp:204): N_j = c_j d_j - s_j d_{j^1}, then the row mix
         double mm[P];
-#pragma unroll
-        for (int j = 0; j < P; j++) mm[j] = 0.0;
-        g.row_guard(rho.re, rho.im);
-        static_for<0, P>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            g.template fmac_row<j>(mm[j], rho.re, D[j]);                               // c_j d_j
-            if constexpr (j < (P & ~1)) g.template fnmac_row<j>(mm[j], rho.im, D[j ^ 1]);   // - s_j d_{j^1}
-        });
+        g.template row_colmix<P>(mm, rho.re, rho.im, D);
         double w0 = 0.0, w1 = 0.0;
 #pragma unroll
         for (int j = 0; j < P; j++) {
@@ -804,14 +787,8 @@ CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterC
     }
     {   // last point: var_{n-1}, mean_{n-1}
         if constexpr (RhoSrc::kRing) rprev = series[n - 1];
-        double var = fma(rprev.z, m.scale, s0);
-        double innov = rprev.y - m.mu;
-        g.row_guard(w, z);
-        static_for<0, P>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            g.template fmac_row<j>(var, w, hall[j]);
-            g.template fnmac_row<j>(innov, z, hall[j]);
-        });
+        double var, innov;
+        g.template row_sums<P>(var, innov, rprev.z, m.scale, s0, rprev.y, m.mu, w, z, hall);
         acc.add_var(var);
         if (WRITE_MV && r == 0) {
             mean_out[n - 1] = (rprev.y - m.mu) - innov;

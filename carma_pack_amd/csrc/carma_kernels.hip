@@ -43,26 +43,32 @@ __global__ __launch_bounds__(64 * WAVES) void k_logdens_carma(const double* __re
     if (live && g.lane() == 0) out[e] = ll;
 }
 
-// Latency-regime variant (carma_ring.h): 128-thread workgroup = consumer wave + rho-producer wave
-// for the same 64/G evaluations.
-template <int P, int G>
-__global__ __launch_bounds__(128) void k_logdens_carma_pc(const double* __restrict__ theta, int B, int d, int q,
-                                                          const double4* __restrict__ series, int n, Prior pr,
-                                                          int ignore_prior, double* __restrict__ out)
+// Latency-regime variant (carma_ring.h): a workgroup holds PAIRS x (consumer wave + rho-producer wave),
+// each pair working on 64/G evaluations.  PAIRS = 2 fills the four SIMDs of a CU from ONE workgroup
+// (two 2-wave workgroups on a CU were observed to share SIMDs).
+template <int P, int G, int PAIRS>
+__global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* __restrict__ theta, int B, int d, int q,
+                                                                  const double4* __restrict__ series, int n, Prior pr,
+                                                                  int ignore_prior, double* __restrict__ out)
 {
     extern __shared__ double4 smem4[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane64 = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, pair = wave >> 1, role = wave & 1, lane64 = tid & 63;
     Grp<G> g{smem4 + wave * 64, lane64, nullptr};
-    Cx* ring = reinterpret_cast<Cx*>(smem4 + 128);
-    long e = ((long)blockIdx.x * 64 + lane64) / G;
+    Cx* ring = reinterpret_cast<Cx*>(smem4 + 128 * PAIRS) + (size_t)pair * RingGeom<P>::ENTRIES;
+    long e = (((long)blockIdx.x * PAIRS + pair) * 64 + lane64) / G;
     const bool live = e < B;
     if (!live) e = B - 1;
-    Model<P> m;
-    model_from_theta<P, G>(g, theta + e * d, q, pr, ignore_prior, m);
-    if (wave == 1) {
-        ring_produce<P, G>(g, m.w, series, n, ring);
+    if (role == 1) {
+        if constexpr (G == 16) {
+            ring_produce_row<P>(g, theta + e * d, series, n, ring);
+        } else {
+            const int r = g.lane();
+            ring_produce<P, G>(g, own_ar_root<P>(theta + e * d, r < P ? r : P - 1), series, n, ring);
+        }
         return;
     }
+    Model<P> m;
+    model_from_theta<P, G>(g, theta + e * d, q, pr, ignore_prior, m);
     bool sing;
     double ll = ring_consume<P, G>(g, m, series, n, ring, &sing);
     ll += log_prior(m.scale, pr.measerr_dof);
@@ -168,32 +174,23 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     // chip is covered, then pack 4 waves per block.
     const long waves = ((long)B + EPW - 1) / EPW;
     const long rows = ((long)B + 3) / 4;      // waves with one evaluation per 16-lane DPP row
+    auto launch_pc = [&](auto kern, long npairs, int pairs) -> hipError_t {
+        const size_t lds = (size_t)pairs * (128 * sizeof(double4) + RingGeom<P>::BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((npairs + pairs - 1) / pairs)), dim3(128 * pairs), lds, st, theta, B, d, q,
+                           series, n, pr, ignore_prior, out);
+        return hipGetLastError();
+    };
     if (rows <= 512 && n >= 8) {
         // very few evaluations in flight (BASELINE configs 2, 3: 1024): one evaluation per DPP row, the
         // cross-lane traffic of a step folded into FP64 DPP operands (filter_loop_row), rho producer wave
-        const size_t lds = 128 * sizeof(double4) + RingGeom<P>::BYTES;
-        static bool attr16_set = false;
-        if (!attr16_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_pc<P, 16>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr16_set = true;
-        }
-        hipLaunchKernelGGL((k_logdens_carma_pc<P, 16>), dim3((unsigned)rows), dim3(128), lds, st, theta, B, d, q, series,
-                           n, pr, ignore_prior, out);
+        return rows <= 256 ? launch_pc(&k_logdens_carma_pc<P, 16, 1>, rows, 1) : launch_pc(&k_logdens_carma_pc<P, 16, 2>, rows, 2);
     } else if (waves <= 1024 && n >= 8) {
         // few evaluations in flight: one wave's instruction stream is the run time, so split it
-        // (consumer + rho producer, carma_ring.h).  At most 4 workgroups (37 KiB of LDS each) per CU.
-        const size_t lds = 128 * sizeof(double4) + RingGeom<P>::BYTES;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_pc<P, G>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_logdens_carma_pc<P, G>), dim3((unsigned)waves), dim3(128), lds, st, theta, B, d, q, series,
-                           n, pr, ignore_prior, out);
+        // (consumer + rho producer, carma_ring.h)
+        return waves <= 256 ? launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1) : launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);
     } else if (waves <= 2048) {
         hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n,
                            pr, ignore_prior, out);
