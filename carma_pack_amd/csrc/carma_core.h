@@ -205,7 +205,11 @@ struct LogLikAcc {
     }
     CARMA_DEV void add_var(double var)
     {
+#ifdef __HIPCC__
+        asm("v_min_f64 %0, %0, %1" : "+v"(vmin) : "v"(var));     // no canonicalising v_max in front
+#else
         vmin = fmin(vmin, var);
+#endif
         int e;
         prod = frexp(prod * var, &e);      // v_frexp_mant_f64 + v_frexp_exp_i32_f64
         esum += e;
@@ -769,6 +773,8 @@ CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterC
             else
                 w0 = fma(D[j], hall[j], w0);
         }
+        // (h.k = h D h^T + s0 would save this add, but sums the individually large h_r c_r of an
+        // ill-conditioned model instead of their well-conditioned total s0: measurably worse parity)
         w = w0 + w1;                                 // (D h^T)_r
         k = w + c_own;
         rprev = rcur;
