@@ -211,6 +211,33 @@ def test_full_size_properties(cpa, readme):
     assert np.array_equal(a[fin], d[fin])
 
 
+@pytest.mark.parametrize("p,q", [(2, 1), (3, 2), (4, 0), (5, 3), (6, 5), (7, 2)])
+def test_launch_shapes_agree(cpa, p, q):
+    """The three launch shapes -- row variant (<= 2048 evaluations, one evaluation per DPP row), G-lane
+    producer/consumer (<= 8192) and the throughput kernel -- against the oracle and each other."""
+    t, y, yerr = irregular_series(203, seed=50 + p)
+    rng = np.random.default_rng(500 + 10 * p + q)
+    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(48)])
+    ctx = cpa.Context(t, y, yerr, p, q)
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    want = m.logdensity_batch(th, nthreads=8)
+    from mp_truth import loglik_truth
+    arb = lambda i: loglik_truth(t, y, yerr, th[i % 48], p, q)[0]   # noqa: E731
+    res = {}
+    for name, B in (("row", 48), ("row2", 1500), ("pc", 3000), ("pc2", 6000), ("plain", 20000)):
+        big = np.tile(th, (B // 48 + 1, 1))[:B]
+        got = ctx.logdensity(big)
+        # every copy of a theta gives the same bits, wherever it sits in the launch
+        assert np.array_equal(got, np.tile(got[:48], B // 48 + 1)[:B], equal_nan=True), name
+        res[name] = got[:48]
+        assert_parity(res[name], want, RTOL, "%s p=%d q=%d" % (name, p, q), arbiter=arb, max_arbitrated=3)
+    fin = np.isfinite(want)
+    for name in ("row2", "pc", "pc2", "plain"):
+        assert np.array_equal(np.isfinite(res[name]), fin)
+    assert np.array_equal(res["row"], res["row2"], equal_nan=True)
+    assert np.array_equal(res["pc"], res["pc2"], equal_nan=True)
+
+
 @pytest.mark.parametrize("p,q,n", [(7, 6, 10000), (6, 2, 3001), (2, 1, 513), (3, 0, 1000), (4, 3, 64)])
 def test_long_series_vs_oracle(cpa, p, q, n):
     """BASELINE config 4 shape (CARMA(7,6), n = 10^4) and other orders on long irregular series."""
