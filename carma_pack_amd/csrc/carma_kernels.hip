@@ -67,14 +67,23 @@ __global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* 
         }
         return;
     }
+    CARMA_STAMP_DECL;
+    CARMA_STAMP(st0);
     Model<P> m;
     model_from_theta<P, G>(g, theta + e * d, q, pr, ignore_prior, m);
+    CARMA_STAMP(st1);
     bool sing;
     double ll = ring_consume<P, G>(g, m, series, n, ring, &sing);
+    CARMA_STAMP(st2);
     ll += log_prior(m.scale, pr.measerr_dof);
     const double ninf = -1.0 / 0.0;
     if (sing || !m.valid) ll = ninf;
     if (live && g.lane() == 0) out[e] = ll;
+    CARMA_STAMP(st3);
+#if defined(CARMA_STAMPS)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("kernel stamps (100 MHz ticks): model %llu  reset+loop %llu  tail %llu\n", st1 - st0, st2 - st1, st3 - st2);
+#endif
 }
 
 __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ theta, int B,

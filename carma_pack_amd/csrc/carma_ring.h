@@ -185,7 +185,15 @@ __device__ __forceinline__ double ring_consume(const Grp<G>& g, const Model<P>& 
                                                int n, const Cx* __restrict__ ring, bool* singular)
 {
     FilterConsts<P> fc;
+#if defined(CARMA_STAMPS)
+    unsigned long long r0, r1;
+    CARMA_STAMP(r0);
+#endif
     filter_reset<P, G>(g, m, fc);
+#if defined(CARMA_STAMPS)
+    CARMA_STAMP(r1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("reset %llu ticks\n", r1 - r0);
+#endif
     RhoRing<P, G> src{g, ring};
     double ll;
     if constexpr (G == 16)

@@ -62,7 +62,50 @@ struct Grp {
     }
     // value held by the neighbouring lane (lane ^ 1): the other member of a root pair
     CARMA_DEV static double partner(double v) { return dpp_xor1(v); }
-    // value of v held by lane j of this group (j identical in every lane of the group)
+    // value of v held by lane J of this group, J a compile-time constant: DPP, no LDS round trip.
+    //   G = 16: one row_newbcast (v_mov_b64_dpp for doubles); G = 8 / 4: one per group of the 16-lane
+    //   row, selected with the bank mask (a bank is 4 lanes); G = 2: a quad permutation.
+    template <int J, class T>
+    CARMA_DEV static T bcast_c(T v)
+    {
+        static_assert(J >= 0 && J < G, "lane of the group");
+        if constexpr (G == 16) {
+            return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, true);
+        } else if constexpr (G == 8) {
+            T o = __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0x3, false);
+            return __builtin_amdgcn_update_dpp(o, v, 0x150 + 8 + J, 0xf, 0xc, false);
+        } else if constexpr (G == 4) {
+            T o = __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0x1, false);
+            o = __builtin_amdgcn_update_dpp(o, v, 0x150 + 4 + J, 0xf, 0x2, false);
+            o = __builtin_amdgcn_update_dpp(o, v, 0x150 + 8 + J, 0xf, 0x4, false);
+            return __builtin_amdgcn_update_dpp(o, v, 0x150 + 12 + J, 0xf, 0x8, false);
+        } else {
+            static_assert(G == 2, "group size");
+            return __builtin_amdgcn_update_dpp(v, v, J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6), 0xf, 0xf, true);
+        }
+    }
+    // value of v held by lane j of this group (j identical in every lane of the group).  Every call
+    // site sits in a fully unrolled loop, so j is a constant by the time the switch is simplified and
+    // one DPP case survives; a run-time j falls through to ds_bpermute.
+    template <class T>
+    CARMA_DEV T bcast_any(T v, int j) const
+    {
+        switch (j) {
+#define CARMA_BC_CASE(J) \
+    case J:              \
+        if constexpr (J < G) return bcast_c<(J < G ? J : 0)>(v); \
+        break;
+            CARMA_BC_CASE(0) CARMA_BC_CASE(1) CARMA_BC_CASE(2) CARMA_BC_CASE(3) CARMA_BC_CASE(4) CARMA_BC_CASE(5)
+            CARMA_BC_CASE(6) CARMA_BC_CASE(7) CARMA_BC_CASE(8) CARMA_BC_CASE(9) CARMA_BC_CASE(10) CARMA_BC_CASE(11)
+            CARMA_BC_CASE(12) CARMA_BC_CASE(13) CARMA_BC_CASE(14) CARMA_BC_CASE(15)
+#undef CARMA_BC_CASE
+            default: break;
+        }
+        return __shfl(v, gbase() + j, 64);
+    }
+    // bcast_u: for call sites in fully unrolled loops (constant j -> DPP); bcast: run-time j (ds_bpermute)
+    CARMA_DEV double bcast_u(double v, int j) const { return bcast_any<double>(v, j); }
+    CARMA_DEV int bcast_iu(int v, int j) const { return bcast_any<int>(v, j); }
     CARMA_DEV double bcast(double v, int j) const { return __shfl(v, gbase() + j, 64); }
     CARMA_DEV int bcast_i(int v, int j) const { return __shfl(v, gbase() + j, 64); }
 

@@ -88,7 +88,9 @@ struct Grp {
         return v;
     }
     double bcast(double v, int j) const { return xchg(v, j); }
+    double bcast_u(double v, int j) const { return xchg(v, j); }
     double partner(double v) const { return xchg(v, r ^ 1); }
+    int bcast_iu(int v, int j) const { return bcast_i(v, j); }
     int bcast_i(int v, int j) const
     {
         sh->islot[r] = v;

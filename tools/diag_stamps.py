@@ -15,4 +15,8 @@ t, y, yerr = g['t'], g['y'], g['yerr']
 ctx = L0.Context(t, y, yerr, 5, 3, max_stdev=10*np.sqrt(np.mean(y*y)-np.mean(y)**2))
 th = theta_batch(np.random.default_rng(2), int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 5, 3, t, y, theta_center=g['theta'][0])
 out = ctx.logdensity(th)
+print("---- second launch (warm)")
+out = ctx.logdensity(th)
+print("---- third launch (warm)")
+out = ctx.logdensity(th)
 print("finite", np.isfinite(out).sum())
