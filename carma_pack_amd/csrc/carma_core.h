@@ -41,10 +41,25 @@ CARMA_DEV Cx cmulc(Cx a, Cx b) { return {a.re * b.re + a.im * b.im, a.im * b.re 
 CARMA_DEV Cx cadd(Cx a, Cx b) { return {a.re + b.re, a.im + b.im}; }
 CARMA_DEV Cx csub(Cx a, Cx b) { return {a.re - b.re, a.im - b.im}; }
 CARMA_DEV Cx cscale(Cx a, double s) { return {a.re * s, a.im * s}; }
+// 1/v to ~1 ulp: v_rcp_f64 + two Newton steps on the GPU (the IEEE division expands to 12
+// instructions), plain division on the host.
+CARMA_DEV double recip(double v)
+{
+#ifdef __HIPCC__
+    // v_rcp_f64 is good to 2^-24.4 (measured); one cubic step s0 (1 + e + e^2), e = 1 - v s0, leaves
+    // e^3 ~ 1e-22 plus one rounding: 0.5 ulp on 4M random inputs, one instruction less than two
+    // Newton steps and a shorter dependent chain
+    const double s0 = __builtin_amdgcn_rcp(v);
+    const double e = fma(-v, s0, 1.0);
+    return fma(s0, fma(e, e, e), s0);
+#else
+    return 1.0 / v;
+#endif
+}
 CARMA_DEV Cx cdiv(Cx a, Cx b)
 {
-    double den = b.re * b.re + b.im * b.im;
-    return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+    const double s = recip(b.re * b.re + b.im * b.im);       // one reciprocal instead of two IEEE divisions
+    return {(a.re * b.re + a.im * b.im) * s, (a.im * b.re - a.re * b.im) * s};
 }
 CARMA_DEV Cx csel(bool m, Cx a, Cx b) { return {m ? a.re : b.re, m ? a.im : b.im}; }
 
@@ -178,9 +193,10 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
 #pragma unroll
         for (int j = 1; j < P; j++) {
             if (j > rr) {
-                Cx qd = cdiv(csub(m.w, m.wall[j]), cadd(m.w, m.wall[j]));
-                double frac = hypot(qd.re, qd.im);
-                if (frac <= 1e-4) viol = true;
+                // |(w - w_j) / (w + w_j)| <= 1e-4 (carpack.cpp:709-732), compared as squared moduli
+                const Cx dn = csub(m.w, m.wall[j]), sm = cadd(m.w, m.wall[j]);
+                const double n2 = dn.re * dn.re + dn.im * dn.im, d2 = sm.re * sm.re + sm.im * sm.im;
+                if (n2 <= 1e-8 * d2) viol = true;
             }
         }
         double nviol = g.sum((r < P && viol) ? 1.0 : 0.0);
@@ -330,21 +346,6 @@ CARMA_DEV void filter_reset(const GrpT& g, const Model<P>& m, FilterConsts<P>& f
     fc.sing = sing;
 }
 
-// 1/v to ~1 ulp: v_rcp_f64 + two Newton steps on the GPU (the IEEE division expands to 12
-// instructions), plain division on the host.
-CARMA_DEV double recip(double v)
-{
-#ifdef __HIPCC__
-    // v_rcp_f64 is good to 2^-24.4 (measured); one cubic step s0 (1 + e + e^2), e = 1 - v s0, leaves
-    // e^3 ~ 1e-22 plus one rounding: 0.5 ulp on 4M random inputs, one instruction less than two
-    // Newton steps and a shorter dependent chain
-    const double s0 = __builtin_amdgcn_rcp(v);
-    const double e = fma(-v, s0, 1.0);
-    return fma(s0, fma(e, e, e), s0);
-#else
-    return 1.0 / v;
-#endif
-}
 
 // Where the transition factors rho_j(k) = exp(omega_j dt_k) of a group come from.
 // RhoInline: every lane computes its own factor one step ahead and shares it through the group's
