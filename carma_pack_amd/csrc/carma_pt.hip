@@ -212,6 +212,236 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
                                           nswap, samples, sample_lp, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row variant: ONE CHAIN PER 16-LANE DPP ROW (filter_loop_row), 4 chains + their rho producer wave per
+// workgroup, a ladder of T chains spread over wpl = ceil(T/4) workgroups on different CUs.
+//
+// Why: with one ladder per workgroup (k_pt) a CU hosts 2 chain waves + 2 producer waves, and a Kalman
+// step costs the CU ~2200 SIMD-cycles -- the kernel is bound by the issue rate of ONE CU while 3/4 of
+// the chip idles (16 temperatures x 64 replicas use 64 of 256 CUs).  The row loop needs ~450 cycles per
+// step and chain instead of ~560, and spreading the ladder gives every group of 4 chains its own CU.
+// The price is that the swap sweep crosses workgroups: once per iteration the ladder's workgroups
+// publish (theta, log-posterior) to global memory, meet at an arrival counter (all of them are
+// resident: the host only picks this kernel when the whole grid fits the chip), and every workgroup
+// replays the same hot->cold decisions (exchange_decide, same counter-based uniforms) for its ladder.
+// Staging is double buffered, so a workgroup can run at most one exchange ahead of the slowest one.
+// A barrier that does not complete within ~seconds sets abort_flag and the launch ends (reported as an
+// error by the host) instead of hanging the GPU.
+template <int P>
+__global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
+                                                const double* __restrict__ temps, double* __restrict__ theta,
+                                                double* __restrict__ logpost, double* __restrict__ chol,
+                                                unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,
+                                                double* __restrict__ samples, double* __restrict__ sample_lp)
+{
+    constexpr int G = 16, CPW = 4;                         // lanes per chain, chains per workgroup
+    extern __shared__ double4 smem4[];
+    const int tid = threadIdx.x, lane64 = tid & 63;
+    const bool producer = tid >= 64;
+    const int d = L.d, T = L.T, per = 4 * d + d * d;
+    Cx* ring = reinterpret_cast<Cx*>(smem4 + 128);
+    double* base = reinterpret_cast<double*>(ring + RingGeom<P>::ENTRIES);    // CPW chain scratches
+    double* s_lp = base + (size_t)CPW * per;               // [T] the ladder's log-posteriors (exchange)
+    double* s_dbeta = s_lp + T;
+    double* s_logu = s_dbeta + T;
+    unsigned* s_nswap = reinterpret_cast<unsigned*>(s_logu + T);
+    int* s_src = reinterpret_cast<int*>(s_nswap + T);
+    int* s_flag = s_src + T;                               // [1] abort seen
+    const long lad = blockIdx.x / S.wpl;                   // local replica (ladder) index
+    const int part = (int)(blockIdx.x % S.wpl);
+    const long ch0 = lad * T;                              // first chain of the ladder in the state arrays
+
+    // chain scratch slot i holds chain min(part*4 + i, T-1); slots past the ladder's end are dummies
+    // that keep the wave's control flow uniform and are never written back
+    for (int i = tid; i < CPW * d; i += 128) {
+        const int slot = i / d, cg = min(part * CPW + slot, T - 1);
+        base[(size_t)slot * per + (i % d)] = theta[(ch0 + cg) * d + (i % d)];
+    }
+    for (int i = tid; i < CPW * d * d; i += 128) {
+        const int slot = i / (d * d), cg = min(part * CPW + slot, T - 1);
+        base[(size_t)slot * per + 4 * d + (i % (d * d))] = chol[(ch0 + cg) * d * d + (i % (d * d))];
+    }
+    for (int i = tid; i < T; i += 128) {
+        s_dbeta[i] = i > 0 ? 1.0 / temps[i] - 1.0 / temps[i - 1] : 0.0;
+        s_nswap[i] = 0;
+    }
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+
+    Grp<G> g{smem4 + (tid & ~63), lane64, nullptr};
+    const int row = lane64 >> 4;
+    const int c = part * CPW + row;                        // chain (temperature index) of this row
+    const bool active = c < T;
+    const int cc = active ? c : T - 1;
+    ChainScratch cs;
+    cs.th = base + (size_t)row * per;
+    cs.thn = cs.th + d;
+    cs.z = cs.th + 2 * d;
+    cs.v = cs.th + 3 * d;
+    cs.R = cs.th + 4 * d;
+    const uint32_t chain_base = (uint32_t)((L.replica0 + lad) * L.T_global + L.slot0);
+    RngKey key{L.seed0, L.seed1, chain_base + (uint32_t)cc};
+    double lp = logpost[ch0 + cc];
+    const double temperature = temps[cc];
+    unsigned nacc = 0, nexch = 0;
+    int buf = 0;
+    const size_t nchain_all = (size_t)L.R * T;
+
+    for (int it = 0; it < L.niter; it++) {
+        const uint64_t iter = L.iter0 + (uint64_t)it;
+        double znorm2 = 0.0;
+        if (!producer) znorm2 = ram_propose<G>(g, cs, d, iter, key);
+        __syncthreads();                                   // proposals visible to the producer wave
+        if (producer) {
+            ring_produce_row<P>(g, cs.thn, series, L.n, ring);
+        } else {
+            Model<P> m;
+            model_from_theta<P, G>(g, cs.thn, L.q, pr, 0, m);
+            bool sing;
+            double ll = ring_consume<P, G>(g, m, series, L.n, ring, &sing);
+            ll += log_prior(m.scale, pr.measerr_dof);
+            if (sing || !m.valid) ll = -1.0 / 0.0;
+            if (ram_finish<G>(g, cs, d, temperature, iter, L.maxiter, key, ll, znorm2, &lp)) nacc++;
+        }
+        if (L.do_exchange && T > 1) {
+            // publish this workgroup's chains
+            double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
+            double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
+            if (!producer && active) {
+                for (int j = g.lane(); j < d; j += G) st_th[(ch0 + c) * d + j] = cs.th[j];
+                if (g.lane() == 0) st_lp[ch0 + c] = lp;
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target = (unsigned)S.wpl * (nexch + 1);
+                unsigned spins = 0;
+                while (__hip_atomic_load(&S.counter[lad], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    if (__hip_atomic_load(S.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                        ++spins > 20000000u) {
+                        __hip_atomic_store(S.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *s_flag = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads();
+            if (*s_flag) break;                            // uniform: the whole workgroup leaves
+            __threadfence();
+            // the ladder's log-posteriors and swap uniforms (keyed by the hotter chain's global slot)
+            for (int i = tid; i < T; i += 128) {
+                s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_src[i] = i;
+                RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
+                s_logu[i] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+            }
+            __syncthreads();
+            if (tid == 0) exchange_decide(T, s_lp, s_dbeta, s_logu, s_src, s_nswap);
+            __syncthreads();
+            if (!producer && active) {
+                const int from = s_src[c];
+                if (from != c)
+                    for (int j = g.lane(); j < d; j += G)
+                        cs.th[j] = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lp = s_lp[c];
+            }
+            __syncthreads();
+            buf ^= 1;
+            nexch++;
+        }
+        if (L.save_thin > 0 && ((it + 1) % L.save_thin) == 0 && part == 0 && tid < G) {
+            // coldest chain of the ladder (Sampler::SaveValues, src/samplers.cpp:118-124): row 0 of part 0
+            const long s = L.save_offset + (it + 1) / L.save_thin - 1;
+            if (s < L.sample_cap) {
+                for (int j = tid; j < d; j += G) samples[(lad * L.sample_cap + s) * d + j] = base[j];
+                if (tid == 0) sample_lp[lad * L.sample_cap + s] = lp;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < CPW * d; i += 128) {
+        const int slot = i / d, cg = part * CPW + slot;
+        if (cg < T) theta[(ch0 + cg) * d + (i % d)] = base[(size_t)slot * per + (i % d)];
+    }
+    for (int i = tid; i < CPW * d * d; i += 128) {
+        const int slot = i / (d * d), cg = part * CPW + slot;
+        if (cg < T) chol[(ch0 + cg) * d * d + (i % (d * d))] = base[(size_t)slot * per + 4 * d + (i % (d * d))];
+    }
+    if (!producer && active && g.lane() == 0) {
+        logpost[ch0 + c] = lp;
+        naccept[ch0 + c] += nacc;
+    }
+    if (part == 0)
+        for (int i = tid; i < T; i += 128) nswap[ch0 + i] += s_nswap[i];
+}
+
+static size_t pt_row_lds(int d, int T)
+{
+    const size_t per = 4 * (size_t)d + (size_t)d * d;
+    return 128 * sizeof(double4) + RingGeom<2>::BYTES + (4 * per + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
+}
+
+template <int P>
+static const void* pt_row_fn()
+{
+    return reinterpret_cast<const void*>(&k_pt_row<P>);
+}
+
+static const void* pt_row_fn_p(int p)
+{
+    switch (p) {
+        case 2: return pt_row_fn<2>();
+        case 3: return pt_row_fn<3>();
+        case 4: return pt_row_fn<4>();
+        case 5: return pt_row_fn<5>();
+        case 6: return pt_row_fn<6>();
+        case 7: return pt_row_fn<7>();
+        default: return nullptr;
+    }
+}
+
+long pt_row_capacity(int p, int d, int T, int n)
+{
+    const void* fn = pt_row_fn_p(p);
+    if (!fn || n < 32 || T < 1) return 0;
+    const size_t lds = pt_row_lds(d, T);
+    if (lds > 160 * 1024) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 0;
+    int dev = 0, ncu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 128, lds) != hipSuccess) return 0;
+    return (long)ncu * per_cu;
+}
+
+template <int P>
+static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const double4* series, const Prior& pr,
+                                  const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
+                                  unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
+{
+    const size_t lds = pt_row_lds(L.d, L.T);
+    hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(128), lds, st, L, S, series, pr, temps,
+                       theta, logpost, chol, naccept, nswap, samples, sample_lp);
+    return hipGetLastError();
+}
+
+hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const double4* series, const Prior& pr,
+                         const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
+                         unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
+{
+    switch (p) {
+        case 2: return launch_pt_row_p<2>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
+        case 3: return launch_pt_row_p<3>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
+        case 4: return launch_pt_row_p<4>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
+        case 5: return launch_pt_row_p<5>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
+        case 6: return launch_pt_row_p<6>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
+        case 7: return launch_pt_row_p<7>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_pt(int p, const PtLaunch& L, const double4* series, const Prior& pr, const double* temps,
                      double* theta, double* logpost, double* chol, unsigned* naccept, unsigned* nswap, double* samples,
                      double* sample_lp, hipStream_t st)

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -31,6 +32,11 @@ struct PtState {
     long cap = 0;
     bool started = false;
     unsigned long long stat_iters = 0;
+    // row-variant kernel (k_pt_row): ladders spread over wpl workgroups, swap through global staging
+    bool use_row = false;
+    int wpl = 0;
+    double *d_stage_th = nullptr, *d_stage_lp = nullptr;
+    unsigned *d_counter = nullptr, *d_abort = nullptr;
 };
 
 void pt_state_free(Ctx* c)
@@ -47,6 +53,10 @@ void pt_state_free(Ctx* c)
     if (s->d_nswap) (void)hipFree(s->d_nswap);
     if (s->d_samples) (void)hipFree(s->d_samples);
     if (s->d_slp) (void)hipFree(s->d_slp);
+    if (s->d_stage_th) (void)hipFree(s->d_stage_th);
+    if (s->d_stage_lp) (void)hipFree(s->d_stage_lp);
+    if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->d_abort) (void)hipFree(s->d_abort);
     delete s;
     c->pt = nullptr;
 }
@@ -162,8 +172,17 @@ static int pt_launch_chunks(Ctx* c, long niter, int do_exchange, int thin, long*
         L.slot0 = s->slot0;
         L.T_global = s->T_global;
         L.replica0 = s->replica0;
-        hipError_t e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta,
-                                 s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->stream);
+        hipError_t e;
+        if (s->use_row) {
+            e = hipMemsetAsync(s->d_counter, 0, sizeof(unsigned) * s->R, c->stream);
+            if (e != hipSuccess) return hip_fail(e, "reset pt counters");
+            PtRowSync S{s->d_stage_th, s->d_stage_lp, s->d_counter, s->d_abort, s->wpl};
+            e = launch_pt_row(c->p, L, S, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta,
+                              s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->stream);
+        } else {
+            e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
+                          s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->stream);
+        }
         if (e != hipSuccess) return hip_fail(e, "launch pt kernel");
         s->iter += ch;
         s->stat_iters += ch;
@@ -172,6 +191,15 @@ static int pt_launch_chunks(Ctx* c, long niter, int do_exchange, int thin, long*
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return hip_fail(e, "pt kernel");
+    if (s->use_row) {
+        unsigned aborted = 0;
+        e = hipMemcpy(&aborted, s->d_abort, sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "pt abort flag");
+        if (aborted) {
+            set_error("pt kernel: a cross-workgroup swap barrier timed out (workgroups of a ladder not co-resident?)");
+            return CARMA_EHIP;
+        }
+    }
     return CARMA_OK;
 }
 
@@ -232,6 +260,24 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     if (e == hipSuccess) e = hipMemcpy(s->d_chol, chol.data(), sizeof(double) * chol.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_nacc, 0, sizeof(unsigned) * nchain);
     if (e == hipSuccess) e = hipMemset(s->d_nswap, 0, sizeof(unsigned) * nchain);
+    // Kernel choice.  The row variant needs every workgroup of the grid resident at the same time
+    // (its swap step is a cross-workgroup rendezvous); otherwise one workgroup per ladder (k_pt).
+    // CARMA_PT_KERNEL=ladder|row overrides (row only where it is safe).
+    if (e == hipSuccess && c->p >= 2) {
+        const int wpl = (ntemps + 3) / 4;
+        const long cap = pt_row_capacity(c->p, d, ntemps, c->n);
+        const char* force = getenv("CARMA_PT_KERNEL");
+        const bool want = !(force && std::strcmp(force, "ladder") == 0);
+        if (want && cap >= (long)nreplicas * wpl) {
+            s->use_row = true;
+            s->wpl = wpl;
+            e = hipMalloc(&s->d_stage_th, sizeof(double) * 2 * nchain * d);
+            if (e == hipSuccess) e = hipMalloc(&s->d_stage_lp, sizeof(double) * 2 * nchain);
+            if (e == hipSuccess) e = hipMalloc(&s->d_counter, sizeof(unsigned) * nreplicas);
+            if (e == hipSuccess) e = hipMalloc(&s->d_abort, sizeof(unsigned));
+            if (e == hipSuccess) e = hipMemset(s->d_abort, 0, sizeof(unsigned));
+        }
+    }
     if (e != hipSuccess) {
         int rc = hip_fail(e, "carma_pt_create");
         pt_state_free(c);

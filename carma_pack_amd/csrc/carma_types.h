@@ -29,4 +29,14 @@ struct PtLaunch {
     unsigned replica0;           // global index of local replica 0            (replica sharding)
 };
 
+// Cross-workgroup exchange state of the row-variant PT kernel (k_pt_row): a ladder is spread over
+// `wpl` workgroups, which meet once per iteration through global memory.
+struct PtRowSync {
+    double* stage_th;        // [2][R*T*d] current values published for the swap
+    double* stage_lp;        // [2][R*T]
+    unsigned* counter;       // [R] arrivals of the ladder's workgroups (zeroed before every launch)
+    unsigned* abort_flag;    // [1] set when a barrier timed out (the launch then ends early)
+    int wpl;                 // workgroups per ladder = ceil(T / 4)
+};
+
 }  // namespace carma
