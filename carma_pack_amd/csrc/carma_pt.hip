@@ -18,6 +18,7 @@
 
 #include "grp_device.h"
 #include "carma_pt_core.h"
+#include "carma_pt_row.h"
 #include "carma_ring.h"
 #include "carma_launch.h"
 
@@ -238,10 +239,10 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
     extern __shared__ double4 smem4[];
     const int tid = threadIdx.x, lane64 = tid & 63;
     const bool producer = tid >= 64;
-    const int d = L.d, T = L.T, per = 4 * d + d * d;
+    const int d = L.d, T = L.T;
     Cx* ring = reinterpret_cast<Cx*>(smem4 + 128);
-    double* base = reinterpret_cast<double*>(ring + RingGeom<P>::ENTRIES);    // CPW chain scratches
-    double* s_lp = base + (size_t)CPW * per;               // [T] the ladder's log-posteriors (exchange)
+    double* s_thn = reinterpret_cast<double*>(ring + RingGeom<P>::ENTRIES);   // [CPW][16] proposals
+    double* s_lp = s_thn + CPW * PT_DMAX;                  // [T] the ladder's log-posteriors (exchange)
     double* s_dbeta = s_lp + T;
     double* s_logu = s_dbeta + T;
     unsigned* s_nswap = reinterpret_cast<unsigned*>(s_logu + T);
@@ -251,34 +252,26 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
     const int part = (int)(blockIdx.x % S.wpl);
     const long ch0 = lad * T;                              // first chain of the ladder in the state arrays
 
-    // chain scratch slot i holds chain min(part*4 + i, T-1); slots past the ladder's end are dummies
-    // that keep the wave's control flow uniform and are never written back
-    for (int i = tid; i < CPW * d; i += 128) {
-        const int slot = i / d, cg = min(part * CPW + slot, T - 1);
-        base[(size_t)slot * per + (i % d)] = theta[(ch0 + cg) * d + (i % d)];
-    }
-    for (int i = tid; i < CPW * d * d; i += 128) {
-        const int slot = i / (d * d), cg = min(part * CPW + slot, T - 1);
-        base[(size_t)slot * per + 4 * d + (i % (d * d))] = chol[(ch0 + cg) * d * d + (i % (d * d))];
-    }
     for (int i = tid; i < T; i += 128) {
         s_dbeta[i] = i > 0 ? 1.0 / temps[i] - 1.0 / temps[i - 1] : 0.0;
         s_nswap[i] = 0;
     }
     if (tid == 0) *s_flag = 0;
-    __syncthreads();
 
     Grp<G> g{smem4 + (tid & ~63), lane64, nullptr};
-    const int row = lane64 >> 4;
+    const int row = lane64 >> 4, j = lane64 & 15;
     const int c = part * CPW + row;                        // chain (temperature index) of this row
     const bool active = c < T;
+    // rows past the ladder's end shadow its last chain: uniform control flow, nothing written back
     const int cc = active ? c : T - 1;
-    ChainScratch cs;
-    cs.th = base + (size_t)row * per;
-    cs.thn = cs.th + d;
-    cs.z = cs.th + 2 * d;
-    cs.v = cs.th + 3 * d;
-    cs.R = cs.th + 4 * d;
+    double* thn_lds = s_thn + row * PT_DMAX;
+    // chain state in registers (carma_pt_row.h): lane j owns component j and column j of R
+    RowChain ch;
+    ch.th = j < d ? theta[(ch0 + cc) * d + j] : 0.0;
+    ch.thn = ch.th;
+    ch.z = ch.v = 0.0;
+#pragma unroll
+    for (int k = 0; k < PT_DMAX; k++) ch.Rc[k] = (j < d && k <= j) ? chol[(ch0 + cc) * d * d + (size_t)k * d + j] : 0.0;
     const uint32_t chain_base = (uint32_t)((L.replica0 + lad) * L.T_global + L.slot0);
     RngKey key{L.seed0, L.seed1, chain_base + (uint32_t)cc};
     double lp = logpost[ch0 + cc];
@@ -286,33 +279,42 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
     unsigned nacc = 0, nexch = 0;
     int buf = 0;
     const size_t nchain_all = (size_t)L.R * T;
+    __syncthreads();
 
+    CARMA_STAMP_DECL;
+    unsigned long long st5 = 0, st6 = 0, st7 = 0;
     for (int it = 0; it < L.niter; it++) {
         const uint64_t iter = L.iter0 + (uint64_t)it;
         double znorm2 = 0.0;
-        if (!producer) znorm2 = ram_propose<G>(g, cs, d, iter, key);
+        CARMA_STAMP(st0);
+        if (!producer) znorm2 = ram_propose_row(g, ch, d, iter, key, thn_lds);
+        CARMA_STAMP(st1);
         __syncthreads();                                   // proposals visible to the producer wave
+        CARMA_STAMP(st2);
         if (producer) {
-            ring_produce_row<P>(g, cs.thn, series, L.n, ring);
+            ring_produce_row<P>(g, thn_lds, series, L.n, ring);
         } else {
             Model<P> m;
-            model_from_theta<P, G>(g, cs.thn, L.q, pr, 0, m);
+            model_from_theta<P, G>(g, thn_lds, L.q, pr, 0, m);
             bool sing;
             double ll = ring_consume<P, G>(g, m, series, L.n, ring, &sing);
             ll += log_prior(m.scale, pr.measerr_dof);
             if (sing || !m.valid) ll = -1.0 / 0.0;
-            if (ram_finish<G>(g, cs, d, temperature, iter, L.maxiter, key, ll, znorm2, &lp)) nacc++;
+            CARMA_STAMP(st3);
+            if (ram_finish_row(g, ch, d, temperature, iter, L.maxiter, key, ll, znorm2, &lp)) nacc++;
+            CARMA_STAMP(st4);
         }
         if (L.do_exchange && T > 1) {
             // publish this workgroup's chains
             double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
             double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
             if (!producer && active) {
-                for (int j = g.lane(); j < d; j += G) st_th[(ch0 + c) * d + j] = cs.th[j];
-                if (g.lane() == 0) st_lp[ch0 + c] = lp;
+                if (j < d) st_th[(ch0 + c) * d + j] = ch.th;
+                if (j == 0) st_lp[ch0 + c] = lp;
             }
             __threadfence();
             __syncthreads();
+            CARMA_STAMP(st5);
             if (tid == 0) {
                 __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target = (unsigned)S.wpl * (nexch + 1);
@@ -328,59 +330,84 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
                 }
             }
             __syncthreads();
+            CARMA_STAMP(st6);
             if (*s_flag) break;                            // uniform: the whole workgroup leaves
             __threadfence();
-            // the ladder's log-posteriors and swap uniforms (keyed by the hotter chain's global slot)
-            for (int i = tid; i < T; i += 128) {
-                s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_src[i] = i;
-                RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
-                s_logu[i] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
-            }
-            __syncthreads();
-            if (tid == 0) exchange_decide(T, s_lp, s_dbeta, s_logu, s_src, s_nswap);
-            __syncthreads();
-            if (!producer && active) {
-                const int from = s_src[c];
-                if (from != c)
-                    for (int j = g.lane(); j < d; j += G)
-                        cs.th[j] = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lp = s_lp[c];
+            // the ladder's log-posteriors and swap uniforms (keyed by the hotter chain's global slot):
+            // lane i of the chain wave owns temperature i, the sweep runs through v_readlane
+            if (T <= 64) {
+                if (!producer) {
+                    const int i = lane64 < T ? lane64 : T - 1;
+                    double lp_i = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
+                    const double logu_i = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+                    int src_i = i;
+                    bool sw;
+                    exchange_decide_wave(T, lane64, lp_i, s_dbeta[i], logu_i, src_i, &sw);
+                    if (sw && lane64 < T) s_nswap[lane64]++;
+                    const int from = __shfl(src_i, cc, 64);
+                    lp = __shfl(lp_i, cc, 64);
+                    if (from != cc && j < d)
+                        ch.th = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                for (int i = tid; i < T; i += 128) {
+                    s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_src[i] = i;
+                    RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
+                    s_logu[i] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+                }
+                __syncthreads();
+                if (tid == 0) exchange_decide(T, s_lp, s_dbeta, s_logu, s_src, s_nswap);
+                __syncthreads();
+                if (!producer) {
+                    const int from = s_src[cc];
+                    if (from != cc && j < d)
+                        ch.th = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lp = s_lp[cc];
+                }
             }
             __syncthreads();
             buf ^= 1;
             nexch++;
+            CARMA_STAMP(st7);
+#if defined(CARMA_STAMPS)
+            if (blockIdx.x == 0 && tid == 0 && it == L.niter - 1)
+                printf("pt_row stamps (cycles): propose %llu  barrier %llu  model+reset+filter %llu  finish %llu  publish %llu  "
+                       "rendezvous %llu  decide+gather %llu\n",
+                       st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6);
+#endif
         }
         if (L.save_thin > 0 && ((it + 1) % L.save_thin) == 0 && part == 0 && tid < G) {
             // coldest chain of the ladder (Sampler::SaveValues, src/samplers.cpp:118-124): row 0 of part 0
             const long s = L.save_offset + (it + 1) / L.save_thin - 1;
             if (s < L.sample_cap) {
-                for (int j = tid; j < d; j += G) samples[(lad * L.sample_cap + s) * d + j] = base[j];
+                if (j < d) samples[(lad * L.sample_cap + s) * d + j] = ch.th;
                 if (tid == 0) sample_lp[lad * L.sample_cap + s] = lp;
             }
         }
     }
+    if (!producer && active) {
+        if (j < d) {
+            theta[(ch0 + c) * d + j] = ch.th;
+#pragma unroll
+            for (int k = 0; k < PT_DMAX; k++)
+                if (k <= j) chol[(ch0 + c) * d * d + (size_t)k * d + j] = ch.Rc[k];
+        }
+        if (j == 0) {
+            logpost[ch0 + c] = lp;
+            naccept[ch0 + c] += nacc;
+        }
+    }
     __syncthreads();
-    for (int i = tid; i < CPW * d; i += 128) {
-        const int slot = i / d, cg = part * CPW + slot;
-        if (cg < T) theta[(ch0 + cg) * d + (i % d)] = base[(size_t)slot * per + (i % d)];
-    }
-    for (int i = tid; i < CPW * d * d; i += 128) {
-        const int slot = i / (d * d), cg = part * CPW + slot;
-        if (cg < T) chol[(ch0 + cg) * d * d + (i % (d * d))] = base[(size_t)slot * per + 4 * d + (i % (d * d))];
-    }
-    if (!producer && active && g.lane() == 0) {
-        logpost[ch0 + c] = lp;
-        naccept[ch0 + c] += nacc;
-    }
     if (part == 0)
         for (int i = tid; i < T; i += 128) nswap[ch0 + i] += s_nswap[i];
 }
 
 static size_t pt_row_lds(int d, int T)
 {
-    const size_t per = 4 * (size_t)d + (size_t)d * d;
-    return 128 * sizeof(double4) + RingGeom<2>::BYTES + (4 * per + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
+    (void)d;
+    return 128 * sizeof(double4) + RingGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
 }
 
 template <int P>
@@ -413,7 +440,9 @@ long pt_row_capacity(int p, int d, int T, int n)
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 128, lds) != hipSuccess) return 0;
-    return (long)ncu * per_cu;
+    // one workgroup per CU: beyond that the ladder kernel (8 chains per wave) has the better throughput,
+    // and a grid no larger than the CU count is resident as a whole with a wide margin
+    return per_cu >= 1 ? (long)ncu : 0;
 }
 
 template <int P>

@@ -1,0 +1,140 @@
+// carma_pt_row.h -- the Robust-Adaptive-Metropolis step of carma_pt_core.h with the chain state in
+// REGISTERS of one 16-lane DPP row (k_pt_row, gfx950 only).
+//
+// Lane j (< d <= 16) of the row owns component j of the chain: th_j, the proposal thn_j, the unit draw
+// z_j, the rank-1 vector v_j and COLUMN j of the upper-triangular Cholesky factor R (Rc[k] = R_kj,
+// zero for k > j).  Everything another lane needs arrives by a DPP row broadcast (v_mov_b64_dpp
+// row_newbcast:k, one instruction, no LDS round trip, no group barrier):
+//     thn_j = th_j + sum_{k<=j} R_kj z_k           steps.cpp:60-73    (z_k broadcast from lane k)
+//     CholUpdateR1, step k: R_kk, v_k broadcast     steps.cpp:111-131
+// Same draws (Philox keys), same formulas and operation order per element as ram_propose / ram_finish;
+// divisions by R_kk and c are multiplications by their reciprocals (recip(), 0.5 ulp).
+#pragma once
+#include "carma_pt_core.h"
+
+namespace carma {
+
+constexpr int PT_DMAX = 16;
+
+struct RowChain {
+    double th;              // component j of the current value (lane j)
+    double thn;             // proposal
+    double z, v;
+    double Rc[PT_DMAX];     // column j of R
+};
+
+// z ~ t_8^d, thn = th + R^T z (steps.cpp:60-73).  Returns |z|^2.  thn is also stored to thn_lds[j] for
+// the model code and the producer wave.
+__device__ __forceinline__ double ram_propose_row(const Grp<16>& g, RowChain& ch, int d, uint64_t iter, const RngKey& key,
+                                                  double* thn_lds)
+{
+    const int j = g.lane();
+    const double zj = rng_student_t8(key, iter, (uint32_t)(j < d ? j : 0));
+    ch.z = j < d ? zj : 0.0;
+    double znorm2 = 0.0, acc = 0.0;
+    static_for<0, PT_DMAX>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (k < d) {
+            const double zk = Grp<16>::bcast_c<k>(ch.z);
+            znorm2 += zk * zk;
+            acc += ch.Rc[k] * zk;                       // R_kj is zero for k > j
+        }
+    });
+    ch.v = acc;
+    ch.thn = ch.th + acc;
+    if (j < d) thn_lds[j] = ch.thn;
+    g.sync();
+    return znorm2;
+}
+
+// CholUpdateR1 (steps.cpp:111-131) on the register-resident factor.
+__device__ __forceinline__ void chol_update_row(const Grp<16>& g, int d, RowChain& ch, bool downdate)
+{
+    const int j = g.lane();
+    const double sign = downdate ? -1.0 : 1.0;
+    static_for<0, PT_DMAX>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (k < d) {
+            const double Rkk = Grp<16>::bcast_c<k>(ch.Rc[k]);
+            const double vk = Grp<16>::bcast_c<k>(ch.v);
+            const double rr = sqrt(Rkk * Rkk + sign * vk * vk);
+            const double iR = recip(Rkk);
+            const double c = rr * iR, s = vk * iR, ic = Rkk * recip(rr);
+            const double Rkj = (ch.Rc[k] + sign * s * ch.v) * ic;
+            const double vj = c * ch.v - s * Rkj;
+            ch.Rc[k] = (j == k) ? rr : (j > k ? Rkj : ch.Rc[k]);
+            ch.v = (j > k) ? vj : ch.v;
+        }
+    });
+}
+
+// Metropolis accept with the tempered ratio, then the RAM rank-1 update (steps.cpp:36-56, 77-99).
+__device__ __forceinline__ bool ram_finish_row(const Grp<16>& g, RowChain& ch, int d, double temperature, uint64_t iter,
+                                               int maxiter, const RngKey& key, double ll, double znorm2, double* lp)
+{
+    double alpha = (ll - *lp) / temperature;
+    bool accept = false;
+    const bool fin = (alpha - alpha) == 0.0;
+    if (!fin) {
+        alpha = 0.0;                                    // steps.cpp:41-46
+    } else {
+        const double u = rng_uniform(key, iter, RNG_ACCEPT, 0);
+        alpha = fmin(exp(alpha), 1.0);
+        accept = u < alpha;
+    }
+    if (accept) {                                       // parameter_.Save(new_value) (steps.cpp:77)
+        ch.th = ch.thn;
+        *lp = ll;
+    }
+    if ((long)iter < (long)maxiter) {                   // steps.cpp:82-99
+        const double cb = cbrt((double)iter);               // iter^(2/3) without pow (iter = 0 -> step 1)
+        const double step = fmin(1.0, (double)d / (cb * cb));
+        const double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(znorm2);
+        ch.v *= fac;
+        chol_update_row(g, d, ch, alpha < 0.25);
+    }
+    return accept;
+}
+
+// ExchangeStep sweep hot -> cold (steps.hpp:318-362, same decisions as exchange_decide) executed by a
+// whole wave on values held in lanes: lane i (< T <= 64) owns temperature i's log-posterior, its
+// 1/T_i - 1/T_{i-1} and the log of its swap uniform.  Every step reads the two values it needs with
+// v_readlane (uniform index), so the serial dependence runs through SGPRs instead of T LDS round trips.
+// On return lane i holds the log-posterior now sitting at temperature i and the index of the chain
+// its state comes from; *swapped is set for the lanes whose pair (i, i-1) swapped.
+__device__ __forceinline__ void exchange_decide_wave(int T, int lane, double& lp, double dbeta, double logu, int& src,
+                                                     bool* swapped)
+{
+    auto rl = [](double v, int i) {
+        int lo = __builtin_amdgcn_readlane(__double2loint(v), i);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
+        return __hiloint2double(hi, lo);
+    };
+    const double lp_in = lp;
+    double hot = rl(lp_in, T - 1);
+    int hot_src = T - 1;
+    bool sw = false;
+    for (int i = T - 1; i > 0; i--) {
+        const double cold = rl(lp_in, i - 1);
+        const double a = (cold - hot) * rl(dbeta, i);
+        const bool swap = rl(logu, i) < a;                 // uniform
+        const double lp_i = swap ? cold : hot;
+        const int src_i = swap ? i - 1 : hot_src;
+        if (lane == i) {
+            lp = lp_i;
+            src = src_i;
+            sw = swap;
+        }
+        if (!swap) {
+            hot = cold;
+            hot_src = i - 1;
+        }
+    }
+    if (lane == 0) {
+        lp = hot;
+        src = hot_src;
+    }
+    *swapped = sw;
+}
+
+}  // namespace carma
