@@ -128,6 +128,35 @@ def test_gpu_matches_emulator_trajectory(cpa):
     np.testing.assert_allclose(lp1[0], out["lp"], rtol=1e-8)
 
 
+@pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1)])
+def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkeypatch):
+    """The two sampler kernels -- k_pt (one workgroup per ladder) and k_pt_row (one chain per DPP row,
+    ladder spread over workgroups, register-resident RAM step, cross-workgroup swap rendezvous) -- use
+    the same Philox keys and formulas: from the same seed and start they must produce the same chains
+    (accept/swap decisions identical, values to rounding), saved samples included."""
+    from helpers import irregular_series
+    t, y, yerr = irregular_series(80, seed=70 + p)
+    ms = _pop_stdev(y)
+    res = {}
+    for kern in ("ladder", "row"):
+        monkeypatch.setenv("CARMA_PT_KERNEL", kern)
+        ctx = cpa.Context(t, y, yerr, p, q, max_stdev=ms)
+        ctx.pt_create(T, R, adapt_iters=120, seed=77)
+        ctx.pt_start(None)
+        ctx.pt_iterate(150)
+        smp, slp = ctx.pt_sample(40, thin=2)
+        th, lp = ctx.pt_get_chains()
+        acc, swp = ctx.pt_stats()
+        res[kern] = (th, lp, smp, slp, acc, swp)
+    a, b = res["ladder"], res["row"]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-8)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(b[3], a[3], rtol=1e-8)
+    np.testing.assert_array_equal(b[4], a[4])
+    np.testing.assert_array_equal(b[5], a[5])
+
+
 def test_gpu_sampler_matches_literal_cpu_sampler(cpa):
     """Distributional parity of A9-A11: the GPU sampler (all RAM steps of an iteration concurrently,
     then the swap sweep; Philox) against the oracle's literal restatement of the reference's sampler
