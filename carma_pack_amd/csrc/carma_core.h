@@ -762,7 +762,7 @@ CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterC
         g.template row_gain<P>(nt, z, D, k, s, si);
         // state transition (kfilter.cpp:200-201)
         const double zp = g.partner(z);
-        z = rho.re * z - rho.im * zp;
+        z = fma(rho.re, z, -(rho.im * zp));           // explicit contraction: same bits in every variant of this loop
         // transition of the covariance (kfilter.cpp:204): N_j = c_j d_j - s_j d_{j^1}, then the row mix
         double mm[P];
         g.template row_colmix<P>(mm, rho.re, rho.im, D);
@@ -770,7 +770,7 @@ CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterC
 #pragma unroll
         for (int j = 0; j < P; j++) {
             const double mp = g.partner(mm[j]);
-            D[j] = rho.re * mm[j] - rho.im * mp;
+            D[j] = fma(rho.re, mm[j], -(rho.im * mp));
             if (j & 1)
                 w1 = fma(D[j], hall[j], w1);
             else

@@ -18,6 +18,7 @@
 #include "carma_core.h"
 #include "carma_ring.h"
 #include "carma_predict.h"
+#include "carma_pipe3.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -84,6 +85,42 @@ __global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* 
     if (blockIdx.x == 0 && threadIdx.x == 0)
         printf("kernel stamps (100 MHz ticks): model %llu  reset+loop %llu  tail %llu\n", st1 - st0, st2 - st1, st3 - st2);
 #endif
+}
+
+// Smallest launches (<= 1024 evaluations): covariance wave + mean wave + rho producer per 4 evaluations
+// (carma_pipe3.h).  192 threads, 81 KiB of LDS: one workgroup per CU.
+template <int P>
+__global__ __launch_bounds__(192) void k_logdens_carma_p3(const double* __restrict__ theta, int B, int d, int q,
+                                                          const double4* __restrict__ series, int n, Prior pr,
+                                                          int ignore_prior, double* __restrict__ out)
+{
+    extern __shared__ double4 smem4[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane64 = tid & 63;
+    Grp<16> g{nullptr, lane64, nullptr};
+    Cx* ring = reinterpret_cast<Cx*>(smem4);
+    long e = ((long)blockIdx.x * 64 + lane64) / 16;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    if (wave == 2) {
+        pipe3_produce<P>(g, theta + e * d, series, n, ring);
+        return;
+    }
+    // both recursion waves set the model up themselves (in parallel; nothing to hand over)
+    Model<P> m;
+    model_from_theta<P, 16>(g, theta + e * d, q, pr, ignore_prior, m);
+    FilterConsts<P> fc;
+    filter_reset<P, 16>(g, m, fc);
+    RowConsts<P> rc;
+    row_consts<P>(g, m, fc, rc);
+    if (wave == 0) {
+        pipe3_cov<P>(g, m, rc, n, ring);
+        return;
+    }
+    double ll = pipe3_mean<P>(g, m, rc, n, ring);
+    ll += log_prior(m.scale, pr.measerr_dof);
+    const double ninf = -1.0 / 0.0;
+    if (fc.sing || !m.valid) ll = ninf;
+    if (live && g.lane() == 0) out[e] = ll;
 }
 
 __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ theta, int B,
@@ -185,14 +222,28 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     const long rows = ((long)B + 3) / 4;      // waves with one evaluation per 16-lane DPP row
     auto launch_pc = [&](auto kern, long npairs, int pairs) -> hipError_t {
         const size_t lds = (size_t)pairs * (128 * sizeof(double4) + RingGeom<P>::BYTES);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024);
+        if (ea != hipSuccess) return ea;
         hipLaunchKernelGGL(kern, dim3((unsigned)((npairs + pairs - 1) / pairs)), dim3(128 * pairs), lds, st, theta, B, d, q,
                            series, n, pr, ignore_prior, out);
         return hipGetLastError();
     };
-    if (rows <= 512 && n >= 8) {
+    // Kernels with > 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize.  It is set
+    // before EVERY such launch: setting it once per process is not enough -- after a
+    // hipFuncSetAttribute / occupancy query on another kernel of the module (carma_pt_create does
+    // that) a later 81 KiB launch failed with hipErrorUnknown.  The call costs ~1 us on the host and
+    // the launches are asynchronous.
+    auto big_lds = [](const void* kf) { return hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    if (rows <= 256 && n >= 8) {
+        // one workgroup per CU: covariance wave + mean wave + producer wave (carma_pipe3.h)
+        const size_t lds = Pipe3Geom<P>::BYTES;
+        hipError_t ea = big_lds(reinterpret_cast<const void*>(&k_logdens_carma_p3<P>));
+        if (ea != hipSuccess) return ea;
+        hipLaunchKernelGGL((k_logdens_carma_p3<P>), dim3((unsigned)rows), dim3(192), lds, st, theta, B, d, q, series, n, pr,
+                           ignore_prior, out);
+        return hipGetLastError();
+    } else if (rows <= 512 && n >= 8) {
         // very few evaluations in flight (BASELINE configs 2, 3: 1024): one evaluation per DPP row, the
         // cross-lane traffic of a step folded into FP64 DPP operands (filter_loop_row), rho producer wave
         return rows <= 256 ? launch_pc(&k_logdens_carma_pc<P, 16, 1>, rows, 1) : launch_pc(&k_logdens_carma_pc<P, 16, 2>, rows, 2);
@@ -214,6 +265,7 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,
                                 const Prior& pr, int ignore_prior, double* out, hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     switch (p) {
         case 2: return launch_logdens_p<2>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
         case 3: return launch_logdens_p<3>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
@@ -228,6 +280,7 @@ hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q,
 hipError_t launch_logdens_car1(const double* theta, int B, const double4* series, int n, const Prior& pr, double* out,
                                hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     const unsigned blocks = (unsigned)(((long)B + 63) / 64);
     hipLaunchKernelGGL(k_logdens_car1, dim3(blocks), dim3(64), 0, st, theta, B, series, n, pr, out);
     return hipGetLastError();
@@ -245,6 +298,7 @@ static hipError_t launch_kfilter_p(const double* om, const double* ma, double si
 hipError_t launch_kfilter_carma(int p, const double* om, const double* ma, double sigsqr, const double4* series, int n,
                                 double* mean, double* var, int* singular, hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     switch (p) {
         case 2: return launch_kfilter_p<2>(om, ma, sigsqr, series, n, mean, var, singular, st);
         case 3: return launch_kfilter_p<3>(om, ma, sigsqr, series, n, mean, var, singular, st);
@@ -270,6 +324,7 @@ static hipError_t launch_predict_p(const double* om, const double* ma, double si
 hipError_t launch_predict_carma(int p, const double* om, const double* ma, double sigsqr, const double4* series, int n,
                                 const double* tpred, int M, double* pmean, double* pvar, int* singular, hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     switch (p) {
         case 2: return launch_predict_p<2>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
         case 3: return launch_predict_p<3>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
@@ -284,6 +339,7 @@ hipError_t launch_predict_carma(int p, const double* om, const double* ma, doubl
 hipError_t launch_predict_car1(double sigsqr, double omega, const double4* series, int n, const double* tpred, int M,
                                double* pmean, double* pvar, hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     const unsigned blocks = (unsigned)(((long)M + 63) / 64);
     hipLaunchKernelGGL(k_predict_car1, dim3(blocks), dim3(64), 0, st, sigsqr, omega, series, n, tpred, M, pmean, pvar);
     return hipGetLastError();
@@ -292,6 +348,7 @@ hipError_t launch_predict_car1(double sigsqr, double omega, const double4* serie
 hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* series, int n, double* mean, double* var,
                                hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     hipLaunchKernelGGL(k_kfilter_car1, dim3(1), dim3(64), 0, st, sigsqr, omega, series, n, mean, var);
     return hipGetLastError();
 }

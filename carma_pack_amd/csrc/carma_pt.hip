@@ -174,13 +174,10 @@ static hipError_t launch_pt_k(const PtLaunch& L, int nthr, size_t lds, const dou
                               const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
                               unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt<P, G, MAXT, PC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // before every launch (see launch_logdens_p: once per process is not enough)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt<P, G, MAXT, PC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pt<P, G, MAXT, PC>), dim3((unsigned)L.R), dim3((unsigned)nthr), lds, st, L, series, pr, temps,
                        theta, logpost, chol, naccept, nswap, samples, sample_lp);
     return hipGetLastError();
@@ -436,13 +433,15 @@ long pt_row_capacity(int p, int d, int T, int n)
     const size_t lds = pt_row_lds(d, T);
     if (lds > 160 * 1024) return 0;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 0;
-    int dev = 0, ncu = 0, per_cu = 0;
+    int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 128, lds) != hipSuccess) return 0;
-    // one workgroup per CU: beyond that the ladder kernel (8 chains per wave) has the better throughput,
-    // and a grid no larger than the CU count is resident as a whole with a wide margin
-    return per_cu >= 1 ? (long)ncu : 0;
+    // One workgroup per CU: beyond that the ladder kernel (8 chains per wave) has the better throughput,
+    // and a grid no larger than the CU count is resident as a whole with a wide margin (128 threads,
+    // < 40 KiB of LDS, ~140 VGPRs fit any CU several times over).  No occupancy query: on this stack
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor returned hipErrorUnknown for a kernel that had not
+    // been launched yet, and HIP's last-error is sticky across later successful calls.
+    return (long)ncu;
 }
 
 template <int P>
@@ -451,6 +450,9 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
                                   unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
 {
     const size_t lds = pt_row_lds(L.d, L.T);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt_row<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(128), lds, st, L, S, series, pr, temps,
                        theta, logpost, chol, naccept, nswap, samples, sample_lp);
     return hipGetLastError();
@@ -460,6 +462,7 @@ hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const dou
                          const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
                          unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     switch (p) {
         case 2: return launch_pt_row_p<2>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
         case 3: return launch_pt_row_p<3>(L, S, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
@@ -475,6 +478,7 @@ hipError_t launch_pt(int p, const PtLaunch& L, const double4* series, const Prio
                      double* theta, double* logpost, double* chol, unsigned* naccept, unsigned* nswap, double* samples,
                      double* sample_lp, hipStream_t st)
 {
+    (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     switch (p) {
         case 1: return launch_pt_p<1>(L, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);
         case 2: return launch_pt_p<2>(L, series, pr, temps, theta, logpost, chol, naccept, nswap, samples, sample_lp, st);

@@ -154,13 +154,20 @@ def test_random_batch_vs_oracle_config2(cpa, readme):
 def test_ragged_and_empty_batches(cpa, readme):
     g = readme
     ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3, max_stdev=_pop_var_stdev(g["y"]))
-    full = ctx.logdensity(np.tile(g["theta"], (40, 1)))       # 1280 evals
+    big = np.tile(g["theta"], (40, 1))                        # 1280 evals
+    full = ctx.logdensity(big)                                # two-wave row kernel (> 1024 evaluations)
+    full1k = ctx.logdensity(big[:1024])                       # three-wave pipeline (<= 1024 evaluations)
     assert ctx.logdensity(np.empty((0, 11))).shape == (0,)
-    for B in (1, 7, 8, 9, 63, 65, 1025):
-        th = np.tile(g["theta"], (B // 32 + 1, 1))[:B]
+    for B in (1, 7, 8, 9, 63, 65, 1023, 1025, 1279):
+        th = big[:B]
         got = ctx.logdensity(th)
-        # bit-identical regardless of batch size / position in the wave
-        assert np.array_equal(got, full[:B], equal_nan=True)
+        # bit-identical regardless of batch size / position in the wave (within one launch shape;
+        # different shapes are different instruction streams and agree to rounding)
+        ref = full1k if B <= 1024 else full
+        assert np.array_equal(got, ref[:B], equal_nan=True)
+    fin = np.isfinite(full1k)
+    assert np.array_equal(fin, np.isfinite(full[:1024]))
+    assert np.allclose(full1k[fin], full[:1024][fin], rtol=1e-12, atol=0)
     with pytest.raises(ValueError):
         cpa.Context(g["t"], g["y"], g["yerr"], 3, 3)
     with pytest.raises(ValueError):
@@ -213,8 +220,9 @@ def test_full_size_properties(cpa, readme):
 
 @pytest.mark.parametrize("p,q", [(2, 1), (3, 2), (4, 0), (5, 3), (6, 5), (7, 2)])
 def test_launch_shapes_agree(cpa, p, q):
-    """The three launch shapes -- row variant (<= 2048 evaluations, one evaluation per DPP row), G-lane
-    producer/consumer (<= 8192) and the throughput kernel -- against the oracle and each other."""
+    """The four launch shapes -- three-wave pipeline (<= 1024 evaluations), two-wave row variant (<= 2048,
+    one evaluation per DPP row), G-lane producer/consumer (<= 8192) and the throughput kernel -- against
+    the oracle and each other."""
     t, y, yerr = irregular_series(203, seed=50 + p)
     rng = np.random.default_rng(500 + 10 * p + q)
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(48)])
@@ -224,7 +232,7 @@ def test_launch_shapes_agree(cpa, p, q):
     from mp_truth import loglik_truth
     arb = lambda i: loglik_truth(t, y, yerr, th[i % 48], p, q)[0]   # noqa: E731
     res = {}
-    for name, B in (("row", 48), ("row2", 1500), ("pc", 3000), ("pc2", 6000), ("plain", 20000)):
+    for name, B in (("p3", 48), ("p3b", 1000), ("row", 1100), ("row2", 1500), ("pc", 3000), ("pc2", 6000), ("plain", 20000)):
         big = np.tile(th, (B // 48 + 1, 1))[:B]
         got = ctx.logdensity(big)
         # every copy of a theta gives the same bits, wherever it sits in the launch
@@ -232,8 +240,9 @@ def test_launch_shapes_agree(cpa, p, q):
         res[name] = got[:48]
         assert_parity(res[name], want, RTOL, "%s p=%d q=%d" % (name, p, q), arbiter=arb, max_arbitrated=3)
     fin = np.isfinite(want)
-    for name in ("row2", "pc", "pc2", "plain"):
+    for name in ("p3", "p3b", "row", "row2", "pc", "pc2", "plain"):
         assert np.array_equal(np.isfinite(res[name]), fin)
+    assert np.array_equal(res["p3"], res["p3b"], equal_nan=True)
     assert np.array_equal(res["row"], res["row2"], equal_nan=True)
     assert np.array_equal(res["pc"], res["pc2"], equal_nan=True)
 
