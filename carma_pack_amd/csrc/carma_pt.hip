@@ -20,6 +20,7 @@
 #include "carma_pt_core.h"
 #include "carma_pt_row.h"
 #include "carma_ring.h"
+#include "carma_pipe3.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -226,7 +227,7 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
 // A barrier that does not complete within ~seconds sets abort_flag and the launch ends (reported as an
 // error by the host) instead of hanging the GPU.
 template <int P>
-__global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
+__global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
                                                 const double* __restrict__ temps, double* __restrict__ theta,
                                                 double* __restrict__ logpost, double* __restrict__ chol,
                                                 unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,
@@ -235,11 +236,13 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
     constexpr int G = 16, CPW = 4;                         // lanes per chain, chains per workgroup
     extern __shared__ double4 smem4[];
     const int tid = threadIdx.x, lane64 = tid & 63;
-    const bool producer = tid >= 64;
+    const int wave = tid >> 6;                             // 0: chains + covariance recursion, 1: mean recursion, 2: rho producer
+    const bool producer = wave != 0;                        // "not the chain-owning wave"
     const int d = L.d, T = L.T;
-    Cx* ring = reinterpret_cast<Cx*>(smem4 + 128);
-    double* s_thn = reinterpret_cast<double*>(ring + RingGeom<P>::ENTRIES);   // [CPW][16] proposals
-    double* s_lp = s_thn + CPW * PT_DMAX;                  // [T] the ladder's log-posteriors (exchange)
+    Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3.h rings
+    double* s_thn = reinterpret_cast<double*>(ring + Pipe3Geom<P>::ENTRIES);  // [CPW][16] proposals
+    double* s_ll = s_thn + CPW * PT_DMAX;                  // [CPW] log-density of the proposals (mean wave -> chain wave)
+    double* s_lp = s_ll + CPW;                             // [T] the ladder's log-posteriors (exchange)
     double* s_dbeta = s_lp + T;
     double* s_logu = s_dbeta + T;
     unsigned* s_nswap = reinterpret_cast<unsigned*>(s_logu + T);
@@ -249,13 +252,13 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
     const int part = (int)(blockIdx.x % S.wpl);
     const long ch0 = lad * T;                              // first chain of the ladder in the state arrays
 
-    for (int i = tid; i < T; i += 128) {
+    for (int i = tid; i < T; i += 192) {
         s_dbeta[i] = i > 0 ? 1.0 / temps[i] - 1.0 / temps[i - 1] : 0.0;
         s_nswap[i] = 0;
     }
     if (tid == 0) *s_flag = 0;
 
-    Grp<G> g{smem4 + (tid & ~63), lane64, nullptr};
+    Grp<G> g{nullptr, lane64, nullptr};
     const int row = lane64 >> 4, j = lane64 & 15;
     const int c = part * CPW + row;                        // chain (temperature index) of this row
     const bool active = c < T;
@@ -288,15 +291,28 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
         CARMA_STAMP(st1);
         __syncthreads();                                   // proposals visible to the producer wave
         CARMA_STAMP(st2);
-        if (producer) {
-            ring_produce_row<P>(g, thn_lds, series, L.n, ring);
+        // the three-wave pipeline of carma_pipe3.h on the proposals; the mean wave hands the log-density back
+        if (wave == 2) {
+            pipe3_produce<P>(g, thn_lds, series, L.n, ring);
         } else {
             Model<P> m;
             model_from_theta<P, G>(g, thn_lds, L.q, pr, 0, m);
-            bool sing;
-            double ll = ring_consume<P, G>(g, m, series, L.n, ring, &sing);
-            ll += log_prior(m.scale, pr.measerr_dof);
-            if (sing || !m.valid) ll = -1.0 / 0.0;
+            FilterConsts<P> fc;
+            filter_reset<P, G>(g, m, fc);
+            RowConsts<P> rc;
+            row_consts<P>(g, m, fc, rc);
+            if (wave == 0) {
+                pipe3_cov<P>(g, m, rc, L.n, ring);
+            } else {
+                double ll = pipe3_mean<P>(g, m, rc, L.n, ring);
+                ll += log_prior(m.scale, pr.measerr_dof);
+                if (fc.sing || !m.valid) ll = -1.0 / 0.0;
+                if (j == 0) s_ll[row] = ll;
+            }
+        }
+        __syncthreads();                                   // log-densities visible to the chain wave
+        if (wave == 0) {
+            const double ll = s_ll[row];
             CARMA_STAMP(st3);
             if (ram_finish_row(g, ch, d, temperature, iter, L.maxiter, key, ll, znorm2, &lp)) nacc++;
             CARMA_STAMP(st4);
@@ -305,18 +321,24 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
             // publish this workgroup's chains
             double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
             double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
+            // Agent-scope (write-through) stores and loads for the staged values instead of a device-wide
+            // fence: a release/acquire fence at agent scope writes back and invalidates the whole L2 of the
+            // XCD, and with 256 workgroups doing that every iteration the swap cost grew from 4 to 20 us
+            // (the L2-resident series had to be re-fetched each time).  The stores are complete (vmcnt)
+            // before the arrival counter is bumped.
             if (!producer && active) {
-                if (j < d) st_th[(ch0 + c) * d + j] = ch.th;
-                if (j == 0) st_lp[ch0 + c] = lp;
+                if (j < d) __hip_atomic_store(&st_th[(ch0 + c) * d + j], ch.th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j == 0) __hip_atomic_store(&st_lp[ch0 + c], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
             CARMA_STAMP(st5);
             if (tid == 0) {
-                __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target = (unsigned)S.wpl * (nexch + 1);
                 unsigned spins = 0;
-                while (__hip_atomic_load(&S.counter[lad], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                while (__hip_atomic_load(&S.counter[lad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     if (__hip_atomic_load(S.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
                         ++spins > 20000000u) {
                         __hip_atomic_store(S.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
             __syncthreads();
             CARMA_STAMP(st6);
             if (*s_flag) break;                            // uniform: the whole workgroup leaves
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             // the ladder's log-posteriors and swap uniforms (keyed by the hotter chain's global slot):
             // lane i of the chain wave owns temperature i, the sweep runs through v_readlane
             if (T <= 64) {
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
                         ch.th = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
-                for (int i = tid; i < T; i += 128) {
+                for (int i = tid; i < T; i += 192) {
                     s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_src[i] = i;
                     RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
@@ -398,13 +420,13 @@ __global__ __launch_bounds__(128) void k_pt_row(PtLaunch L, PtRowSync S, const d
     }
     __syncthreads();
     if (part == 0)
-        for (int i = tid; i < T; i += 128) nswap[ch0 + i] += s_nswap[i];
+        for (int i = tid; i < T; i += 192) nswap[ch0 + i] += s_nswap[i];
 }
 
 static size_t pt_row_lds(int d, int T)
 {
     (void)d;
-    return 128 * sizeof(double4) + RingGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
+    return Pipe3Geom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
 }
 
 template <int P>
@@ -453,7 +475,7 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt_row<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(128), lds, st, L, S, series, pr, temps,
+    hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(192), lds, st, L, S, series, pr, temps,
                        theta, logpost, chol, naccept, nswap, samples, sample_lp);
     return hipGetLastError();
 }
