@@ -246,13 +246,13 @@ struct FilterConsts {
     Cx c_own;     // (V b^H)_r
     Cx ball[P];   // b_j for all j
     double s0;    // Re(b V b^H)
-    bool sing;    // exactly zero pivot in the Vandermonde solve
+    bool sing;    // singular Vandermonde system (two equal roots)
 };
 
 // Reset (kfilter.cpp:138-186).
-// Column r of the Vandermonde matrix E_ir = omega_r^i lives in lane r; the right-hand side
-// e_{p-1} is replicated.  LU with partial pivoting (|re|+|im| pivot rule), forward
-// substitution folded in, then column-oriented back substitution.
+// Lane r holds the powers of its own root (column r of the Vandermonde matrix E_ir = omega_r^i) for the
+// rotated MA coefficient b_r; the solve E J = e_{p-1} is done in closed form (see below; the first
+// version of this file ran a lane-distributed LU with partial pivoting, 6.4k cycles against 1k).
 template <int P, int G, class GrpT>
 CARMA_DEV void filter_reset(const GrpT& g, const Model<P>& m, FilterConsts<P>& fc)
 {
@@ -265,59 +265,30 @@ CARMA_DEV void filter_reset(const GrpT& g, const Model<P>& m, FilterConsts<P>& f
         for (int i = 0; i < P; i++) {
             a[i] = pw;
             pw = cmul(pw, m.w);
-            rhs[i] = {i == P - 1 ? 1.0 : 0.0, 0.0};
         }
     }
     Cx b_own = {0.0, 0.0};   // rotated MA coefficient b_r = sum_i beta_i omega_r^i (kfilter.cpp:162)
 #pragma unroll
     for (int i = 0; i < P; i++) b_own = cadd(b_own, cscale(a[i], m.beta[i]));
 
-    bool sing = false;
+    // J = E^{-1} e_{p-1} (kfilter.cpp:144-160).  E is the Vandermonde matrix of the roots, and the last
+    // column of its inverse has the closed form J_r = 1 / prod_{l != r} (omega_r - omega_l) (the
+    // leading coefficients of the Lagrange basis), which replaces the LU solve: p-1 complex products
+    // and one reciprocal per lane, accurate to a few ulp whatever the conditioning of E (the reference's
+    // LAPACK LU loses cond(E) eps; tests arbitrate such cases against 50-digit arithmetic).
+    // Singular E <=> two equal roots <=> a zero product: the reference's arma::solve throws, -> -inf.
+    Cx dprod = {1.0, 0.0};
+    const int rr = r < P ? r : P - 1;
 #pragma unroll
-    for (int k = 0; k < P; k++) {
-        int piv = k;
-        double best = fabs(a[k].re) + fabs(a[k].im);
-#pragma unroll
-        for (int i = k + 1; i < P; i++) {
-            double v = fabs(a[i].re) + fabs(a[i].im);
-            bool gt = v > best;
-            best = gt ? v : best;
-            piv = gt ? i : piv;
-        }
-        piv = g.bcast_iu(piv, k);
-        best = g.bcast_u(best, k);
-        if (best == 0.0) sing = true;
-#pragma unroll
-        for (int i = k + 1; i < P; i++) {
-            bool sw = (piv == i);
-            Cx t = a[i];
-            a[i] = csel(sw, a[k], a[i]);
-            a[k] = csel(sw, t, a[k]);
-            Cx tr = rhs[i];
-            rhs[i] = csel(sw, rhs[k], rhs[i]);
-            rhs[k] = csel(sw, tr, rhs[k]);
-        }
-        Cx rinv = cdiv(Cx{1.0, 0.0}, a[k]);
-#pragma unroll
-        for (int i = k + 1; i < P; i++) {
-            Cx l = cmul(a[i], rinv);
-            l.re = g.bcast_u(l.re, k);
-            l.im = g.bcast_u(l.im, k);
-            Cx upd = csub(a[i], cmul(l, a[k]));
-            a[i] = csel(r > k, upd, a[i]);
-            rhs[i] = csub(rhs[i], cmul(l, rhs[k]));
-        }
+    for (int l = 0; l < P; l++) {
+        const Cx f = csub(m.w, m.wall[l]);
+        dprod = (l != rr) ? cmul(dprod, f) : dprod;
     }
+    const bool zero = (dprod.re == 0.0 && dprod.im == 0.0);
+    const bool sing = g.sum((act && zero) ? 1.0 : 0.0) != 0.0;
+    const Cx Jown = cdiv(Cx{1.0, 0.0}, dprod);
 #pragma unroll
-    for (int k = P - 1; k >= 0; k--) {
-        Cx ukk = {g.bcast_u(a[k].re, k), g.bcast_u(a[k].im, k)};
-        rhs[k] = cdiv(rhs[k], ukk);
-#pragma unroll
-        for (int i = 0; i < k; i++) {
-            Cx uik = {g.bcast_u(a[i].re, k), g.bcast_u(a[i].im, k)};
-            rhs[i] = csub(rhs[i], cmul(rhs[k], uik));
-        }
-    }
+    for (int j = 0; j < P; j++) rhs[j] = {g.bcast_u(Jown.re, j), g.bcast_u(Jown.im, j)};
     // rhs[] now holds J (replicated).  b for all lanes:
     Cx ball[P];
 #pragma unroll
