@@ -58,8 +58,13 @@ CARMA_DEV double recip(double v)
 }
 CARMA_DEV Cx cdiv(Cx a, Cx b)
 {
+#ifdef CARMA_EXACT_CDIV
+    const double den = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+#else
     const double s = recip(b.re * b.re + b.im * b.im);       // one reciprocal instead of two IEEE divisions
     return {(a.re * b.re + a.im * b.im) * s, (a.im * b.re - a.re * b.im) * s};
+#endif
 }
 CARMA_DEV Cx csel(bool m, Cx a, Cx b) { return {m ? a.re : b.re, m ? a.im : b.im}; }
 

@@ -247,6 +247,37 @@ def test_launch_shapes_agree(cpa, p, q):
     assert np.array_equal(res["pc"], res["pc2"], equal_nan=True)
 
 
+@pytest.mark.parametrize("p,q", [(2, 0), (5, 3), (7, 4)])
+def test_series_lengths_around_chunk_boundaries(cpa, p, q):
+    """The ring kernels work in 16-step chunks (one barrier each, buffers rotating): every series length
+    around the chunk boundaries, in every launch shape that uses a ring, against the oracle."""
+    rng = np.random.default_rng(900 + p)
+    for n in (2, 3, 7, 8, 9, 15, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49, 50, 65):
+        t, y, yerr = irregular_series(n, seed=n)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(12)])
+        ctx = cpa.Context(t, y, yerr, p, q)
+        m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+        want = m.logdensity_batch(th, ignore_prior=True)
+        roots = [np.asarray(orc.ar_roots(v, p)) for v in th]
+        dup = np.array([np.min(np.abs(r[:, None] - r[None, :]) + np.eye(p)) == 0.0 for r in roots])
+        from mp_truth import loglik_truth
+        arb = lambda i: loglik_truth(t, y, yerr, th[i % 12], p, q)[0]   # noqa: E731
+        for B in (12, 1100, 3000):       # three-wave pipeline / two-wave row kernel / G-lane producer-consumer
+            big = np.tile(th, (B // 12 + 1, 1))[:B]
+            got = ctx.logdensity(big, ignore_prior=True)
+            assert np.array_equal(got, np.tile(got[:12], B // 12 + 1)[:B], equal_nan=True), (n, B)
+            # exactly repeated roots (the helper degenerates for 2-point series): the reference's LU leaves a
+            # rounding-sized pivot and returns garbage (NaN or finite), the closed-form solve detects the
+            # singular system and returns -inf (the reference's own runtime_error path); not comparable
+            ok = ~dup
+            assert np.isneginf(got[:12][dup]).all()
+            if ok.any():
+                # (random prior-like CARMA(7,4) models on a few dozen points reach cond ~ 1e6, where the
+                # reference itself is 1e-10 off the 50-digit value: same order of magnitude required)
+                assert_parity(got[:12][ok], want[ok], RTOL, "p=%d q=%d n=%d B=%d" % (p, q, n, B),
+                              arbiter=lambda i: arb(np.flatnonzero(ok)[i]), max_arbitrated=3, arb_factor=5.0)
+
+
 @pytest.mark.parametrize("p,q,n", [(7, 6, 10000), (6, 2, 3001), (2, 1, 513), (3, 0, 1000), (4, 3, 64)])
 def test_long_series_vs_oracle(cpa, p, q, n):
     """BASELINE config 4 shape (CARMA(7,6), n = 10^4) and other orders on long irregular series."""
