@@ -74,17 +74,32 @@ CARMA_DEV Cx quad_root(double lq1, double lq2, int which)
 {
     double q1 = exp(lq1), q2 = exp(lq2);
     double disc = q2 * q2 - 4.0 * q1;
+    const double sq = sqrt(fabs(disc));              // one sqrt for both signs of the discriminant
     Cx r;
     if (disc > 0) {
-        double sq = sqrt(disc);
         r.re = which ? -0.5 * (q2 - sq) : -0.5 * (q2 + sq);
         r.im = 0.0;
     } else {
         r.re = -0.5 * q2;
-        double im = -0.5 * sqrt(-disc);
+        double im = -0.5 * sq;
         r.im = which ? -im : im;
     }
     return r;
+}
+// both members of the pair from one evaluation of the exponentials and the square root
+CARMA_DEV void quad_roots(double lq1, double lq2, Cx& r0, Cx& r1)
+{
+    double q1 = exp(lq1), q2 = exp(lq2);
+    double disc = q2 * q2 - 4.0 * q1;
+    const double sq = sqrt(fabs(disc));
+    if (disc > 0) {
+        r0 = {-0.5 * (q2 + sq), 0.0};
+        r1 = {-0.5 * (q2 - sq), 0.0};
+    } else {
+        const double im = -0.5 * sq;
+        r0 = {-0.5 * q2, im};
+        r1 = {-0.5 * q2, -im};
+    }
 }
 
 // Model quantities of one evaluation, as held by lane r of its group.
@@ -131,21 +146,21 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
 #pragma unroll
         for (int i = 0; i < P; i++) cf[i] = {0.0, 0.0};
         cf[0] = {1.0, 0.0};
+        auto fold = [&](const Cx root, const int i) __attribute__((always_inline)) {   // cf *= (x - root), root number i
 #pragma unroll
-        for (int i = 0; i < P - 1; i++) {
-            if (i < q) {
-                Cx root;
-                if ((q & 1) && i == q - 1) {
-                    root.re = -exp(theta[3 + P + q - 1]);
-                    root.im = 0.0;
-                } else {
-                    int pair = i >> 1;
-                    root = quad_root(theta[3 + P + 2 * pair], theta[3 + P + 2 * pair + 1], i & 1);
-                }
+            for (int k = P - 1; k >= 1; k--) {
+                if (k <= i + 1) cf[k] = csub(cf[k], cmul(root, cf[k - 1]));
+            }
+        };
 #pragma unroll
-                for (int k = P - 1; k >= 1; k--) {
-                    if (k <= i + 1) cf[k] = csub(cf[k], cmul(root, cf[k - 1]));
-                }
+        for (int i0 = 0; i0 < P - 1; i0 += 2) {        // one quadratic factor (two roots) at a time
+            if (i0 + 1 < q) {
+                Cx r0, r1;
+                quad_roots(theta[3 + P + i0], theta[3 + P + i0 + 1], r0, r1);
+                fold(r0, i0);
+                if (i0 + 1 < P - 1) fold(r1, i0 + 1);
+            } else if (i0 < q) {                       // odd q: the last root is real (carpack.cpp:548-552)
+                fold(Cx{-exp(theta[3 + P + q - 1]), 0.0}, i0);
             }
         }
         double cq = 0.0;
