@@ -267,6 +267,8 @@ struct FilterConsts {
     Cx ball[P];   // b_j for all j
     double s0;    // Re(b V b^H)
     bool sing;    // singular Vandermonde system (two equal roots)
+    Cx Jown;      // J_r, last column of E^{-1}
+    Cx Jall[P];   // J_j for all j
 };
 
 // Reset (kfilter.cpp:138-186).
@@ -335,6 +337,9 @@ CARMA_DEV void filter_reset(const GrpT& g, const Model<P>& m, FilterConsts<P>& f
 #pragma unroll
     for (int j = 0; j < P; j++) fc.ball[j] = ball[j];
     fc.sing = sing;
+    fc.Jown = Jown;
+#pragma unroll
+    for (int j = 0; j < P; j++) fc.Jall[j] = rhs[j];
 }
 
 

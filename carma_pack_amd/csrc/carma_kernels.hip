@@ -14,11 +14,15 @@
 // series (24 B/datum, shared by every evaluation and L2/scalar-cache resident) + 8(d+1) B/eval.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "grp_device.h"
 #include "carma_core.h"
 #include "carma_ring.h"
 #include "carma_predict.h"
 #include "carma_pipe3.h"
+#include "carma_scan_dev.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -85,6 +89,21 @@ __global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* 
     if (blockIdx.x == 0 && threadIdx.x == 0)
         printf("kernel stamps (100 MHz ticks): model %llu  reset+loop %llu  tail %llu\n", st1 - st0, st2 - st1, st3 - st2);
 #endif
+}
+
+// Time-parallel filter (carma_scan.h): one evaluation per wave, every lane a block of SMAX consecutive data.
+template <int P, int SMAX>
+__global__ __launch_bounds__(64) void k_logdens_carma_scan(const double* __restrict__ theta, int B, int d, int q,
+                                                           const double4* __restrict__ series, int n, Prior pr,
+                                                           int ignore_prior, double* __restrict__ out)
+{
+    extern __shared__ double4 smem4[];
+    double2* xch = reinterpret_cast<double2*>(smem4);
+    double* sh = reinterpret_cast<double*>(xch + ScanLds<P>::NPAIR * 64);
+    const int lane = threadIdx.x;
+    const long e = blockIdx.x;
+    const double ll = scan_logdensity<P, SMAX>(theta + e * d, q, series, n, pr, ignore_prior, lane, xch, sh);
+    if (lane == 0) out[e] = ll;
 }
 
 // Smallest launches (<= 1024 evaluations): covariance wave + mean wave + rho producer per 4 evaluations
@@ -235,6 +254,17 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     // that) a later 81 KiB launch failed with hipErrorUnknown.  The call costs ~1 us on the host and
     // the launches are asynchronous.
     auto big_lds = [](const void* kf) { return hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    if constexpr (P <= 5) {
+        // time-parallel filter (carma_scan.h), opt-in while it is being evaluated: CARMA_LOGDENS_KERNEL=scan
+        const char* ek = getenv("CARMA_LOGDENS_KERNEL");
+        const bool want_scan = ek && strcmp(ek, "scan") == 0;
+        if (want_scan && n >= 2 && n <= 64 * 5 && B <= 4096) {
+            const size_t lds = ScanLds<P>::BYTES;
+            hipLaunchKernelGGL((k_logdens_carma_scan<P, 5>), dim3((unsigned)B), dim3(64), lds, st, theta, B, d, q, series, n, pr,
+                               ignore_prior, out);
+            return hipGetLastError();
+        }
+    }
     if (rows <= 256 && n >= 8) {
         // one workgroup per CU: covariance wave + mean wave + producer wave (carma_pipe3.h)
         const size_t lds = Pipe3Geom<P>::BYTES;

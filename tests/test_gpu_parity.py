@@ -388,3 +388,24 @@ def test_edge_cases_nan_inf_tiny_series(cpa, readme):
     assert c3.n == 2 and c3.logdensity(th, ignore_prior=True) == a
     with pytest.raises(ValueError):
         cpa.Context(t[:1], y[:1], yerr[:1], 2, 1)
+
+
+def test_scan_kernel_opt_in(cpa, readme, monkeypatch):
+    """The experimental time-parallel kernel (carma_scan.h, CARMA_LOGDENS_KERNEL=scan): same answers as the
+    default kernels on ordinary parameter vectors; its known weakness (rounding amplified by the signal-to-
+    noise ratio) is bounded here at 1e-7 over the whole 1024-theta bench batch."""
+    g = readme
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    th = theta_batch(np.random.default_rng(2), 1024, 5, 3, t, y, theta_center=g["theta"][0])
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_var_stdev(y))
+    ref = ctx.logdensity(th)
+    monkeypatch.setenv("CARMA_LOGDENS_KERNEL", "scan")
+    got = ctx.logdensity(th)
+    again = ctx.logdensity(th)
+    monkeypatch.delenv("CARMA_LOGDENS_KERNEL")
+    assert np.array_equal(got, again, equal_nan=True)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin)
+    rel = np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])
+    print("scan kernel: median rel diff %.1e, 99%% %.1e, max %.1e" % (np.median(rel), np.quantile(rel, 0.99), rel.max()))
+    assert np.median(rel) < 1e-13 and rel.max() < 1e-7
