@@ -16,7 +16,7 @@
 // sequential filter, ~1/10 of its dependent depth, all 64 lanes busy.  Plain C++ (fma), shared with the
 // CPU test harness (tests/emu).
 //
-// STATUS: experimental, opt-in (CARMA_LOGDENS_KERNEL=scan).  It matches the oracle to 1e-10 on ordinary
+// STATUS: experimental, opt-in (CARMA_LOGDENS_KERNEL=scan).  It matches the CPU reference path to 1e-10 on ordinary
 // parameter vectors, but its rounding errors are amplified by the signal-to-noise ratio of the model (the
 // combine solves with W = I + C J, J ~ 1/yerr^2): 1e-9 on theta #330 of the bench batch, where the sequential
 // filter is at 4e-13 -- it does not meet the parity bar, and at 40 us per 1024-evaluation launch it is not
