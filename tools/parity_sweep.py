@@ -1,0 +1,43 @@
+"""Wide parity sweep: many random prior-like parameter vectors for every order against the CPU reference
+restatement (test infrastructure, tests/ oracle), with the 50-digit arbiter for the entries above 1e-10.
+Run on the GPU box:  python tools/parity_sweep.py [ntheta]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import carma_pack_amd as cpa
+import oracle as orc
+from helpers import irregular_series, prior_like_theta
+from mp_truth import loglik_truth
+
+ntheta = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+tot = bad = worse = better = 0
+orders = [int(v) for v in os.environ.get("SWEEP_P", "2,3,4,5,6,7").split(",")]
+for p in orders:
+    for q in range(0, p):
+        t, y, yerr = irregular_series(150, seed=100 * p + q)
+        rng = np.random.default_rng(7000 + 10 * p + q)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(ntheta)])
+        ctx = cpa.Context(t, y, yerr, p, q)
+        m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+        want = m.logdensity_batch(th, nthreads=os.cpu_count() or 8)
+        got = ctx.logdensity(th)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin), (p, q)
+        rel = np.abs(got[fin] - want[fin]) / np.abs(want[fin])
+        idx = np.flatnonzero(fin)[rel > 1e-10]
+        nw = nb = 0
+        for i in idx[:10]:
+            T = float(loglik_truth(t, y, yerr, th[i], p, q)[0])
+            eg, eo = abs(got[i] - T) / abs(T), abs(want[i] - T) / abs(T)
+            if eg > max(1e-10, 3 * eo):
+                nw += 1
+                if os.environ.get("SWEEP_VERBOSE"):
+                    print("   theta %d: gpu err %.1e  reference err %.1e" % (i, eg, eo))
+            if eg < eo / 3:
+                nb += 1
+        better += nb
+        tot += fin.sum(); bad += idx.size; worse += nw
+        print("p=%d q=%d: finite %4d  median %.1e  99%% %.1e  max %.1e  >1e-10: %d (GPU worse than 3x reference on %d of the first %d)" % (
+            p, q, fin.sum(), np.median(rel), np.quantile(rel, 0.99), rel.max(), idx.size, nw, min(10, idx.size)), flush=True)
+print("total finite %d, above 1e-10: %d (%.3f%%), of the arbitrated ones GPU >3x worse than the reference: %d, >3x better: %d" % (tot, bad, 100.0 * bad / tot, worse, better))
