@@ -128,7 +128,8 @@ def test_gpu_matches_emulator_trajectory(cpa):
     np.testing.assert_allclose(lp1[0], out["lp"], rtol=1e-8)
 
 
-@pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1)])
+@pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1), (3, 1, 1, 5), (3, 1, 2, 1),
+                                     (4, 2, 17, 2), (2, 0, 33, 1), (3, 2, 64, 1), (2, 1, 70, 1)])
 def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkeypatch):
     """The two sampler kernels -- k_pt (one workgroup per ladder) and k_pt_row (one chain per DPP row,
     ladder spread over workgroups, register-resident RAM step, cross-workgroup swap rendezvous) -- use
