@@ -6,6 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import carma_pack_amd as cpa
+if os.environ.get("SWEEP_LIB"):
+    import carma_pack_amd._lib as _L
+    _L.LIB_PATH = os.environ["SWEEP_LIB"]
+    _L.lib = _L._load()
 import oracle as orc
 from helpers import irregular_series, prior_like_theta
 from mp_truth import loglik_truth
