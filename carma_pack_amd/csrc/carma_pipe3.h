@@ -111,7 +111,7 @@ __device__ __forceinline__ void pipe3_cov(const Grp<16>& g, const Model<P>& m, c
     double D[P];
 #pragma unroll
     for (int j = 0; j < P; j++) D[j] = 0.0;
-    double w = 0.0, k = rc.c_own;
+    double w = 0.0;
     const double2* rho_b = nullptr;      // this lane's rho entries of the current chunk
     const double2* rec_b = nullptr;
     double2* link_b = nullptr;
@@ -123,8 +123,8 @@ __device__ __forceinline__ void pipe3_cov(const Grp<16>& g, const Model<P>& m, c
             rec_n = rec_b[s + 1];
         }
         // var_{kk-1} = s0 + e + h.w   (kfilter.cpp:180-182, 209-210)
-        double var;
-        g.template row_sums_var<P>(var, rec.y, m.scale, rc.s0, w, rc.hall);
+        double var, k;                                        // k = w + c, the gain Cov(z, y) of this step
+        g.template row_sums_var<P>(var, k, rec.y, m.scale, rc.s0, w, rc.c_own, rc.hall);
         const double sv = recip(var);
         // d_j = D_j - (k s) k_j   (kfilter.cpp:197); the mean wave gets the gain k_r and var
         double nt;
@@ -144,7 +144,6 @@ __device__ __forceinline__ void pipe3_cov(const Grp<16>& g, const Model<P>& m, c
                 w0 = fma(D[j], rc.hall[j], w0);
         }
         w = w0 + w1;                                          // (D h^T)_r
-        k = w + rc.c_own;
     };
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c

@@ -166,10 +166,11 @@ struct Grp {
     }
     // halves of row_sums / row_gain for the covariance wave and the mean wave of carma_pipe3.h
     template <int P>
-    CARMA_DEV void row_sums_var(double& var, double e, double scale, double s0, double w, const double (&h)[P]) const
+    CARMA_DEV void row_sums_var(double& var, double& k, double e, double scale, double s0, double w, double c_own,
+                                const double (&h)[P]) const
     {
         static_assert(G == 16, "row broadcast");
-        RowAsm<P>::sums_var(var, e, scale, s0, w, h);
+        RowAsm<P>::sums_var(var, k, e, scale, s0, w, c_own, h);
     }
     template <int P>
     CARMA_DEV void row_sums_innov(double& innov, double y, double mu, double z, const double (&h)[P]) const
