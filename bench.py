@@ -155,11 +155,11 @@ def main():
         # (profiles/r01: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB per dispatch; gfx950
         # FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound)
         traffic_gbs_bytes, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_v7.json")
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_v8.json")
         if B == 1024 and os.path.exists(pmc):
             pj = json.load(open(pmc))
             traffic_gbs_bytes = (2.0 * pj["FETCH_SIZE"]["mean"] + pj["WRITE_SIZE"]["mean"]) * 1024.0
-            traffic_src = "profiles/r01/pmc_v7.json (rocprofv3 --pmc, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch"
+            traffic_src = "profiles/r01/pmc_v8.json (rocprofv3 --pmc, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch"
         res = {
             "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
             "value": value,
