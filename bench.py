@@ -156,9 +156,13 @@ def main():
         # FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound)
         traffic_gbs_bytes, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01", "pmc_v8.json")
+        pmc_extra = None
         if B == 1024 and os.path.exists(pmc):
             pj = json.load(open(pmc))
             traffic_gbs_bytes = (2.0 * pj["FETCH_SIZE"]["mean"] + pj["WRITE_SIZE"]["mean"]) * 1024.0
+            # what actually bounds the kernel: the instruction stream of its critical wave
+            pmc_extra = {k: pj[k]["mean"] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                                                     "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if k in pj}
             traffic_src = "profiles/r01/pmc_v8.json (rocprofv3 --pmc, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch"
         res = {
             "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
@@ -194,6 +198,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_eval * B,
                 "note": "latency/FP64-VALU bound by construction (sequential n-step recursion); "
                         "HBM roofline reported as north_star asks",
+                "pmc_per_launch": pmc_extra,
                 "fp64_valu": {
                     "flops_per_eval": flops_per_eval,
                     "achieved_tflops": flops_per_eval * B / (kernel_ms * 1e-3) / 1e12,
