@@ -132,7 +132,10 @@ __global__ __launch_bounds__(192) void k_logdens_carma_p3(const double* __restri
     RowConsts<P> rc;
     row_consts<P>(g, m, fc, rc);
     if (wave == 0) {
-        pipe3_cov<P>(g, m, rc, n, ring);
+        if constexpr (RowAsm<P>::NSLOT < P)
+            pipe3_cov_split<P>(g, m, rc, n, ring);
+        else
+            pipe3_cov<P>(g, m, rc, n, ring);
         return;
     }
     double ll = pipe3_mean<P>(g, m, rc, n, ring);

@@ -165,6 +165,85 @@ __device__ __forceinline__ void pipe3_cov(const Grp<16>& g, const Model<P>& m, c
     __syncthreads();                                          // barrier nc
 }
 
+// wave A with SPLIT ROWS: row r of D lives in two lanes of the 16-lane DPP row -- lane r holds the columns
+// of the even root pairs (half A), lane 8 + r those of the odd pairs (half B; RowAsm<P>::HALF / SLOT).
+// The DPP instructions are per column either way (one v_fmac_f64_dpp per column, now with a bank mask
+// that selects the owning half), but everything that is per ENTRY -- the zero-initialisation of the
+// column mix, the row mix with its partner moves, the h-weighted row sum -- shrinks from p to
+// NSLOT = ceil(p/2 pairs) entries per lane; the two partial row sums meet by one row_ror:8.
+template <int P>
+__device__ __forceinline__ void pipe3_cov_split(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc, int n,
+                                                Cx* __restrict__ ring)
+{
+    using Geo = Pipe3Geom<P>;
+    using RA = RowAsm<P>;
+    constexpr int C = Geo::C, NS = RA::NSLOT;
+    const int lane = g.lane64;
+    const bool halfB = (lane & 8) != 0;
+    const int nc = (n + C - 1) / C;
+    // constants of row r in BOTH of its lanes
+    const double c_own = __shfl(rc.c_own, lane & ~8, 64);
+    double hs[NS];                                   // h of the column held in slot i of this half
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        double ha = 0.0, hb = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            if (RA::SLOT[j] == i && RA::HALF[j] == 0) ha = rc.hall[j];
+            if (RA::SLOT[j] == i && RA::HALF[j] == 1) hb = rc.hall[j];
+        }
+        hs[i] = halfB ? hb : ha;
+    }
+    double D[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) D[i] = 0.0;
+    double w = 0.0;
+    const double2* rho_b = nullptr;
+    const double2* rec_b = nullptr;
+    double2* link_b = nullptr;
+    double2 rho_n = make_double2(1.0, 0.0), rec_n = make_double2(0.0, 0.0);
+    auto pass = [&](const int s, const bool more) __attribute__((always_inline)) {
+        const double2 rho = rho_n, rec = rec_n;
+        if (more) {
+            rho_n = rho_b[(size_t)(s + 1) * Geo::SLOT];
+            rec_n = rec_b[s + 1];
+        }
+        double var, k;
+        g.template row_sums_var<P>(var, k, rec.y, m.scale, rc.s0, w, c_own, rc.hall);
+        const double sv = recip(var);
+        double nt;
+        RA::gain_split(nt, D, k, sv);
+        link_b[(size_t)s * Geo::SLOT] = make_double2(k, var);
+        double mm[NS];
+        RA::colmix_split(mm, rho.x, rho.y, D);
+        double wp = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const double mp = g.partner(mm[i]);
+            D[i] = fma(rho.x, mm[i], -(rho.y * mp));
+            wp = fma(D[i], hs[i], wp);
+        }
+        w = wp + __builtin_amdgcn_update_dpp(wp, wp, 0x128, 0xf, 0xf, true);      // + the other half's partial (row_ror:8)
+    };
+    for (int c = 0; c < nc; c++) {
+        __syncthreads();                                      // barrier c
+        rho_b = reinterpret_cast<const double2*>(ring + (size_t)(c % 3) * C * Geo::SLOT) + (lane & ~8);
+        rec_b = reinterpret_cast<const double2*>(ring + Geo::REC_OFF) + (c % 3) * C;
+        link_b = reinterpret_cast<double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + lane;
+        rho_n = rho_b[0];
+        rec_n = rec_b[0];
+        const int len = (n - c * C < C) ? n - c * C : C;
+        if (len == C) {
+#pragma unroll 4
+            for (int s = 0; s < C; s++) pass(s, s + 1 < C);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < len; s++) pass(s, true);
+        }
+    }
+    __syncthreads();                                          // barrier nc
+}
+
 // wave B: the state mean and the log-likelihood sum
 template <int P>
 __device__ __forceinline__ double pipe3_mean(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc, int n,

@@ -302,7 +302,10 @@ __global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const d
             RowConsts<P> rc;
             row_consts<P>(g, m, fc, rc);
             if (wave == 0) {
-                pipe3_cov<P>(g, m, rc, L.n, ring);
+                if constexpr (RowAsm<P>::NSLOT < P)
+                    pipe3_cov_split<P>(g, m, rc, L.n, ring);
+                else
+                    pipe3_cov<P>(g, m, rc, L.n, ring);
             } else {
                 double ll = pipe3_mean<P>(g, m, rc, L.n, ring);
                 ll += log_prior(m.scale, pr.measerr_dof);

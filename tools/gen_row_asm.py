@@ -80,6 +80,63 @@ def block_gain_cov(P):
     return lines, outs, ins
 
 
+# ---- split rows (carma_pipe3.h, covariance wave): row r of D lives in TWO lanes of the 16-lane DPP row, lane r
+# (half A, bank mask 0x3) and lane 8 + r (half B, bank mask 0xc); root pairs alternate between the halves.
+def split_map(P):
+    half, slot, cnt = {}, {}, [0, 0]
+    for j in range(P):
+        hf = (j // 2) & 1
+        half[j] = hf
+        slot[j] = cnt[hf]
+        cnt[hf] += 1
+    return half, slot, max(cnt)
+
+
+BANK = ["0x3", "0xc"]
+
+
+def no_adjacent_same_dst(lines):
+    """A bank-masked v_fmac_f64_dpp immediately followed by another access to the SAME destination register
+    with the other bank mask returned stale data in the masked-off lanes (seen on gfx950 for p = 3: the lanes
+    of half A lost the term written two instructions earlier).  One instruction in between is enough
+    (p = 4, 5, 6, 7 have that by construction and pass); where the order cannot provide it, an s_nop does."""
+    out = []
+    prev_dst = None
+    for l in lines:
+        dst = l.split()[1].rstrip(",") if l.startswith("v_fmac_f64_dpp") else None
+        if dst is not None and dst == prev_dst:
+            out.append("s_nop 0")
+        out.append(l)
+        prev_dst = dst
+    return out
+
+
+def block_gain_split(P):
+    # operands: 0 nt, 1..NS D_slot | k, s
+    half, slot, ns = split_map(P)
+    ik, is_ = 1 + ns, 2 + ns
+    lines = ["v_mul_f64 %%0, %%%d, -%%%d" % (ik, is_)]
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %%%d, %%%d, %%0 row_newbcast:%d row_mask:0xf bank_mask:%s" % (1 + slot[j], ik, j, BANK[half[j]]))
+    outs = '"=&v"(nt), ' + ", ".join('"+v"(D[%d])' % i for i in range(ns))
+    ins = '"v"(k), "v"(s)'
+    return no_adjacent_same_dst(lines), outs, ins
+
+
+def block_colmix_split(P):
+    # operands: 0..NS-1 mm_slot | NS c, NS+1 s, NS+2.. D_slot
+    half, slot, ns = split_map(P)
+    ic, is_, iD = ns, ns + 1, ns + 2
+    lines = ["v_mov_b64 %%%d, 0" % i for i in range(ns)]
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %%%d, %%%d, %%%d row_newbcast:%d row_mask:0xf bank_mask:%s" % (slot[j], ic, iD + slot[j], j, BANK[half[j]]))
+    for j in range(P & ~1):
+        lines.append("v_fmac_f64_dpp %%%d, -%%%d, %%%d row_newbcast:%d row_mask:0xf bank_mask:%s" % (slot[j], is_, iD + slot[j ^ 1], j, BANK[half[j]]))
+    outs = ", ".join('"=&v"(mm[%d])' % i for i in range(ns))
+    ins = '"v"(c), "v"(s), ' + ", ".join('"v"(D[%d])' % i for i in range(ns))
+    return no_adjacent_same_dst(lines), outs, ins
+
+
 def emit(lines, outs, ins):
     body = "\n".join('            "%s\\n\\t"' % l for l in lines[:-1]) + '\n            "%s"' % lines[-1]
     return "        asm volatile(\n%s\n            : %s\n            : %s);\n" % (body, outs, ins)
@@ -126,6 +183,21 @@ for P in range(2, 8):
     l, o, i = block_gain_cov(P)
     out.append('    // covariance wave: nt = -(k s) ;  D_j += k@j nt')
     out.append('    static __device__ __forceinline__ void gain_cov(double& nt, double (&D)[%d], double k, double s)' % P)
+    out.append('    {')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    half, slot, ns = split_map(P)
+    out.append('    // split rows: column j of a row lives in half HALF[j] (0: lanes 0-7, 1: lanes 8-15) at register slot SLOT[j]')
+    out.append('    static constexpr int NSLOT = %d;' % ns)
+    out.append('    static constexpr int HALF[%d] = {%s};' % (P, ", ".join(str(half[j]) for j in range(P))))
+    out.append('    static constexpr int SLOT[%d] = {%s};' % (P, ", ".join(str(slot[j]) for j in range(P))))
+    l, o, i = block_gain_split(P)
+    out.append('    static __device__ __forceinline__ void gain_split(double& nt, double (&D)[%d], double k, double s)' % ns)
+    out.append('    {')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    l, o, i = block_colmix_split(P)
+    out.append('    static __device__ __forceinline__ void colmix_split(double (&mm)[%d], double c, double s, const double (&D)[%d])' % (ns, ns))
     out.append('    {')
     out.append(emit(l, o, i).rstrip("\n"))
     out.append('    }')
