@@ -12,7 +12,7 @@ import emu_build as emu
 import oracle as orc
 from helpers import irregular_series, prior_like_theta
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "proto"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "proto"))
 from scan_real import real_model  # noqa: E402
 
 

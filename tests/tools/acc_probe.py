@@ -1,7 +1,8 @@
 """Accuracy probe on an ill-conditioned case (p=7, q=4, n=49): GPU error against 50-digit arithmetic."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import carma_pack_amd._lib as L0
 if len(sys.argv) > 1:

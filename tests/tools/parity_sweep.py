@@ -2,7 +2,7 @@
 restatement (test infrastructure, tests/ oracle), with the 50-digit arbiter for the entries above 1e-10.
 Run on the GPU box:  python tools/parity_sweep.py [ntheta]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import carma_pack_amd as cpa

@@ -4,7 +4,7 @@ elements (A, b, C, eta, J)), to see whether the time-parallel form keeps the 1e-
 on the bench's 1024-theta batch, including its ill-conditioned members.  Not part of the product."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as orc
 from carma_pack_amd.synth import theta_batch

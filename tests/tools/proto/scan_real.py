@@ -4,7 +4,7 @@ recursions, phase 2 = Hillis-Steele scan over the lanes with the general combine
 elimination for (I + C J)), phase 3 = ordinary filter inside each block from the prefix state."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as orc
 from carma_pack_amd.synth import theta_batch
