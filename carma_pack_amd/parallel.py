@@ -42,6 +42,23 @@ def philox_uniform(seed, chain, iteration, purpose, idx=0):
     return (k + 0.5) / 9007199254740992.0
 
 
+def philox_uniform_chains(seed, chains, iteration, purpose, idx=0):
+    """`philox_uniform` for an array of chain ids at once (numpy uint64 arithmetic, same bits)."""
+    m = np.uint64(_MASK)
+    c0 = np.full(len(chains), iteration & _MASK, dtype=np.uint64)
+    c1 = np.full(len(chains), (iteration >> 32) & _MASK, dtype=np.uint64)
+    c2 = np.asarray(chains, dtype=np.uint64) & m
+    c3 = np.full(len(chains), ((purpose << 24) | idx) & _MASK, dtype=np.uint64)
+    k0, k1 = seed & _MASK, (seed >> 32) & _MASK
+    s32 = np.uint64(32)
+    for _ in range(10):
+        p0, p1 = np.uint64(_M0) * c0, np.uint64(_M1) * c2          # 32 x 32 -> 64 bits, no overflow
+        c0, c1, c2, c3 = ((p1 >> s32) ^ c1 ^ np.uint64(k0)) & m, p1 & m, ((p0 >> s32) ^ c3 ^ np.uint64(k1)) & m, p0 & m
+        k0, k1 = (k0 + _W0) & _MASK, (k1 + _W1) & _MASK
+    k = ((c0 << s32) | c1) >> np.uint64(11)
+    return (k.astype(np.float64) + 0.5) / 9007199254740992.0
+
+
 def shard_slice(n, rank, world):
     """Contiguous, balanced split of range(n)."""
     base, rem = divmod(n, world)
@@ -99,41 +116,71 @@ class LadderShard(object):
         backend.pt_shard(ntemps_global, self.slot0, 0)
         self.nswap_boundary = 0
         self.nprop_boundary = 0
+        # On a GPU the chain state lives in two torch tensors that the sampler is bound to
+        # (carma_pt_bind_state): the kernels advance them in place and the boundary exchange below
+        # reads, sends and overwrites single temperature rows without the state ever visiting the host.
+        self._th = self._lp = None
+        if str(device).startswith("cuda") and hasattr(backend, "pt_bind_state"):
+            import torch
+            self._th = torch.empty((nreplicas, self.T_local, backend.d), dtype=torch.float64, device=device)
+            self._lp = torch.empty((nreplicas, self.T_local), dtype=torch.float64, device=device)
+            torch.cuda.synchronize(device)
+            backend.pt_bind_state(self._th.data_ptr(), self._lp.data_ptr())
 
     def start(self, init=None):
         self.b.pt_start(init)
 
+    def _swap_with(self, peer, send):
+        """Send `send` to `peer` and return what it sent us.  RCCL moves device memory directly; a
+        process group that cannot (gloo) gets the R x (d+1) doubles staged through the host."""
+        import torch
+        dist = self.dist
+        staged = send.is_cuda and dist.get_backend() != "nccl"
+        buf = send.cpu() if staged else send
+        recv = torch.empty_like(buf)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, peer), dist.P2POp(dist.irecv, recv, peer)]):
+            w.wait()
+        return recv.to(send.device) if staged else recv
+
     def _exchange_boundary(self, upper):
         """Exchange with the rank above (`upper`=True: my hottest chain vs its coldest) or below."""
         import torch
-        dist = self.dist
         peer = self.rank + 1 if upper else self.rank - 1
-        th, lp = self.b.pt_get_chains()                      # [R][Tl][d], [R][Tl]
         mine = self.T_local - 1 if upper else 0
+        hot_slot = self.slot0 + self.T_local if upper else self.slot0          # global slot of the hotter chain
+        t_hot, t_cold = float(self.temps[hot_slot]), float(self.temps[hot_slot - 1])
+        u = philox_uniform_chains(self.seed, np.arange(self.R) * self.T_global + hot_slot, self.iteration, RNG_SWAP)
+        self.nprop_boundary += self.R
+        if self._th is not None:                             # device-resident state
+            th, lp = self._th, self._lp
+            d = th.shape[2]
+            other = self._swap_with(peer, torch.cat([th[:, mine, :], lp[:, mine, None]], dim=1).contiguous())
+            my_lp, ot_lp = lp[:, mine].clone(), other[:, d]
+            hot_lp, cold_lp = (ot_lp, my_lp) if upper else (my_lp, ot_lp)
+            # ExchangeStep::DoStep (steps.hpp:331-339); both ranks evaluate the same expression on the same bits
+            alpha = torch.exp((cold_lp - hot_lp) / t_hot + (hot_lp - cold_lp) / t_cold).clamp(max=1.0)
+            alpha = torch.where(torch.isfinite(alpha), alpha, torch.zeros_like(alpha))
+            acc = torch.from_numpy(u).to(th.device) < alpha
+            th[:, mine, :] = torch.where(acc[:, None], other[:, :d], th[:, mine, :])
+            lp[:, mine] = torch.where(acc, ot_lp, my_lp)
+            self.nswap_boundary += int(acc.sum())
+            torch.cuda.current_stream(th.device).synchronize()          # the sampler runs on its own stream
+            return
+        th, lp = self.b.pt_get_chains()                      # [R][Tl][d], [R][Tl]
         d = th.shape[2]
         send = torch.from_numpy(np.concatenate([th[:, mine, :], lp[:, mine, None]], axis=1).copy()).to(self.device)
-        recv = torch.empty_like(send)
-        ops = [dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        other = recv.cpu().numpy()
-        hot_slot = self.slot0 + self.T_local if upper else self.slot0          # global slot of the hotter chain
-        t_hot, t_cold = self.temps[hot_slot], self.temps[hot_slot - 1]
+        other = self._swap_with(peer, send).cpu().numpy()
         my_lp, ot_lp = lp[:, mine], other[:, d]
         hot_lp, cold_lp = (ot_lp, my_lp) if upper else (my_lp, ot_lp)
-        # ExchangeStep::DoStep (steps.hpp:331-339)
         with np.errstate(over="ignore", invalid="ignore"):
             alpha = np.minimum(np.exp((cold_lp - hot_lp) / t_hot + (hot_lp - cold_lp) / t_cold), 1.0)
         alpha = np.where(np.isfinite(alpha), alpha, 0.0)
-        u = np.array([philox_uniform(self.seed, r * self.T_global + hot_slot, self.iteration, RNG_SWAP)
-                      for r in range(self.R)])
         acc = u < alpha
         if acc.any():
             th[acc, mine, :] = other[acc, :d]
             lp[acc, mine] = other[acc, d]
             self.b.pt_set_chains(th, lp)
         self.nswap_boundary += int(acc.sum())
-        self.nprop_boundary += self.R
 
     def iterate(self, niter):
         """niter x (local RAM steps + local swap sweep, then alternating even/odd boundary swaps)."""
@@ -150,5 +197,7 @@ class LadderShard(object):
 
     def coldest(self):
         """(theta[R][d], logpost[R]) of temperature 0 -- meaningful on rank 0."""
+        if self._th is not None:
+            return self._th[:, 0, :].cpu().numpy(), self._lp[:, 0].cpu().numpy()
         th, lp = self.b.pt_get_chains()
         return th[:, 0, :], lp[:, 0]

@@ -1,0 +1,95 @@
+"""GPU test of one temperature ladder sharded over ranks (BASELINE config 4's partitioning,
+carma_pack_amd/parallel.py `LadderShard`) with the real sampler behind it.
+
+The GPU box has one device, so both ranks of the world_size-2 group run on cuda:0 and the process
+group is gloo (RCCL refuses two ranks on one device): the chain state stays device-resident and bound
+to the sampler (carma_pt_bind_state), only the R x (d+1) boundary rows are staged for the transport.
+What is pinned: the log-posterior travels with its parameter vector (stored value == a fresh
+evaluation by the CPU oracle, as carma_unit_tests.cpp:783-1114 pins the reference sampler), both
+sides of the boundary take identical decisions, and the device-resident exchange walks the same
+trajectory as the host-mediated one."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P, Q, TG, R, NITER, SEED = 3, 1, 5, 6, 40, 4242
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _series():
+    rng = np.random.default_rng(11)
+    n = 80
+    t = np.cumsum(rng.uniform(1.0, 3.0, n))
+    y = np.cumsum(rng.standard_normal(n)) * 0.3 + 0.2 * rng.standard_normal(n)
+    return t, y - y.mean(), np.full(n, 0.2)
+
+
+def _worker(rank, world, port, q, resident):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import carma_pack_amd as cpa
+        from carma_pack_amd import parallel as par
+        t, y, e = _series()
+        ctx = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std())
+        sh = par.LadderShard(ctx, TG, R, adapt_iters=NITER, seed=SEED, dist=dist, device="cuda:0" if resident else "cpu")
+        assert (sh._th is not None) == resident
+        sh.start()
+        sh.iterate(NITER)
+        th, lp = ctx.pt_get_chains()
+        if resident:
+            assert np.array_equal(th, sh._th.cpu().numpy()) and np.array_equal(lp, sh._lp.cpu().numpy())
+        q.put((rank, sh.nswap_boundary, sh.nprop_boundary, sh.slot0, th, lp))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(resident):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, resident)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_ladder_sharded_over_two_ranks():
+    import oracle as orc
+    res = _run(resident=True)
+    (r0, sw0, pr0, s0, th0, lp0), (r1, sw1, pr1, s1, th1, lp1) = res
+    assert (s0, th0.shape[1], s1, th1.shape[1]) == (0, 3, 3, 2)
+    assert sw0 == sw1 and pr0 == pr1 == R * (NITER // 2)          # the single boundary is even: active every other iteration
+    assert 0 < sw0 < pr0
+    # stored log-posterior == LogDensity(theta) for every chain on both ranks, swapped ones included
+    t, y, e = _series()
+    ms = 10.0 * y.std()
+    th = np.concatenate([th0, th1], axis=1).reshape(-1, 3 + P + Q)
+    lp = np.concatenate([lp0, lp1], axis=1).ravel()
+    assert np.all(np.isfinite(lp))
+    from helpers import assert_parity
+    from mp_truth import loglik_truth
+    m = orc.OracleModel(t, y, e, P, Q, max_stdev=ms)
+    assert_parity(lp, m.logdensity_batch(th), 1e-10, "sharded chain states",
+                  arbiter=lambda i: loglik_truth(t, y, e, th[i], P, Q)[0])
+    # the host-mediated exchange (state copied out and back every boundary) walks the same trajectory
+    host = _run(resident=False)
+    for a, b in zip(res, host):
+        assert a[1] == b[1] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
