@@ -46,12 +46,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hook for a one-GPU box: CARMA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and moves the barrier /
+    # max-time reduction to gloo (RCCL refuses two ranks on one device).  The driver never sets it.
+    share = os.environ.get("CARMA_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import carma_pack_amd as cpa
     from carma_pack_amd.synth import theta_batch
@@ -61,7 +68,7 @@ def main():
     p, q = 5, 3
     n, d, B = t.size, 3 + p + q, args.batch
     max_stdev = 10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)      # src/carmcmc.cpp:85-89
-    ctx = cpa.Context(t, y, yerr, p, q, max_stdev=max_stdev, device=local_rank)
+    ctx = cpa.Context(t, y, yerr, p, q, max_stdev=max_stdev, device=dev_index)
 
     # synthetic parameter vectors: posterior-like + prior-like, 8 distinct
     # batches per rank so consecutive steps never see the same input.

@@ -1,0 +1,57 @@
+"""The bench.py contract on the GPU box: one JSON line with the required keys at N=1, and the N>1 launch
+path (torch.distributed.run, one rank per process, barrier + max-over-ranks) exercised with two ranks
+sharing cuda:0 (CARMA_BENCH_SHARE_GPU=1: gloo for the barrier, since RCCL refuses two ranks on one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5", "--mcmc-iters", "200",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert KEYS | {"cpu_baseline"} <= set(j)
+    assert j["n_gpus"] == 1 and j["steps"] == 50 and j["unit"] == "evals/s" and j["dtype"] == "f64"
+    assert j["finite_in_last_batch"] == 1024 and j["value"] > 1e6           # north_star target on one GPU
+    rf, cb = j["roofline"], j["cpu_baseline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 1024) < 1e-6 * 1024
+
+
+def test_two_ranks_sharing_the_gpu():
+    env = dict(os.environ, CARMA_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "50", "--warmup", "5", "--mcmc-iters", "200"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert KEYS <= set(j) and "cpu_baseline" not in j                      # CPU leg runs on rank 0 at N=1 only
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["finite_in_last_batch"] == 1024
+    assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 2 * 1024) < 1e-6 * 2048          # whole-job aggregate
