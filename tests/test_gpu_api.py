@@ -149,3 +149,44 @@ def test_carma_model_mcmc_and_mle(cm, golden_dir):
     best, pqlist, aicc = model.choose_order(2, ntrials=4, seed=7)
     assert pqlist == [(1, 0), (2, 0), (2, 1)] and len(aicc) == 3 and (model.p, model.q) in pqlist
     sample.add_mle(mle) if sample.p == 2 else None
+
+
+def test_simulate_is_a_draw_from_the_dense_gp_conditional(cm, golden_dir):
+    """KalmanFilter::Simulate pinned the way carma_unit_tests.cpp:651-781 pins it: the simulated path,
+    whitened by the conditional mean / covariance of the dense Gaussian process given the data, is
+    standard normal white noise (Anderson-Darling < 3.857, ACF inside the 95 % band)."""
+    import os
+    import oracle as orc
+    from scipy.stats import norm
+    g = np.load(os.path.join(golden_dir, "cpp_carma_test300.npz"))
+    t, y, e = g["t"][:120], g["y"][:120], g["yerr"][:120]
+    roots, ma, sigsqr = g["omega"], g["ma"], float(g["sigsqr"])
+    om = cm.vecC()
+    for r in roots:
+        om.append(complex(r))
+    kf = cm.KalmanFilterp(cm.vecD(t.tolist()), cm.vecD(y.tolist()), cm.vecD(e.tolist()), sigsqr, om, cm.vecD(ma.tolist()))
+    span = t[-1] - t[0]
+    nsim = 80
+    tsim = np.linspace(t[0] - 0.05 * span, t[-1] + 0.05 * span, nsim)
+    np.random.seed(123)                                                   # Simulate draws from numpy's global stream
+    ysim = np.array(kf.Simulate(cm.vecD(tsim.tolist())))
+    assert ysim.shape == (nsim,) and np.all(np.isfinite(ysim))
+    # dense GP conditional of the simulated epochs given the data
+    tc = np.concatenate([tsim, t])
+    lags, inv = np.unique(np.abs(tc[:, None] - tc[None, :]).ravel(), return_inverse=True)
+    acv = np.array([orc.variance(roots, ma, np.sqrt(sigsqr), float(dt)) for dt in lags])
+    cov = acv[inv].reshape(tc.size, tc.size)
+    cov[np.arange(nsim, tc.size), np.arange(nsim, tc.size)] += e * e
+    Kdd, Ksd, Kss = cov[nsim:, nsim:], cov[:nsim, nsim:], cov[:nsim, :nsim]
+    sol = np.linalg.solve(Kdd, np.c_[y, Ksd.T])
+    cmean, cvar = Ksd @ sol[:, 0], Kss - Ksd @ sol[:, 1:]
+    L = np.linalg.cholesky(0.5 * (cvar + cvar.T))
+    z = np.linalg.solve(L, ysim - cmean)
+    cdf = norm.cdf(np.sort(z))
+    i = np.arange(1, nsim + 1)
+    ad = -nsim - np.sum((2.0 * i - 1.0) / nsim * (np.log(cdf) + np.log(1.0 - cdf[::-1])))
+    assert ad < 3.857, ad                                                  # 1 % critical value (cpp:756)
+    zc = z - z.mean()
+    maxlag = 30
+    acf = np.array([np.sum(zc[k:] * zc[:nsim - k]) for k in range(1, maxlag + 1)]) / np.sum(zc * zc)
+    assert np.sum(np.abs(acf) > 1.96 / np.sqrt(nsim)) <= 5, acf            # binomial(30, 0.05): P(>5) < 1 %
