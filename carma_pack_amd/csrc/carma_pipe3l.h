@@ -1,0 +1,307 @@
+// carma_pipe3l.h -- the wave pipeline of carma_pipe3.h in a CO-ROTATING FRAME (gfx950 only).
+//
+// The step of the covariance wave is  D <- Phi_k (D - k k^T / var) Phi_k^T  (kfilter.cpp:197, 204) with Phi_k the
+// block-diagonal rotation exp(omega dt_k) of the real modal coordinates; 24 of its 56 issue slots (p = 5) are that
+// rotation.  Write D = A S A^T with A the transition accumulated since the last RE-BASE (all Phi commute):
+//     w~ = S h~ ,  h~ = A^T h        var = s0 + e + h~.w~        k~ = w~ + c~ ,  c~ = A^-1 c
+//     S <- S - k~ k~^T / var         and for the mean  z = A z~ :  innov = y - mu - h~.z~ ,  z~ <- z~ + k~ innov / var
+// -- no rotation of the matrix at all; the per-step vectors h~, c~ depend only on omega and on the time since the
+// re-base and are computed by the PRODUCER waves (two of them: the covariance wave got 1.6x faster).  Element by
+// element the arithmetic is the same as the rotated recursion up to the scale factors e^{+-Re(omega) dt}, which
+// cancel in every product (numpy prototype tests/tools/proto/lazy_frame.py: same error against the CPU oracle as the
+// stepwise rotation, 1e-12 at worst over the bench batch).
+// RE-BASE: before |Re omega| dt_acc could overflow the scale factors or |Im omega| dt_acc cost angle accuracy the
+// accumulated rotation is applied for real (S <- A S A^T, z <- A z~; the column/row mix of carma_pipe3.h) and the
+// frame restarts at the identity.  The schedule is a time grid per evaluation: datum j is a re-base datum when
+// floor(t_j 2^ex) != floor(t_{j-1} 2^ex), 2^-ex <= min over the roots of (LIM_RE / |Re omega|, LIM_IM / |Im omega|);
+// the accumulated time of a non-re-base datum is therefore < 2^-ex.  (Dyadic cells nest: the waves branch on the
+// union of the four evaluations' masks -- that of the finest grid -- and a row without a re-base of its own at such a
+// datum rotates by the identity, so an evaluation's result does not depend on its neighbours in the batch.)  A
+// re-base datum's ring entry holds the accumulated (E cos, E sin) instead of (h~, c~) -- there h~ = h, c~ = c --
+// and a 16-bit mask per chunk tells the recursion waves which data those are.  Chunk 0 is all re-base data (= the stepwise
+// recursion): the producers do not know h and c before the covariance wave has published them (barrier 0).
+//
+//   waves P0, P1 (producers)   ring entry per (datum, evaluation, root), records
+//   wave A (covariance)        [re-base]; w~, var, k~ -> link ring; S -= k~ k~^T / var          (lane r = row r of S)
+//   wave B (mean)              [re-base]; innov, chi2, sum log var; z~ += k~ innov / var        -> log-likelihood
+// Barrier protocol as in carma_pipe3.h: after barrier b the producers write chunk b+1, A works on chunk b, B on b-1.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "carma_pipe3.h"
+
+namespace carma {
+
+template <int P>
+struct Pipe3LGeom {
+    static constexpr int C = 16, SLOT = 64;
+    static constexpr int RING_OFF = 0;                          // double2[3][C][SLOT]
+    static constexpr int LINK_OFF = 3 * C * SLOT;               // double2 {k~_r, var}[2][C][SLOT]
+    static constexpr int REC_OFF = LINK_OFF + 2 * C * SLOT;     // double2 {y, +-yerr^2}[3][C]
+    static constexpr int CONST_OFF = REC_OFF + 3 * C;           // double2 {h_r, c_r}[SLOT]
+    static constexpr int FLAG_OFF = CONST_OFF + SLOT;           // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
+    static constexpr int ENTRIES = FLAG_OFF + 2;
+    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 81.8 KiB
+    static constexpr double LIM_RE = 200.0;                     // |Re omega| dt_acc: scale factors within e^+-200 (squares e^+-400)
+    static constexpr double LIM_IM = 256.0;                     // |Im omega| dt_acc: the phase product rounds to 3e-14 rad at most,
+                                                                // what the stepwise products accumulate over such a window anyway
+};
+
+// DPP move of a double with an explicit `old` value for the lanes the pattern leaves unwritten
+template <int CTRL>
+CARMA_DEV double dpp_mov_old(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// waves P0 / P1 (pw = 0, 1)
+template <int P>
+__device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
+                                               const double4* __restrict__ series, int n, Cx* __restrict__ ring)
+{
+    using Geo = Pipe3LGeom<P>;
+    constexpr int C = Geo::C;
+    constexpr int PPL = 16 / P;
+    const int lane = g.lane64, l = lane & 15;
+    const int sub = l / P, jr = l - sub * P;
+    const bool worker = sub < PPL;
+    const Cx w = own_ar_root<P>(theta, jr);
+    const int nc = (n + C - 1) / C;
+    double2* recs = reinterpret_cast<double2*>(ring + Geo::REC_OFF);
+    if (pw == 0 && l >= P) {
+#pragma unroll 4
+        for (int i = 0; i < 3 * C; i++) ring[(size_t)i * Geo::SLOT + lane] = Cx{0.0, 0.0};
+    }
+    // grid of this evaluation's re-base schedule: cells of width 2^-ex <= min over its roots of (LIM_RE / |Re omega|,
+    // LIM_IM / |Im omega|).  Dyadic widths nest, so the re-base data of the evaluation with the finest grid contain
+    // those of the other three evaluations of the workgroup and the waves branch on that one mask.
+    double wl = fmax(fabs(w.re) * (1.0 / Geo::LIM_RE), fabs(w.im) * (1.0 / Geo::LIM_IM));
+    wl = (wl < 1e12) ? wl : ((wl == wl && wl < 1.0 / 0.0) ? 1e12 : 0.0);
+    wl = Grp<16>::max(wl);
+    int wex;
+    (void)frexp(wl, &wex);
+    const double sc = wl > 0.0 ? ldexp(1.0, wex) : 0.0;
+    const double ninf = -1.0 / 0.0;
+    auto clampi = [n](int i) { return i < n ? (i < 0 ? 0 : i) : n - 1; };
+    double4 rec_n = series[clampi(l)];                       // records are fetched one chunk ahead
+    double carry = __shfl(rec_n.w, 0, 64);                   // time of the current base datum
+    double t_last = carry;                                   // time of the datum before this chunk
+    double2 hc_own = make_double2(0.0, 0.0), hc_par = make_double2(0.0, 0.0);
+    for (int c = 0; c < nc; c++) {
+        const int j0 = c * C;
+        // --- schedule of this chunk: lane s (of every row) looks at datum j0 + s
+#ifdef CARMA_DBG
+        const long long dbg_t0 = clock64();
+#endif
+        const double4 rec = rec_n;
+        rec_n = series[clampi(j0 + C + l)];
+        const double tj = rec.w, tjm = dpp_mov_old<0x111>(t_last, tj);      // row_shr:1, lane 0 <- last datum of the previous chunk
+        t_last = __shfl(tj, 15, 64);
+        const bool fl = (c == 0) || (floor(tj * sc) != floor(tjm * sc));
+        double M = fl ? tj : ninf;                            // inclusive max-scan over the 16 lanes: latest re-base time
+        M = fmax(M, dpp_mov_old<0x111>(ninf, M));      // row_shr:1
+        M = fmax(M, dpp_mov_old<0x112>(ninf, M));      // row_shr:2
+        M = fmax(M, dpp_mov_old<0x114>(ninf, M));      // row_shr:4
+        M = fmax(M, dpp_mov_old<0x118>(ninf, M));      // row_shr:8
+        const double Mx = dpp_mov_old<0x111>(ninf, M);          // exclusive
+        const double dta_l = tj - fmax(carry, Mx);           // time since the base this datum is expressed in
+        carry = fmax(carry, __shfl(M, (lane & ~15) + 15, 64));
+        const unsigned long long fmask = __ballot(fl && j0 + l < n);      // bit 16 row + s: datum j0 + s of that row's evaluation
+        if (pw == 0 && lane < C && j0 + lane < n) recs[(c % 3) * C + lane] = make_double2(rec.y, rec.z);
+        if (pw == 0 && lane == 0) reinterpret_cast<unsigned long long*>(ring + Geo::FLAG_OFF)[c % 3] = fmask;
+        if (c == 1) {                                         // published by the covariance wave before barrier 0
+            const double2* cst = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF) + (lane & ~15);
+            hc_own = cst[jr];
+            hc_par = cst[jr ^ 1];
+        }
+        Cx* buf = ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT + (lane & ~15) + jr;
+#pragma unroll 1
+        for (int s0 = 0; s0 < C; s0 += 2 * PPL) {
+            const int slot = s0 + pw * PPL + sub;
+            const int src = slot < C ? slot : C - 1;
+            const double dta = __shfl(dta_l, (lane & ~15) + src, 64);
+            const bool flag = __shfl((int)fl, (lane & ~15) + src, 64) != 0;
+            if (worker && slot < C && j0 + slot < n) {
+                double ec, es;
+                cexp_step(w.re, w.im, dta, &ec, &es);
+                // h~_r = (A^T h)_r = E (cos h_r + sin h_partner) ;  c~_r = (A^-1 c)_r = (cos c_r + sin c_partner) / E
+                const double inv = recip(fma(ec, ec, es * es));
+                const double ht = fma(ec, hc_own.x, es * hc_par.x);
+                const double ct = fma(ec, hc_own.y, es * hc_par.y) * inv;
+                buf[(size_t)slot * Geo::SLOT] = flag ? Cx{ec, es} : Cx{ht, ct};
+            }
+        }
+#ifdef CARMA_DBG
+        if (blockIdx.x == 0 && lane == 0 && (c == 3 || c == 4)) printf("P%d chunk %d work %lld cycles\n", pw, c, clock64() - dbg_t0);
+#endif
+        __syncthreads();                                      // barrier c: chunk c is in the ring
+    }
+    __syncthreads();                                          // barrier nc (wave B's last chunk)
+}
+
+// wave A: lane r of a 16-lane row holds row r of S.  (The split rows of carma_pipe3.h paid for the per-entry work of
+// the rotation; here the rotation is the exception and the row sum w~ = S h~ wants the whole row in one lane.)
+// The step is a dependent chain  w~ -> t -> var -> 1/var -> S -> w~ ...; the row sums run as two accumulation chains
+// and the reciprocal refinement is folded into the gain so that the chain, not the issue rate, stays short.
+template <int P>
+__device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc, int n,
+                                           Cx* __restrict__ ring)
+{
+    using Geo = Pipe3LGeom<P>;
+    using RA = RowAsm<P>;
+    constexpr int C = Geo::C;
+    const int lane = g.lane64;
+    const int nc = (n + C - 1) / C;
+    const bool act = (lane & 15) < P;
+    const double h_row = act ? rc.h_own : 0.0, c_row = act ? rc.c_own : 0.0;     // idle lanes carry exact zeros
+    reinterpret_cast<double2*>(ring + Geo::CONST_OFF)[lane] = make_double2(h_row, c_row);
+    const double one = 1.0;
+    double S[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) S[j] = 0.0;
+    const double2* ring_b = nullptr;
+    const double2* rec_b = nullptr;
+    double2* link_b = nullptr;
+    double2 hc_n = make_double2(0.0, 0.0), rec_n = make_double2(0.0, 0.0);
+    unsigned rowm = 0;
+    auto pass = [&](const int s, const bool more, const bool rebase) __attribute__((always_inline)) {
+        const double2 hc = hc_n, rec = rec_n;
+        if (more) {
+            hc_n = ring_b[(size_t)(s + 1) * Geo::SLOT];
+            rec_n = rec_b[s + 1];
+        }
+        double ht = hc.x, ct = hc.y;
+        if (rebase) {
+            // S <- A S A^T with the accumulated rotation (kfilter.cpp:204 for the whole window); a row whose own
+            // schedule has no re-base here rotates by the identity and keeps its (h~, c~)
+            const bool mine = (rowm >> s) & 1u;
+            const double rc_ = mine ? hc.x : 1.0, rs_ = mine ? hc.y : 0.0;
+            double mm[P];
+            g.template row_colmix<P>(mm, rc_, rs_, S);
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                const double mp = g.partner(mm[j]);
+                S[j] = fma(rc_, mm[j], -(rs_ * mp));
+            }
+            ht = mine ? h_row : hc.x;
+            ct = mine ? c_row : hc.y;
+        }
+        // w~ = S h~ ; var_j = s0 + e + h~.w~ (kfilter.cpp:180-182, 209-210) ; k~ = w~ + c~
+        double w, var, k;
+        RA::lazy_front(w, var, k, ht, ct, rec.y, m.scale, rc.s0, one, S);
+        link_b[(size_t)s * Geo::SLOT] = make_double2(k, var);
+        // S_j -= (k~ / var) k~_j   (kfilter.cpp:197);  1/var = r0 (1 + e + e^2), e = 1 - var r0, folded into nt = -k~ / var
+        const double r0 = __builtin_amdgcn_rcp(var);
+        const double kr = -k * r0;
+        const double er = fma(-var, r0, 1.0);
+        const double e2 = fma(er, er, er);
+        const double nt = fma(kr, e2, kr);
+        RA::gain_nt(S, k, nt);
+    };
+    const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
+    for (int c = 0; c < nc; c++) {
+        __syncthreads();                                      // barrier c
+        ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + lane;
+        rec_b = reinterpret_cast<const double2*>(ring + Geo::REC_OFF) + (c % 3) * C;
+        link_b = reinterpret_cast<double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + lane;
+        hc_n = ring_b[0];
+        rec_n = rec_b[0];
+        const unsigned long long fm64 = flag_b[c % 3];
+        rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
+        const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
+        const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
+#ifdef CARMA_DBG
+        const long long dbg_t0 = clock64();
+#endif
+        const int len = (n - c * C < C) ? n - c * C : C;
+        if (len == C) {
+#pragma unroll
+            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u);
+        }
+#ifdef CARMA_DBG
+        if (blockIdx.x == 0 && lane == 0 && (c == 3 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "A", c, clock64() - dbg_t0, fm);
+#endif
+    }
+    __syncthreads();                                          // barrier nc
+}
+
+// wave B
+template <int P>
+__device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc, int n,
+                                              const Cx* __restrict__ ring)
+{
+    using Geo = Pipe3LGeom<P>;
+    using RA = RowAsm<P>;
+    constexpr int C = Geo::C;
+    const int lane = g.lane64;
+    const int nc = (n + C - 1) / C;
+    const double one = 1.0;
+    double z = 0.0;
+    LogLikAcc acc;
+    acc.init();
+    const double2* ring_b = nullptr;
+    const double2* rec_b = nullptr;
+    const double2* link_b = nullptr;
+    double2 hc_n = make_double2(0.0, 0.0), rec_n = make_double2(0.0, 0.0), lk_n = make_double2(0.0, 1.0);
+    unsigned rowm = 0;
+    auto pass = [&](const int s, const bool more, const bool rebase) __attribute__((always_inline)) {
+        const double2 hc = hc_n, rec = rec_n, lk = lk_n;      // lk = {k~_r, var_j}
+        if (more) {
+            hc_n = ring_b[(size_t)(s + 1) * Geo::SLOT];
+            rec_n = rec_b[s + 1];
+            lk_n = link_b[(size_t)(s + 1) * Geo::SLOT];
+        }
+        double ht = hc.x;
+        if (rebase) {                                         // z <- A z~ (kfilter.cpp:200-201 for the whole window)
+            const bool mine = (rowm >> s) & 1u;
+            const double rc_ = mine ? hc.x : 1.0, rs_ = mine ? hc.y : 0.0;
+            const double zp = g.partner(z);
+            z = fma(rc_, z, -(rs_ * zp));
+            ht = mine ? rc.h_own : hc.x;
+        }
+        // innov_j = (y - mu) - h~.z~   (kfilter.cpp:184, 207, 213); log-likelihood terms (carpack.hpp:167-171)
+        double innov;
+        RA::innov_t2(innov, rec.x, m.mu, z, ht, one);
+        acc.add_var(lk.y);
+        const double si = recip(lk.y) * innov;
+        acc.chi2 += innov * si;
+        z = fma(lk.x, si, z);                                 // z~ += k~ innov / var (kfilter.cpp:191-194)
+    };
+    const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
+    __syncthreads();                                          // barrier 0
+    for (int c = 0; c < nc; c++) {
+        __syncthreads();                                      // barrier c + 1: wave A has finished chunk c
+        ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + lane;
+        rec_b = reinterpret_cast<const double2*>(ring + Geo::REC_OFF) + (c % 3) * C;
+        link_b = reinterpret_cast<const double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + lane;
+        hc_n = ring_b[0];
+        rec_n = rec_b[0];
+        lk_n = link_b[0];
+        const unsigned long long fm64 = flag_b[c % 3];
+        rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
+        const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
+        const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
+#ifdef CARMA_DBG
+        const long long dbg_t0 = clock64();
+#endif
+        const int len = (n - c * C < C) ? n - c * C : C;
+        if (len == C) {
+#pragma unroll
+            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u);
+        }
+#ifdef CARMA_DBG
+        if (blockIdx.x == 0 && lane == 0 && (c == 3 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "B", c, clock64() - dbg_t0, fm);
+#endif
+    }
+    return acc.total();
+}
+
+}  // namespace carma

@@ -137,6 +137,84 @@ def block_colmix_split(P):
     return no_adjacent_same_dst(lines), outs, ins
 
 
+# ---- co-rotating frame (carma_pipe3l.h): no rotation of the matrix per step; the per-step vectors ht = A^T h and
+# ct = A^-1 c come from the producer waves.
+def block_wsum_split(P):
+    # operands: 0 wp0 (half A partial), 1 wp1 (half B partial) | 2 ht, 3.. S_slot
+    # two accumulators, one per half, so that consecutive instructions never share a destination
+    half, slot, ns = split_map(P)
+    lines = ["v_mov_b64 %0, 0", "v_mov_b64 %1, 0"]
+    order = sorted(range(P), key=lambda j: (slot[j], half[j]))
+    for j in order:
+        lines.append("v_fmac_f64_dpp %%%d, %%2, %%%d row_newbcast:%d row_mask:0xf bank_mask:%s" % (half[j], 3 + slot[j], j, BANK[half[j]]))
+    outs = '"=&v"(wp0), "=&v"(wp1)'
+    ins = '"v"(ht), ' + ", ".join('"v"(S[%d])' % i for i in range(ns))
+    return no_adjacent_same_dst(lines), outs, ins
+
+
+def block_sums_t(P):
+    # operands: 0 var, 1 k, 2 t | 3 e, 4 scale, 5 s0, 6 w, 7 ct, 8 ht, 9 one
+    # t = ht w ; var = |e| scale + s0 + sum_j t@j ; k = w + ct   (the sign of e carries the re-base flag)
+    lines = ["v_mul_f64 %2, %8, %6", "v_fma_f64 %0, |%3|, %4, %5", "v_add_f64 %1, %6, %7"]
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %0, %2, %9" + DPP % j)
+    outs = '"=&v"(var), "=&v"(k), "=&v"(t)'
+    ins = '"v"(e), "v"(scale), "v"(s0), "v"(w), "v"(ct), "v"(ht), "v"(one)'
+    return lines, outs, ins
+
+
+def block_innov_t(P):
+    # operands: 0 innov, 1 t | 2 y, 3 mu, 4 z, 5 ht, 6 one :  t = ht z ; innov = y - mu - sum_j t@j
+    lines = ["v_mul_f64 %1, %5, %4", "v_add_f64 %0, %2, -%3", "s_nop 0"]
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %0, -%1, %6" + DPP % j)
+    outs = '"=&v"(innov), "=&v"(t)'
+    ins = '"v"(y), "v"(mu), "v"(z), "v"(ht), "v"(one)'
+    return lines, outs, ins
+
+
+def block_lazy_front(P):
+    # one evaluation per row, lane r holds row r of S (no split).  operands:
+    #   0 w, 1 var, 2 k, 3 t, 4 a0, 5 a1 | 6 ht, 7 ct, 8 e, 9 scale, 10 s0, 11 one, 12.. S_j
+    # w = sum_j S_j ht@j (two chains) ; t = ht w ; k = w + ct ; var = |e| scale + s0 + sum_j t@j (two chains)
+    lines = ["v_mov_b64 %4, 0", "v_mov_b64 %5, 0"]
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %%%d, %%6, %%%d" % (4 + (j & 1), 12 + j) + DPP % j)
+    lines.append("v_fma_f64 %1, |%8|, %9, %10")
+    lines.append("v_add_f64 %0, %4, %5")
+    lines.append("v_mov_b64 %5, 0")
+    lines.append("v_mul_f64 %3, %6, %0")
+    lines.append("v_add_f64 %2, %0, %7")
+    lines.append("s_nop 0")
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %%%d, %%3, %%11" % (1 if (j & 1) == 0 else 5) + DPP % j)
+    lines.append("v_add_f64 %1, %1, %5")
+    outs = '"=&v"(w), "=&v"(var), "=&v"(k), "=&v"(t), "=&v"(a0), "=&v"(a1)'
+    ins = '"v"(ht), "v"(ct), "v"(e), "v"(scale), "v"(s0), "v"(one), ' + ", ".join('"v"(S[%d])' % j for j in range(P))
+    return lines, outs, ins
+
+
+def block_gain_nt(P):
+    # operands: 0..P-1 S_j | k, nt :  S_j += k@j nt
+    lines = []
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %%%d, %%%d, %%%d" % (j, P, P + 1) + DPP % j)
+    outs = ", ".join('"+v"(S[%d])' % j for j in range(P))
+    ins = '"v"(k), "v"(nt)'
+    return lines, outs, ins
+
+
+def block_innov_t2(P):
+    # operands: 0 innov, 1 t, 2 a1 | 3 y, 4 mu, 5 z, 6 ht, 7 one :  t = ht z ; innov = y - mu - sum_j t@j (two chains)
+    lines = ["v_mul_f64 %1, %6, %5", "v_add_f64 %0, %3, -%4", "v_mov_b64 %2, 0"]
+    for j in range(P):
+        lines.append("v_fmac_f64_dpp %%%d, -%%1, %%7" % (0 if (j & 1) == 0 else 2) + DPP % j)
+    lines.append("v_add_f64 %0, %0, %2")
+    outs = '"=&v"(innov), "=&v"(t), "=&v"(a1)'
+    ins = '"v"(y), "v"(mu), "v"(z), "v"(ht), "v"(one)'
+    return lines, outs, ins
+
+
 def emit(lines, outs, ins):
     body = "\n".join('            "%s\\n\\t"' % l for l in lines[:-1]) + '\n            "%s"' % lines[-1]
     return "        asm volatile(\n%s\n            : %s\n            : %s);\n" % (body, outs, ins)
@@ -199,6 +277,47 @@ for P in range(2, 8):
     l, o, i = block_colmix_split(P)
     out.append('    static __device__ __forceinline__ void colmix_split(double (&mm)[%d], double c, double s, const double (&D)[%d])' % (ns, ns))
     out.append('    {')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    l, o, i = block_wsum_split(P)
+    out.append('    // co-rotating frame: partial row sums wp0 (half A) / wp1 (half B) of S ht@column')
+    out.append('    static __device__ __forceinline__ void wsum_split(double& wp0, double& wp1, double ht, const double (&S)[%d])' % ns)
+    out.append('    {')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    l, o, i = block_sums_t(P)
+    out.append('    // t = ht w ;  var = |e| scale + s0 + sum_j t@j ;  k = w + ct')
+    out.append('    static __device__ __forceinline__ void sums_t(double& var, double& k, double& t, double e, double scale, double s0,')
+    out.append('                                                  double w, double ct, double ht, double one)')
+    out.append('    {')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    l, o, i = block_innov_t(P)
+    out.append('    // t = ht z ;  innov = y - mu - sum_j t@j')
+    out.append('    static __device__ __forceinline__ void innov_t(double& innov, double& t, double y, double mu, double z, double ht,')
+    out.append('                                                   double one)')
+    out.append('    {')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    l, o, i = block_lazy_front(P)
+    out.append('    // co-rotating frame, whole rows: w = sum_j S_j ht@j ; t = ht w ; k = w + ct ; var = |e| scale + s0 + sum_j t@j')
+    out.append('    static __device__ __forceinline__ void lazy_front(double& w, double& var, double& k, double ht, double ct, double e,')
+    out.append('                                                      double scale, double s0, double one, const double (&S)[%d])' % P)
+    out.append('    {')
+    out.append('        double t, a0, a1;')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    l, o, i = block_gain_nt(P)
+    out.append('    // S_j += k@j nt')
+    out.append('    static __device__ __forceinline__ void gain_nt(double (&S)[%d], double k, double nt)' % P)
+    out.append('    {')
+    out.append(emit(l, o, i).rstrip("\n"))
+    out.append('    }')
+    l, o, i = block_innov_t2(P)
+    out.append('    // t = ht z ;  innov = y - mu - sum_j t@j   (two accumulation chains)')
+    out.append('    static __device__ __forceinline__ void innov_t2(double& innov, double y, double mu, double z, double ht, double one)')
+    out.append('    {')
+    out.append('        double t, a1;')
     out.append(emit(l, o, i).rstrip("\n"))
     out.append('    }')
     out.append('};')
