@@ -8,8 +8,8 @@
 // -- no rotation of the matrix at all; the per-step vectors h~, c~ depend only on omega and on the time since the
 // re-base and are computed by the PRODUCER waves (two of them: the covariance wave got 1.6x faster).  Element by
 // element the arithmetic is the same as the rotated recursion up to the scale factors e^{+-Re(omega) dt}, which
-// cancel in every product (numpy prototype tests/tools/proto/lazy_frame.py: same error against the CPU oracle as the
-// stepwise rotation, 1e-12 at worst over the bench batch).
+// cancel in every product (numpy prototype tests/tools/proto/lazy_frame.py: the same error against the reference
+// restatement as the stepwise rotation, 1e-12 at worst over the bench batch).
 // RE-BASE: before |Re omega| dt_acc could overflow the scale factors or |Im omega| dt_acc cost angle accuracy the
 // accumulated rotation is applied for real (S <- A S A^T, z <- A z~; the column/row mix of carma_pipe3.h) and the
 // frame restarts at the identity.  The schedule is a time grid per evaluation: datum j is a re-base datum when
@@ -172,6 +172,7 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
             hc_n = ring_b[(size_t)(s + 1) * Geo::SLOT];
             rec_n = rec_b[s + 1];
         }
+        __builtin_amdgcn_sched_barrier(0);                    // the next pass's entries are requested HERE, a pass ahead
         double ht = hc.x, ct = hc.y;
         if (rebase) {
             // S <- A S A^T with the accumulated rotation (kfilter.cpp:204 for the whole window); a row whose own
@@ -256,6 +257,7 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
             rec_n = rec_b[s + 1];
             lk_n = link_b[(size_t)(s + 1) * Geo::SLOT];
         }
+        __builtin_amdgcn_sched_barrier(0);
         double ht = hc.x;
         if (rebase) {                                         // z <- A z~ (kfilter.cpp:200-201 for the whole window)
             const bool mine = (rowm >> s) & 1u;

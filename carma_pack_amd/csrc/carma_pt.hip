@@ -21,6 +21,7 @@
 #include "carma_pt_row.h"
 #include "carma_ring.h"
 #include "carma_pipe3.h"
+#include "carma_pipe3l.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -227,7 +228,7 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
 // A barrier that does not complete within ~seconds sets abort_flag and the launch ends (reported as an
 // error by the host) instead of hanging the GPU.
 template <int P>
-__global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
+__global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
                                                 const double* __restrict__ temps, double* __restrict__ theta,
                                                 double* __restrict__ logpost, double* __restrict__ chol,
                                                 unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,
@@ -236,11 +237,11 @@ __global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const d
     constexpr int G = 16, CPW = 4;                         // lanes per chain, chains per workgroup
     extern __shared__ double4 smem4[];
     const int tid = threadIdx.x, lane64 = tid & 63;
-    const int wave = tid >> 6;                             // 0: chains + covariance recursion, 1: mean recursion, 2: rho producer
+    const int wave = tid >> 6;                             // 0: chains + covariance recursion, 1: mean recursion, 2, 3: producers
     const bool producer = wave != 0;                        // "not the chain-owning wave"
     const int d = L.d, T = L.T;
-    Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3.h rings
-    double* s_thn = reinterpret_cast<double*>(ring + Pipe3Geom<P>::ENTRIES);  // [CPW][16] proposals
+    Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3l.h rings
+    double* s_thn = reinterpret_cast<double*>(ring + Pipe3LGeom<P>::ENTRIES);  // [CPW][16] proposals
     double* s_ll = s_thn + CPW * PT_DMAX;                  // [CPW] log-density of the proposals (mean wave -> chain wave)
     double* s_lp = s_ll + CPW;                             // [T] the ladder's log-posteriors (exchange)
     double* s_dbeta = s_lp + T;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const d
     const int part = (int)(blockIdx.x % S.wpl);
     const long ch0 = lad * T;                              // first chain of the ladder in the state arrays
 
-    for (int i = tid; i < T; i += 192) {
+    for (int i = tid; i < T; i += 256) {
         s_dbeta[i] = i > 0 ? 1.0 / temps[i] - 1.0 / temps[i - 1] : 0.0;
         s_nswap[i] = 0;
     }
@@ -291,9 +292,9 @@ __global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const d
         CARMA_STAMP(st1);
         __syncthreads();                                   // proposals visible to the producer wave
         CARMA_STAMP(st2);
-        // the three-wave pipeline of carma_pipe3.h on the proposals; the mean wave hands the log-density back
-        if (wave == 2) {
-            pipe3_produce<P>(g, thn_lds, series, L.n, ring);
+        // the wave pipeline of carma_pipe3l.h on the proposals; the mean wave hands the log-density back
+        if (wave >= 2) {
+            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n, ring);
         } else {
             Model<P> m;
             model_from_theta<P, G>(g, thn_lds, L.q, pr, 0, m);
@@ -302,12 +303,9 @@ __global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const d
             RowConsts<P> rc;
             row_consts<P>(g, m, fc, rc);
             if (wave == 0) {
-                if constexpr (RowAsm<P>::NSLOT < P)
-                    pipe3_cov_split<P>(g, m, rc, L.n, ring);
-                else
-                    pipe3_cov<P>(g, m, rc, L.n, ring);
+                pipe3l_cov<P>(g, m, rc, L.n, ring);
             } else {
-                double ll = pipe3_mean<P>(g, m, rc, L.n, ring);
+                double ll = pipe3l_mean<P>(g, m, rc, L.n, ring);
                 ll += log_prior(m.scale, pr.measerr_dof);
                 if (fc.sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const d
                         ch.th = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
-                for (int i = tid; i < T; i += 192) {
+                for (int i = tid; i < T; i += 256) {
                     s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_src[i] = i;
                     RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
@@ -423,13 +421,13 @@ __global__ __launch_bounds__(192) void k_pt_row(PtLaunch L, PtRowSync S, const d
     }
     __syncthreads();
     if (part == 0)
-        for (int i = tid; i < T; i += 192) nswap[ch0 + i] += s_nswap[i];
+        for (int i = tid; i < T; i += 256) nswap[ch0 + i] += s_nswap[i];
 }
 
 static size_t pt_row_lds(int d, int T)
 {
     (void)d;
-    return Pipe3Geom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
+    return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
 }
 
 template <int P>
@@ -478,7 +476,7 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt_row<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(192), lds, st, L, S, series, pr, temps,
+    hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(256), lds, st, L, S, series, pr, temps,
                        theta, logpost, chol, naccept, nswap, samples, sample_lp);
     return hipGetLastError();
 }
