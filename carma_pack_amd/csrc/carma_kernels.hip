@@ -122,8 +122,14 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     long e = ((long)blockIdx.x * 64 + lane64) / 16;
     const bool live = e < B;
     if (!live) e = B - 1;
+#ifdef CARMA_DBG
+    const long long dbg_k0 = clock64();
+#endif
     if (wave >= 2) {
         pipe3l_produce<P>(g, wave - 2, theta + e * d, series, n, ring);
+#ifdef CARMA_DBG
+        if (blockIdx.x == 0 && lane64 == 0) printf("P%d total %lld\n", wave - 2, clock64() - dbg_k0);
+#endif
         return;
     }
     Model<P> m;
@@ -132,11 +138,20 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     filter_reset<P, 16>(g, m, fc);
     RowConsts<P> rc;
     row_consts<P>(g, m, fc, rc);
+#ifdef CARMA_DBG
+    if (blockIdx.x == 0 && lane64 == 0) printf("wave %d setup %lld\n", wave, clock64() - dbg_k0);
+#endif
     if (wave == 0) {
-        pipe3l_cov<P>(g, m, rc, n, ring);
+        pipe3l_cov<P>(g, m, rc, series, n, ring);
+#ifdef CARMA_DBG
+        if (blockIdx.x == 0 && lane64 == 0) printf("A total %lld\n", clock64() - dbg_k0);
+#endif
         return;
     }
-    double ll = pipe3l_mean<P>(g, m, rc, n, ring);
+    double ll = pipe3l_mean<P>(g, m, rc, series, n, ring);
+#ifdef CARMA_DBG
+    if (blockIdx.x == 0 && lane64 == 0) printf("B total %lld\n", clock64() - dbg_k0);
+#endif
     ll += log_prior(m.scale, pr.measerr_dof);
     const double ninf = -1.0 / 0.0;
     if (fc.sing || !m.valid) ll = ninf;

@@ -18,10 +18,12 @@
 // union of the four evaluations' masks -- that of the finest grid -- and a row without a re-base of its own at such a
 // datum rotates by the identity, so an evaluation's result does not depend on its neighbours in the batch.)  A
 // re-base datum's ring entry holds the accumulated (E cos, E sin) instead of (h~, c~) -- there h~ = h, c~ = c --
-// and a 16-bit mask per chunk tells the recursion waves which data those are.  Chunk 0 is all re-base data (= the stepwise
-// recursion): the producers do not know h and c before the covariance wave has published them (barrier 0).
+// and a 16-bit mask per chunk tells the recursion waves which data those are.  The producers need h and c: they
+// evaluate the exp/sincos of chunk 0 while the recursion waves set the model up, wait for the covariance wave to
+// publish (h_r, c_r), and only then form the entries of chunk 0.
 //
-//   waves P0, P1 (producers)   ring entry per (datum, evaluation, root), records
+//   waves P0, P1 (producers)   ring entry per (datum, evaluation, root), re-base masks
+//   (y_j and yerr_j^2 are wave-uniform: the recursion waves read them with scalar loads from the series itself)
 //   wave A (covariance)        [re-base]; w~, var, k~ -> link ring; S -= k~ k~^T / var          (lane r = row r of S)
 //   wave B (mean)              [re-base]; innov, chi2, sum log var; z~ += k~ innov / var        -> log-likelihood
 // Barrier protocol as in carma_pipe3.h: after barrier b the producers write chunk b+1, A works on chunk b, B on b-1.
@@ -37,8 +39,7 @@ struct Pipe3LGeom {
     static constexpr int C = 16, SLOT = 64;
     static constexpr int RING_OFF = 0;                          // double2[3][C][SLOT]
     static constexpr int LINK_OFF = 3 * C * SLOT;               // double2 {k~_r, var}[2][C][SLOT]
-    static constexpr int REC_OFF = LINK_OFF + 2 * C * SLOT;     // double2 {y, +-yerr^2}[3][C]
-    static constexpr int CONST_OFF = REC_OFF + 3 * C;           // double2 {h_r, c_r}[SLOT]
+    static constexpr int CONST_OFF = LINK_OFF + 2 * C * SLOT;   // double2 {h_r, c_r}[SLOT]
     static constexpr int FLAG_OFF = CONST_OFF + SLOT;           // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
     static constexpr int ENTRIES = FLAG_OFF + 2;
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 81.8 KiB
@@ -69,7 +70,6 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     const bool worker = sub < PPL;
     const Cx w = own_ar_root<P>(theta, jr);
     const int nc = (n + C - 1) / C;
-    double2* recs = reinterpret_cast<double2*>(ring + Geo::REC_OFF);
     if (pw == 0 && l >= P) {
 #pragma unroll 4
         for (int i = 0; i < 3 * C; i++) ring[(size_t)i * Geo::SLOT + lane] = Cx{0.0, 0.0};
@@ -89,53 +89,63 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     double carry = __shfl(rec_n.w, 0, 64);                   // time of the current base datum
     double t_last = carry;                                   // time of the datum before this chunk
     double2 hc_own = make_double2(0.0, 0.0), hc_par = make_double2(0.0, 0.0);
+    constexpr int NIT = (C + 2 * PPL - 1) / (2 * PPL);        // exp/sincos evaluations per lane and chunk
+    double ec0[NIT], es0[NIT];                                // chunk 0: evaluated while the other waves set the model up
     for (int c = 0; c < nc; c++) {
         const int j0 = c * C;
         // --- schedule of this chunk: lane s (of every row) looks at datum j0 + s
-#ifdef CARMA_DBG
-        const long long dbg_t0 = clock64();
-#endif
         const double4 rec = rec_n;
         rec_n = series[clampi(j0 + C + l)];
         const double tj = rec.w, tjm = dpp_mov_old<0x111>(t_last, tj);      // row_shr:1, lane 0 <- last datum of the previous chunk
         t_last = __shfl(tj, 15, 64);
-        const bool fl = (c == 0) || (floor(tj * sc) != floor(tjm * sc));
+        const bool fl = floor(tj * sc) != floor(tjm * sc);
         double M = fl ? tj : ninf;                            // inclusive max-scan over the 16 lanes: latest re-base time
-        M = fmax(M, dpp_mov_old<0x111>(ninf, M));      // row_shr:1
-        M = fmax(M, dpp_mov_old<0x112>(ninf, M));      // row_shr:2
-        M = fmax(M, dpp_mov_old<0x114>(ninf, M));      // row_shr:4
-        M = fmax(M, dpp_mov_old<0x118>(ninf, M));      // row_shr:8
-        const double Mx = dpp_mov_old<0x111>(ninf, M);          // exclusive
-        const double dta_l = tj - fmax(carry, Mx);           // time since the base this datum is expressed in
+        M = fmax(M, dpp_mov_old<0x111>(ninf, M));             // row_shr:1
+        M = fmax(M, dpp_mov_old<0x112>(ninf, M));             // row_shr:2
+        M = fmax(M, dpp_mov_old<0x114>(ninf, M));             // row_shr:4
+        M = fmax(M, dpp_mov_old<0x118>(ninf, M));             // row_shr:8
+        const double Mx = dpp_mov_old<0x111>(ninf, M);        // exclusive
+        const double dta_l = tj - fmax(carry, Mx);            // time since the base this datum is expressed in
         carry = fmax(carry, __shfl(M, (lane & ~15) + 15, 64));
         const unsigned long long fmask = __ballot(fl && j0 + l < n);      // bit 16 row + s: datum j0 + s of that row's evaluation
-        if (pw == 0 && lane < C && j0 + lane < n) recs[(c % 3) * C + lane] = make_double2(rec.y, rec.z);
         if (pw == 0 && lane == 0) reinterpret_cast<unsigned long long*>(ring + Geo::FLAG_OFF)[c % 3] = fmask;
-        if (c == 1) {                                         // published by the covariance wave before barrier 0
-            const double2* cst = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF) + (lane & ~15);
-            hc_own = cst[jr];
-            hc_par = cst[jr ^ 1];
-        }
         Cx* buf = ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT + (lane & ~15) + jr;
-#pragma unroll 1
-        for (int s0 = 0; s0 < C; s0 += 2 * PPL) {
-            const int slot = s0 + pw * PPL + sub;
-            const int src = slot < C ? slot : C - 1;
-            const double dta = __shfl(dta_l, (lane & ~15) + src, 64);
-            const bool flag = __shfl((int)fl, (lane & ~15) + src, 64) != 0;
+        auto slot_of = [&](int it) { return it * 2 * PPL + pw * PPL + sub; };
+        auto rotation = [&](int it, double& ec, double& es) {            // accumulated (E cos, E sin) of the lane's slot
+            const int slot = slot_of(it);
+            const double dta = __shfl(dta_l, (lane & ~15) + (slot < C ? slot : C - 1), 64);
+            ec = 1.0;
+            es = 0.0;
+            if (worker && slot < C && j0 + slot < n) cexp_step(w.re, w.im, dta, &ec, &es);
+        };
+        auto entry = [&](int it, double ec, double es) {
+            const int slot = slot_of(it);
+            const bool flag = __shfl((int)fl, (lane & ~15) + (slot < C ? slot : C - 1), 64) != 0;
             if (worker && slot < C && j0 + slot < n) {
-                double ec, es;
-                cexp_step(w.re, w.im, dta, &ec, &es);
                 // h~_r = (A^T h)_r = E (cos h_r + sin h_partner) ;  c~_r = (A^-1 c)_r = (cos c_r + sin c_partner) / E
                 const double inv = recip(fma(ec, ec, es * es));
                 const double ht = fma(ec, hc_own.x, es * hc_par.x);
                 const double ct = fma(ec, hc_own.y, es * hc_par.y) * inv;
                 buf[(size_t)slot * Geo::SLOT] = flag ? Cx{ec, es} : Cx{ht, ct};
             }
+        };
+        if (c == 0) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) rotation(it, ec0[it], es0[it]);
+            __syncthreads();                                  // the covariance wave has published (h_r, c_r)
+            const double2* cst = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF) + (lane & ~15);
+            hc_own = cst[jr];
+            hc_par = cst[jr ^ 1];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) entry(it, ec0[it], es0[it]);
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < NIT; it++) {
+                double ec, es;
+                rotation(it, ec, es);
+                entry(it, ec, es);
+            }
         }
-#ifdef CARMA_DBG
-        if (blockIdx.x == 0 && lane == 0 && (c == 3 || c == 4)) printf("P%d chunk %d work %lld cycles\n", pw, c, clock64() - dbg_t0);
-#endif
         __syncthreads();                                      // barrier c: chunk c is in the ring
     }
     __syncthreads();                                          // barrier nc (wave B's last chunk)
@@ -146,8 +156,8 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
 // The step is a dependent chain  w~ -> t -> var -> 1/var -> S -> w~ ...; the row sums run as two accumulation chains
 // and the reciprocal refinement is folded into the gain so that the chain, not the issue rate, stays short.
 template <int P>
-__device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc, int n,
-                                           Cx* __restrict__ ring)
+__device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc,
+                                           const double4* __restrict__ series, int n, Cx* __restrict__ ring)
 {
     using Geo = Pipe3LGeom<P>;
     using RA = RowAsm<P>;
@@ -157,22 +167,20 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     const bool act = (lane & 15) < P;
     const double h_row = act ? rc.h_own : 0.0, c_row = act ? rc.c_own : 0.0;     // idle lanes carry exact zeros
     reinterpret_cast<double2*>(ring + Geo::CONST_OFF)[lane] = make_double2(h_row, c_row);
+    __syncthreads();                                          // the producers finish chunk 0 with these constants
     const double one = 1.0;
     double S[P];
 #pragma unroll
     for (int j = 0; j < P; j++) S[j] = 0.0;
     const double2* ring_b = nullptr;
-    const double2* rec_b = nullptr;
     double2* link_b = nullptr;
-    double2 hc_n = make_double2(0.0, 0.0), rec_n = make_double2(0.0, 0.0);
+    double2 hc_n = make_double2(0.0, 0.0);
     unsigned rowm = 0;
-    auto pass = [&](const int s, const bool more, const bool rebase) __attribute__((always_inline)) {
-        const double2 hc = hc_n, rec = rec_n;
-        if (more) {
-            hc_n = ring_b[(size_t)(s + 1) * Geo::SLOT];
-            rec_n = rec_b[s + 1];
-        }
-        __builtin_amdgcn_sched_barrier(0);                    // the next pass's entries are requested HERE, a pass ahead
+    int j0 = 0;                                               // first datum of the current chunk
+    auto pass = [&](const int s, const bool more, const bool rebase, const double e) __attribute__((always_inline)) {
+        const double2 hc = hc_n;
+        if (more) hc_n = ring_b[(size_t)(s + 1) * Geo::SLOT];
+        __builtin_amdgcn_sched_barrier(0);                    // the next pass's entry is requested HERE, a pass ahead
         double ht = hc.x, ct = hc.y;
         if (rebase) {
             // S <- A S A^T with the accumulated rotation (kfilter.cpp:204 for the whole window); a row whose own
@@ -191,7 +199,7 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         }
         // w~ = S h~ ; var_j = s0 + e + h~.w~ (kfilter.cpp:180-182, 209-210) ; k~ = w~ + c~
         double w, var, k;
-        RA::lazy_front(w, var, k, ht, ct, rec.y, m.scale, rc.s0, one, S);
+        RA::lazy_front(w, var, k, ht, ct, e, m.scale, rc.s0, one, S);
         link_b[(size_t)s * Geo::SLOT] = make_double2(k, var);
         // S_j -= (k~ / var) k~_j   (kfilter.cpp:197);  1/var = r0 (1 + e + e^2), e = 1 - var r0, folded into nt = -k~ / var
         const double r0 = __builtin_amdgcn_rcp(var);
@@ -205,10 +213,9 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c
         ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + lane;
-        rec_b = reinterpret_cast<const double2*>(ring + Geo::REC_OFF) + (c % 3) * C;
         link_b = reinterpret_cast<double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + lane;
         hc_n = ring_b[0];
-        rec_n = rec_b[0];
+        j0 = c * C;
         const unsigned long long fm64 = flag_b[c % 3];
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
@@ -218,14 +225,19 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
 #endif
         const int len = (n - c * C < C) ? n - c * C : C;
         if (len == C) {
+            // yerr_j^2 is wave-uniform: sixteen scalar loads from the series itself, waited for ONCE (scalar-memory and
+            // LDS returns share a counter, so a scalar load inside the pass would drain the LDS prefetch every step)
+            double ev[C];
 #pragma unroll
-            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u);
+            for (int s = 0; s < C; s++) ev[s] = series[j0 + s].z;
+#pragma unroll
+            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, ev[s]);
         } else {
 #pragma unroll 1
-            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u);
+            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u, series[j0 + s].z);
         }
 #ifdef CARMA_DBG
-        if (blockIdx.x == 0 && lane == 0 && (c == 3 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "A", c, clock64() - dbg_t0, fm);
+        if (blockIdx.x == 0 && lane == 0 && (c <= 1 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "A", c, clock64() - dbg_t0, fm);
 #endif
     }
     __syncthreads();                                          // barrier nc
@@ -233,8 +245,8 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
 
 // wave B
 template <int P>
-__device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc, int n,
-                                              const Cx* __restrict__ ring)
+__device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc,
+                                              const double4* __restrict__ series, int n, const Cx* __restrict__ ring)
 {
     using Geo = Pipe3LGeom<P>;
     using RA = RowAsm<P>;
@@ -246,15 +258,14 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
     LogLikAcc acc;
     acc.init();
     const double2* ring_b = nullptr;
-    const double2* rec_b = nullptr;
     const double2* link_b = nullptr;
-    double2 hc_n = make_double2(0.0, 0.0), rec_n = make_double2(0.0, 0.0), lk_n = make_double2(0.0, 1.0);
+    double2 hc_n = make_double2(0.0, 0.0), lk_n = make_double2(0.0, 1.0);
     unsigned rowm = 0;
-    auto pass = [&](const int s, const bool more, const bool rebase) __attribute__((always_inline)) {
-        const double2 hc = hc_n, rec = rec_n, lk = lk_n;      // lk = {k~_r, var_j}
+    int j0 = 0;
+    auto pass = [&](const int s, const bool more, const bool rebase, const double yj) __attribute__((always_inline)) {
+        const double2 hc = hc_n, lk = lk_n;                   // lk = {k~_r, var_j}
         if (more) {
             hc_n = ring_b[(size_t)(s + 1) * Geo::SLOT];
-            rec_n = rec_b[s + 1];
             lk_n = link_b[(size_t)(s + 1) * Geo::SLOT];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -268,22 +279,22 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
         }
         // innov_j = (y - mu) - h~.z~   (kfilter.cpp:184, 207, 213); log-likelihood terms (carpack.hpp:167-171)
         double innov;
-        RA::innov_t2(innov, rec.x, m.mu, z, ht, one);
+        RA::innov_t2(innov, yj, m.mu, z, ht, one);
         acc.add_var(lk.y);
         const double si = recip(lk.y) * innov;
         acc.chi2 += innov * si;
         z = fma(lk.x, si, z);                                 // z~ += k~ innov / var (kfilter.cpp:191-194)
     };
     const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
+    __syncthreads();                                          // (h_r, c_r) published
     __syncthreads();                                          // barrier 0
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c + 1: wave A has finished chunk c
         ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + lane;
-        rec_b = reinterpret_cast<const double2*>(ring + Geo::REC_OFF) + (c % 3) * C;
         link_b = reinterpret_cast<const double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + lane;
         hc_n = ring_b[0];
-        rec_n = rec_b[0];
         lk_n = link_b[0];
+        j0 = c * C;
         const unsigned long long fm64 = flag_b[c % 3];
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
@@ -293,14 +304,18 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
 #endif
         const int len = (n - c * C < C) ? n - c * C : C;
         if (len == C) {
+            // y_j: scalar loads, as yerr_j^2 in the covariance wave
+            double yv[C];
 #pragma unroll
-            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u);
+            for (int s = 0; s < C; s++) yv[s] = series[j0 + s].y;
+#pragma unroll
+            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, yv[s]);
         } else {
 #pragma unroll 1
-            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u);
+            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u, series[j0 + s].y);
         }
 #ifdef CARMA_DBG
-        if (blockIdx.x == 0 && lane == 0 && (c == 3 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "B", c, clock64() - dbg_t0, fm);
+        if (blockIdx.x == 0 && lane == 0 && (c <= 1 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "B", c, clock64() - dbg_t0, fm);
 #endif
     }
     return acc.total();

@@ -303,9 +303,9 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             RowConsts<P> rc;
             row_consts<P>(g, m, fc, rc);
             if (wave == 0) {
-                pipe3l_cov<P>(g, m, rc, L.n, ring);
+                pipe3l_cov<P>(g, m, rc, series, L.n, ring);
             } else {
-                double ll = pipe3l_mean<P>(g, m, rc, L.n, ring);
+                double ll = pipe3l_mean<P>(g, m, rc, series, L.n, ring);
                 ll += log_prior(m.scale, pr.measerr_dof);
                 if (fc.sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;

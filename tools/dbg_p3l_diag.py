@@ -11,4 +11,4 @@ t, y, yerr = g['t'], g['y'], g['yerr']
 th = theta_batch(np.random.default_rng(2), 4, 5, 3, t, y, theta_center=g['theta'][0])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 ctx = L0.Context(t[:n], y[:n], yerr[:n], 5, 3, max_stdev=10 * y.std())
-print(ctx.logdensity(th, ignore_prior=True))
+ctx.logdensity(th, ignore_prior=True); ctx.logdensity(th, ignore_prior=True); print("---- third"); print(ctx.logdensity(th, ignore_prior=True))

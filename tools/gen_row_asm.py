@@ -175,22 +175,20 @@ def block_innov_t(P):
 
 def block_lazy_front(P):
     # one evaluation per row, lane r holds row r of S (no split).  operands:
-    #   0 w, 1 var, 2 k, 3 t, 4 a0, 5 a1 | 6 ht, 7 ct, 8 e, 9 scale, 10 s0, 11 one, 12.. S_j
-    # w = sum_j S_j ht@j (two chains) ; t = ht w ; k = w + ct ; var = |e| scale + s0 + sum_j t@j (two chains)
-    lines = ["v_mov_b64 %4, 0", "v_mov_b64 %5, 0"]
+    #   0 w, 1 var, 2 k, 3 t | 4 ht, 5 ct, 6 e (wave-uniform, SGPR), 7 scale, 8 s0, 9 one, 10.. S_j
+    # w = sum_j S_j ht@j ; t = ht w ; k = w + ct ; var = |e| scale + s0 + sum_j t@j
+    # Single accumulation chains: the wave is issue bound (tools/ubench/ub7.hip: a dependent v_fmac_f64_dpp costs 8
+    # cycles, an independent one 6), so the second accumulators of a tree would only add their set-up instructions.
+    lines = ["v_mov_b64 %0, 0", "v_fma_f64 %1, |%6|, %7, %8"]
     for j in range(P):
-        lines.append("v_fmac_f64_dpp %%%d, %%6, %%%d" % (4 + (j & 1), 12 + j) + DPP % j)
-    lines.append("v_fma_f64 %1, |%8|, %9, %10")
-    lines.append("v_add_f64 %0, %4, %5")
-    lines.append("v_mov_b64 %5, 0")
-    lines.append("v_mul_f64 %3, %6, %0")
-    lines.append("v_add_f64 %2, %0, %7")
+        lines.append("v_fmac_f64_dpp %%0, %%4, %%%d" % (10 + j) + DPP % j)
+    lines.append("v_mul_f64 %3, %4, %0")
+    lines.append("v_add_f64 %2, %0, %5")
     lines.append("s_nop 0")
     for j in range(P):
-        lines.append("v_fmac_f64_dpp %%%d, %%3, %%11" % (1 if (j & 1) == 0 else 5) + DPP % j)
-    lines.append("v_add_f64 %1, %1, %5")
-    outs = '"=&v"(w), "=&v"(var), "=&v"(k), "=&v"(t), "=&v"(a0), "=&v"(a1)'
-    ins = '"v"(ht), "v"(ct), "v"(e), "v"(scale), "v"(s0), "v"(one), ' + ", ".join('"v"(S[%d])' % j for j in range(P))
+        lines.append("v_fmac_f64_dpp %1, %3, %9" + DPP % j)
+    outs = '"=&v"(w), "=&v"(var), "=&v"(k), "=&v"(t)'
+    ins = '"v"(ht), "v"(ct), "s"(e), "v"(scale), "v"(s0), "v"(one), ' + ", ".join('"v"(S[%d])' % j for j in range(P))
     return lines, outs, ins
 
 
@@ -211,7 +209,7 @@ def block_innov_t2(P):
         lines.append("v_fmac_f64_dpp %%%d, -%%1, %%7" % (0 if (j & 1) == 0 else 2) + DPP % j)
     lines.append("v_add_f64 %0, %0, %2")
     outs = '"=&v"(innov), "=&v"(t), "=&v"(a1)'
-    ins = '"v"(y), "v"(mu), "v"(z), "v"(ht), "v"(one)'
+    ins = '"s"(y), "v"(mu), "v"(z), "v"(ht), "v"(one)'
     return lines, outs, ins
 
 
@@ -304,7 +302,7 @@ for P in range(2, 8):
     out.append('    static __device__ __forceinline__ void lazy_front(double& w, double& var, double& k, double ht, double ct, double e,')
     out.append('                                                      double scale, double s0, double one, const double (&S)[%d])' % P)
     out.append('    {')
-    out.append('        double t, a0, a1;')
+    out.append('        double t;')
     out.append(emit(l, o, i).rstrip("\n"))
     out.append('    }')
     l, o, i = block_gain_nt(P)
