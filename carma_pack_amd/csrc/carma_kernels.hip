@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     const long long dbg_k0 = clock64();
 #endif
     if (wave >= 2) {
-        pipe3l_produce<P>(g, wave - 2, theta + e * d, series, n, ring);
+        pipe3l_produce<P>(g, wave - 2, theta + e * d, series, n, ring, [](int) {});
 #ifdef CARMA_DBG
         if (blockIdx.x == 0 && lane64 == 0) printf("P%d total %lld\n", wave - 2, clock64() - dbg_k0);
 #endif

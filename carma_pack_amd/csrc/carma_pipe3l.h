@@ -58,9 +58,11 @@ CARMA_DEV double dpp_mov_old(double old, double src)
 }
 
 // waves P0 / P1 (pw = 0, 1)
-template <int P>
+// `tail(pw)` runs once all chunks are produced, while the recursion waves work through the last two of them: the
+// sampler kernel draws the next iteration's random numbers there.
+template <int P, class Tail>
 __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
-                                               const double4* __restrict__ series, int n, Cx* __restrict__ ring)
+                                               const double4* __restrict__ series, int n, Cx* __restrict__ ring, Tail&& tail)
 {
     using Geo = Pipe3LGeom<P>;
     constexpr int C = Geo::C;
@@ -148,6 +150,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
         }
         __syncthreads();                                      // barrier c: chunk c is in the ring
     }
+    tail(pw);
     __syncthreads();                                          // barrier nc (wave B's last chunk)
 }
 

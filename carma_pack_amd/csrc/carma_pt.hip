@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
     double* s_logu = s_dbeta + T;
     unsigned* s_nswap = reinterpret_cast<unsigned*>(s_logu + T);
     int* s_src = reinterpret_cast<int*>(s_nswap + T);
-    int* s_flag = s_src + T;                               // [1] abort seen
+    int* s_flag = s_src + T;                               // [1] abort seen (+ pad)
+    double* s_z = reinterpret_cast<double*>(s_flag + 2);   // [64] next iteration's t8 variates, drawn by producer wave 0
+    double* s_lu = s_z + 64;                               // [64] next exchange's log-uniforms (T <= 64), same
     const long lad = blockIdx.x / S.wpl;                   // local replica (ladder) index
     const int part = (int)(blockIdx.x % S.wpl);
     const long ch0 = lad * T;                              // first chain of the ladder in the state arrays
@@ -288,13 +290,23 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
         const uint64_t iter = L.iter0 + (uint64_t)it;
         double znorm2 = 0.0;
         CARMA_STAMP(st0);
-        if (!producer) znorm2 = ram_propose_row(g, ch, d, iter, key, thn_lds);
+        if (!producer) znorm2 = ram_propose_row(g, ch, d, iter, key, thn_lds, it > 0 ? s_z + lane64 : nullptr);
         CARMA_STAMP(st1);
         __syncthreads();                                   // proposals visible to the producer wave
         CARMA_STAMP(st2);
         // the wave pipeline of carma_pipe3l.h on the proposals; the mean wave hands the log-density back
         if (wave >= 2) {
-            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n, ring);
+            // the producers are done two chunks before the recursion waves: the random numbers of the NEXT iteration
+            // (proposal variates, swap uniforms; functions of key and iteration only) are drawn in that time
+            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n, ring, [&](int pw) {
+                if (pw == 0) {
+                    s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
+                } else if (L.do_exchange && T > 1 && T <= 64) {
+                    const int i = lane64 < T ? lane64 : T - 1;
+                    RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
+                    s_lu[lane64] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+                }
+            });
         } else {
             Model<P> m;
             model_from_theta<P, G>(g, thn_lds, L.q, pr, 0, m);
@@ -312,31 +324,35 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             }
         }
         __syncthreads();                                   // log-densities visible to the chain wave
+        const bool exch = L.do_exchange && T > 1;
+        double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
+        double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
         if (wave == 0) {
             const double ll = s_ll[row];
             CARMA_STAMP(st3);
-            if (ram_finish_row(g, ch, d, temperature, iter, L.maxiter, key, ll, znorm2, &lp)) nacc++;
-            CARMA_STAMP(st4);
-        }
-        if (L.do_exchange && T > 1) {
-            // publish this workgroup's chains
-            double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
-            double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
-            // Agent-scope (write-through) stores and loads for the staged values instead of a device-wide
-            // fence: a release/acquire fence at agent scope writes back and invalidates the whole L2 of the
-            // XCD, and with 256 workgroups doing that every iteration the swap cost grew from 4 to 20 us
-            // (the L2-resident series had to be re-fetched each time).  The stores are complete (vmcnt)
-            // before the arrival counter is bumped.
-            if (!producer && active) {
-                if (j < d) __hip_atomic_store(&st_th[(ch0 + c) * d + j], ch.th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (j == 0) __hip_atomic_store(&st_lp[ch0 + c], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double alpha;
+            if (ram_accept_row(ch, temperature, iter, key, ll, &lp, &alpha)) nacc++;
+            if (exch) {
+                // publish this workgroup's chains and ARRIVE at the ladder's rendezvous.  Agent-scope (write-through)
+                // stores and loads for the staged values instead of a device-wide fence: a release/acquire fence at
+                // agent scope writes back and invalidates the whole L2 of the XCD, and with 256 workgroups doing that
+                // every iteration the swap cost grew from 4 to 20 us (the L2-resident series had to be re-fetched each
+                // time).  The stores are complete (vmcnt) before the arrival counter is bumped; both by this wave.
+                if (active) {
+                    if (j < d) __hip_atomic_store(&st_th[(ch0 + c) * d + j], ch.th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (j == 0) __hip_atomic_store(&st_lp[ch0 + c], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                if (tid == 0) __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
+            CARMA_STAMP(st4);
+            // the adaptation of the proposal factor does not touch the state: it runs while the other workgroups arrive
+            ram_adapt_row(g, ch, d, iter, L.maxiter, alpha, znorm2);
             CARMA_STAMP(st5);
+        }
+        if (exch) {
             if (tid == 0) {
-                __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target = (unsigned)S.wpl * (nexch + 1);
                 unsigned spins = 0;
                 while (__hip_atomic_load(&S.counter[lad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -359,8 +375,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
                 if (!producer) {
                     const int i = lane64 < T ? lane64 : T - 1;
                     double lp_i = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
-                    const double logu_i = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+                    const double logu_i = s_lu[lane64];               // drawn by producer wave 1 during the filter
                     int src_i = i;
                     bool sw;
                     exchange_decide_wave(T, lane64, lp_i, s_dbeta[i], logu_i, src_i, &sw);
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             CARMA_STAMP(st7);
 #if defined(CARMA_STAMPS)
             if (blockIdx.x == 0 && tid == 0 && it == L.niter - 1)
-                printf("pt_row stamps (cycles): propose %llu  barrier %llu  model+reset+filter %llu  finish %llu  publish %llu  "
+                printf("pt_row stamps (cycles): propose %llu  barrier %llu  model+reset+filter %llu  accept+publish %llu  adapt %llu  "
                        "rendezvous %llu  decide+gather %llu\n",
                        st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6);
 #endif
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
 static size_t pt_row_lds(int d, int T)
 {
     (void)d;
-    return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16;
+    return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16 + 128 * 8;
 }
 
 template <int P>

@@ -25,11 +25,12 @@ struct RowChain {
 
 // z ~ t_8^d, thn = th + R^T z (steps.cpp:60-73).  Returns |z|^2.  thn is also stored to thn_lds[j] for
 // the model code and the producer wave.
+// `zpre` (may be null): this lane's t8 variate drawn ahead of time by a producer wave (same key, iteration, index)
 __device__ __forceinline__ double ram_propose_row(const Grp<16>& g, RowChain& ch, int d, uint64_t iter, const RngKey& key,
-                                                  double* thn_lds)
+                                                  double* thn_lds, const double* zpre)
 {
     const int j = g.lane();
-    const double zj = rng_student_t8(key, iter, (uint32_t)(j < d ? j : 0));
+    const double zj = zpre ? *zpre : rng_student_t8(key, iter, (uint32_t)(j < d ? j : 0));
     ch.z = j < d ? zj : 0.0;
     double znorm2 = 0.0, acc = 0.0;
     static_for<0, PT_DMAX>([&](auto kc) {
@@ -68,9 +69,9 @@ __device__ __forceinline__ void chol_update_row(const Grp<16>& g, int d, RowChai
     });
 }
 
-// Metropolis accept with the tempered ratio, then the RAM rank-1 update (steps.cpp:36-56, 77-99).
-__device__ __forceinline__ bool ram_finish_row(const Grp<16>& g, RowChain& ch, int d, double temperature, uint64_t iter,
-                                               int maxiter, const RngKey& key, double ll, double znorm2, double* lp)
+// Metropolis accept with the tempered ratio (steps.cpp:36-56); *alpha is the acceptance probability the adaptation uses.
+__device__ __forceinline__ bool ram_accept_row(RowChain& ch, double temperature, uint64_t iter, const RngKey& key, double ll,
+                                               double* lp, double* alpha_out)
 {
     double alpha = (ll - *lp) / temperature;
     bool accept = false;
@@ -86,14 +87,22 @@ __device__ __forceinline__ bool ram_finish_row(const Grp<16>& g, RowChain& ch, i
         ch.th = ch.thn;
         *lp = ll;
     }
-    if ((long)iter < (long)maxiter) {                   // steps.cpp:82-99
+    *alpha_out = alpha;
+    return accept;
+}
+
+// The RAM rank-1 update of the proposal factor (steps.cpp:82-99); independent of the state, so the sampler kernel runs
+// it while the other workgroups of the ladder arrive at the swap rendezvous.
+__device__ __forceinline__ void ram_adapt_row(const Grp<16>& g, RowChain& ch, int d, uint64_t iter, int maxiter, double alpha,
+                                              double znorm2)
+{
+    if ((long)iter < (long)maxiter) {
         const double cb = cbrt((double)iter);               // iter^(2/3) without pow (iter = 0 -> step 1)
         const double step = fmin(1.0, (double)d / (cb * cb));
         const double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(znorm2);
         ch.v *= fac;
         chol_update_row(g, d, ch, alpha < 0.25);
     }
-    return accept;
 }
 
 // ExchangeStep sweep hot -> cold (steps.hpp:318-362, same decisions as exchange_decide) executed by a
