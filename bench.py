@@ -162,7 +162,7 @@ def main():
         # (profiles/r01: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB per dispatch; gfx950
         # FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound)
         traffic_gbs_bytes, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_v9.json")
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_v10.json")
         pmc_extra = None
         if B == 1024 and os.path.exists(pmc):
             pj = json.load(open(pmc))
@@ -170,7 +170,7 @@ def main():
             # what actually bounds the kernel: the instruction stream of its critical wave
             pmc_extra = {k: pj[k]["mean"] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
                                                      "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if k in pj}
-            traffic_src = "profiles/r01/pmc_v9.json (rocprofv3 --pmc, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch"
+            traffic_src = "profiles/r01/pmc_v10.json (rocprofv3 --pmc, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch"
         res = {
             "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
             "value": value,
@@ -197,7 +197,7 @@ def main():
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic_gbs_bytes,
                 "traffic_source": traffic_src,
-                "kernel": ("k_logdens_carma_p3<5>" if B <= 1024 else "k_logdens_carma_pc<5,16,2>" if B <= 2048 else
+                "kernel": ("k_logdens_carma_p3l<5>" if B <= 1024 else "k_logdens_carma_pc<5,16,2>" if B <= 2048 else
                            "k_logdens_carma_pc<5,8,PAIRS>" if B <= 8192 else "k_logdens_carma<5,8,4>"),
                 "kernel_avg_us": 1e3 * kernel_ms,
                 "kernel_min_us": 1e3 * float(kdur_ms.min()),

@@ -21,7 +21,6 @@
 #include "carma_core.h"
 #include "carma_ring.h"
 #include "carma_predict.h"
-#include "carma_pipe3.h"
 #include "carma_pipe3l.h"
 #include "carma_scan_dev.h"
 #include "carma_launch.h"
@@ -107,9 +106,8 @@ __global__ __launch_bounds__(64) void k_logdens_carma_scan(const double* __restr
     if (lane == 0) out[e] = ll;
 }
 
-// Smallest launches (<= 1024 evaluations): covariance wave + mean wave + rho producer per 4 evaluations
-// (carma_pipe3.h).  192 threads, 81 KiB of LDS: one workgroup per CU.
-// Co-rotating-frame pipeline (carma_pipe3l.h): covariance wave, mean wave, two producer waves.
+// Smallest launches (<= 1024 evaluations): covariance wave + mean wave + two producer waves per 4 evaluations, in a
+// co-rotating frame (carma_pipe3l.h).  256 threads, 82 KiB of LDS: one workgroup per CU.
 template <int P>
 __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restrict__ theta, int B, int d, int q,
                                                            const double4* __restrict__ series, int n, Prior pr,
@@ -152,43 +150,6 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
 #ifdef CARMA_DBG
     if (blockIdx.x == 0 && lane64 == 0) printf("B total %lld\n", clock64() - dbg_k0);
 #endif
-    ll += log_prior(m.scale, pr.measerr_dof);
-    const double ninf = -1.0 / 0.0;
-    if (fc.sing || !m.valid) ll = ninf;
-    if (live && g.lane() == 0) out[e] = ll;
-}
-
-template <int P>
-__global__ __launch_bounds__(192) void k_logdens_carma_p3(const double* __restrict__ theta, int B, int d, int q,
-                                                          const double4* __restrict__ series, int n, Prior pr,
-                                                          int ignore_prior, double* __restrict__ out)
-{
-    extern __shared__ double4 smem4[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane64 = tid & 63;
-    Grp<16> g{nullptr, lane64, nullptr};
-    Cx* ring = reinterpret_cast<Cx*>(smem4);
-    long e = ((long)blockIdx.x * 64 + lane64) / 16;
-    const bool live = e < B;
-    if (!live) e = B - 1;
-    if (wave == 2) {
-        pipe3_produce<P>(g, theta + e * d, series, n, ring);
-        return;
-    }
-    // both recursion waves set the model up themselves (in parallel; nothing to hand over)
-    Model<P> m;
-    model_from_theta<P, 16>(g, theta + e * d, q, pr, ignore_prior, m);
-    FilterConsts<P> fc;
-    filter_reset<P, 16>(g, m, fc);
-    RowConsts<P> rc;
-    row_consts<P>(g, m, fc, rc);
-    if (wave == 0) {
-        if constexpr (RowAsm<P>::NSLOT < P)
-            pipe3_cov_split<P>(g, m, rc, n, ring);
-        else
-            pipe3_cov<P>(g, m, rc, n, ring);
-        return;
-    }
-    double ll = pipe3_mean<P>(g, m, rc, n, ring);
     ll += log_prior(m.scale, pr.measerr_dof);
     const double ninf = -1.0 / 0.0;
     if (fc.sing || !m.valid) ll = ninf;
@@ -318,20 +279,12 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             return hipGetLastError();
         }
     }
-    if (rows <= 256 && n >= 8 && !(getenv("CARMA_LOGDENS_KERNEL") && strcmp(getenv("CARMA_LOGDENS_KERNEL"), "p3") == 0)) {
+    if (rows <= 256 && n >= 8) {
         // one workgroup per CU: covariance wave + mean wave + two producer waves, co-rotating frame (carma_pipe3l.h)
         const size_t lds = Pipe3LGeom<P>::BYTES;
         hipError_t ea = big_lds(reinterpret_cast<const void*>(&k_logdens_carma_p3l<P>));
         if (ea != hipSuccess) return ea;
         hipLaunchKernelGGL((k_logdens_carma_p3l<P>), dim3((unsigned)rows), dim3(256), lds, st, theta, B, d, q, series, n, pr,
-                           ignore_prior, out);
-        return hipGetLastError();
-    } else if (rows <= 256 && n >= 8) {
-        // the same pipeline with the rotation applied every step (carma_pipe3.h): CARMA_LOGDENS_KERNEL=p3
-        const size_t lds = Pipe3Geom<P>::BYTES;
-        hipError_t ea = big_lds(reinterpret_cast<const void*>(&k_logdens_carma_p3<P>));
-        if (ea != hipSuccess) return ea;
-        hipLaunchKernelGGL((k_logdens_carma_p3<P>), dim3((unsigned)rows), dim3(192), lds, st, theta, B, d, q, series, n, pr,
                            ignore_prior, out);
         return hipGetLastError();
     } else if (rows <= 512 && n >= 8) {

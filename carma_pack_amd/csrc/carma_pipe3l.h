@@ -1,4 +1,6 @@
-// carma_pipe3l.h -- the wave pipeline of carma_pipe3.h in a CO-ROTATING FRAME (gfx950 only).
+// carma_pipe3l.h -- the wave pipeline of the latency regime (<= 1024 evaluations), in a CO-ROTATING FRAME (gfx950 only).
+// One evaluation per 16-lane DPP row, four evaluations per workgroup; the step is cut between the covariance recursion
+// (which does not depend on the data) and the mean recursion, and the two halves run on different SIMDs one chunk apart.
 //
 // The step of the covariance wave is  D <- Phi_k (D - k k^T / var) Phi_k^T  (kfilter.cpp:197, 204) with Phi_k the
 // block-diagonal rotation exp(omega dt_k) of the real modal coordinates; 24 of its 56 issue slots (p = 5) are that
@@ -11,7 +13,7 @@
 // cancel in every product (numpy prototype tests/tools/proto/lazy_frame.py: the same error against the reference
 // restatement as the stepwise rotation, 1e-12 at worst over the bench batch).
 // RE-BASE: before |Re omega| dt_acc could overflow the scale factors or |Im omega| dt_acc cost angle accuracy the
-// accumulated rotation is applied for real (S <- A S A^T, z <- A z~; the column/row mix of carma_pipe3.h) and the
+// accumulated rotation is applied for real (S <- A S A^T, z <- A z~; column mix by DPP, row mix with the pair partner) and the
 // frame restarts at the identity.  The schedule is a time grid per evaluation: datum j is a re-base datum when
 // floor(t_j 2^ex) != floor(t_{j-1} 2^ex), 2^-ex <= min over the roots of (LIM_RE / |Re omega|, LIM_IM / |Im omega|);
 // the accumulated time of a non-re-base datum is therefore < 2^-ex.  (Dyadic cells nest: the waves branch on the
@@ -26,13 +28,37 @@
 //   (y_j and yerr_j^2 are wave-uniform: the recursion waves read them with scalar loads from the series itself)
 //   wave A (covariance)        [re-base]; w~, var, k~ -> link ring; S -= k~ k~^T / var          (lane r = row r of S)
 //   wave B (mean)              [re-base]; innov, chi2, sum log var; z~ += k~ innov / var        -> log-likelihood
-// Barrier protocol as in carma_pipe3.h: after barrier b the producers write chunk b+1, A works on chunk b, B on b-1.
+// One __syncthreads() per 16-datum chunk for all four waves: after barrier b the producers write chunk b+1 (ring
+// buffer (b+1)%3), A works on chunk b (reads ring b%3, writes link b%2), B on chunk b-1 -- all distinct buffers.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "carma_pipe3.h"
+#include "carma_core.h"
+#include "grp_device.h"
+#include "carma_ring.h"
 
 namespace carma {
+
+// real-coordinate constants of one evaluation, as held by lane r of its row (see filter_loop_real)
+template <int P>
+struct RowConsts {
+    double h_own, c_own, s0;
+    double hall[P];
+};
+template <int P>
+__device__ __forceinline__ void row_consts(const Grp<16>& g, const Model<P>& m, const FilterConsts<P>& fc, RowConsts<P>& rc)
+{
+    const int r = g.lane();
+    const bool act = r < P;
+    const bool cpx = (m.w.im != 0.0) && (r < (P & ~1));
+    const bool odd = r & 1;
+    const double c_im_partner = g.partner(fc.c_own.im);
+    rc.h_own = !act ? 0.0 : (cpx ? (odd ? 2.0 * fc.b_own.im : 2.0 * fc.b_own.re) : fc.b_own.re);
+    rc.c_own = cpx ? (odd ? c_im_partner : fc.c_own.re) : fc.c_own.re;
+    rc.s0 = fc.s0;
+#pragma unroll
+    for (int j = 0; j < P; j++) rc.hall[j] = g.bcast_u(rc.h_own, j);
+}
 
 template <int P>
 struct Pipe3LGeom {
@@ -154,8 +180,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     __syncthreads();                                          // barrier nc (wave B's last chunk)
 }
 
-// wave A: lane r of a 16-lane row holds row r of S.  (The split rows of carma_pipe3.h paid for the per-entry work of
-// the rotation; here the rotation is the exception and the row sum w~ = S h~ wants the whole row in one lane.)
+// wave A: lane r of a 16-lane row holds row r of S (the row sum w~ = S h~ wants the whole row in one lane).
 // The step is a dependent chain  w~ -> t -> var -> 1/var -> S -> w~ ...; the row sums run as two accumulation chains
 // and the reciprocal refinement is folded into the gain so that the chain, not the issue rate, stays short.
 template <int P>

@@ -20,7 +20,6 @@
 #include "carma_pt_core.h"
 #include "carma_pt_row.h"
 #include "carma_ring.h"
-#include "carma_pipe3.h"
 #include "carma_pipe3l.h"
 #include "carma_launch.h"
 

@@ -1,6 +1,6 @@
 // carma_scan.h -- the Kalman log-likelihood as an ASSOCIATIVE SCAN OVER TIME (latency regime).
 //
-// With <= 1024 evaluations in flight the sequential filter (carma_core.h / carma_pipe3.h) is bound by
+// With <= 1024 evaluations in flight the sequential filter (carma_core.h / carma_pipe3l.h) is bound by
 // n - 1 dependent steps of one wave.  Here ONE WAVE serves one evaluation and every LANE owns a block of
 // s = ceil(n / 64) consecutive data: the filter over a block is an element (A, b, C, eta, J) of the
 // associative operator of Sarkka & Garcia-Fernandez (IEEE TAC 2021, "Temporal parallelization of

@@ -164,26 +164,6 @@ struct Grp {
         static_assert(G == 16, "row broadcast");
         RowAsm<P>::gain(nt, z, D, k, s, si);
     }
-    // halves of row_sums / row_gain for the covariance wave and the mean wave of carma_pipe3.h
-    template <int P>
-    CARMA_DEV void row_sums_var(double& var, double& k, double e, double scale, double s0, double w, double c_own,
-                                const double (&h)[P]) const
-    {
-        static_assert(G == 16, "row broadcast");
-        RowAsm<P>::sums_var(var, k, e, scale, s0, w, c_own, h);
-    }
-    template <int P>
-    CARMA_DEV void row_sums_innov(double& innov, double y, double mu, double z, const double (&h)[P]) const
-    {
-        static_assert(G == 16, "row broadcast");
-        RowAsm<P>::sums_innov(innov, y, mu, z, h);
-    }
-    template <int P>
-    CARMA_DEV void row_gain_cov(double& nt, double (&D)[P], double k, double s) const
-    {
-        static_assert(G == 16, "row broadcast");
-        RowAsm<P>::gain_cov(nt, D, k, s);
-    }
     //   mm_j = c@j D_j - s@j D_{j^1}
     template <int P>
     CARMA_DEV void row_colmix(double (&mm)[P], double c, double s, const double (&D)[P]) const

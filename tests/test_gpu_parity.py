@@ -156,7 +156,7 @@ def test_ragged_and_empty_batches(cpa, readme):
     ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3, max_stdev=_pop_var_stdev(g["y"]))
     big = np.tile(g["theta"], (40, 1))                        # 1280 evals
     full = ctx.logdensity(big)                                # two-wave row kernel (> 1024 evaluations)
-    full1k = ctx.logdensity(big[:1024])                       # three-wave pipeline (<= 1024 evaluations)
+    full1k = ctx.logdensity(big[:1024])                       # four-wave pipeline (<= 1024 evaluations)
     assert ctx.logdensity(np.empty((0, 11))).shape == (0,)
     for B in (1, 7, 8, 9, 63, 65, 1023, 1025, 1279):
         th = big[:B]
@@ -220,7 +220,7 @@ def test_full_size_properties(cpa, readme):
 
 @pytest.mark.parametrize("p,q", [(2, 1), (3, 2), (4, 0), (5, 3), (6, 5), (7, 2)])
 def test_launch_shapes_agree(cpa, p, q):
-    """The four launch shapes -- three-wave pipeline (<= 1024 evaluations), two-wave row variant (<= 2048,
+    """The four launch shapes -- four-wave co-rotating pipeline (<= 1024 evaluations), two-wave row variant (<= 2048,
     one evaluation per DPP row), G-lane producer/consumer (<= 8192) and the throughput kernel -- against
     the oracle and each other."""
     t, y, yerr = irregular_series(203, seed=50 + p)

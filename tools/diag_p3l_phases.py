@@ -1,3 +1,5 @@
+"""Phase timings of the latency-regime pipeline (carma_pipe3l.h): cycles per chunk of every wave, set-up time, from the
+diagnostic build  DIAG_FLAGS=-DCARMA_DBG tools/build_diag.sh  (device printf of workgroup 0; third launch = warm)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
