@@ -49,6 +49,10 @@ def main():
     # Test hook for a one-GPU box: CARMA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and moves the barrier /
     # max-time reduction to gloo (RCCL refuses two ranks on one device).  The driver never sets it.
     share = os.environ.get("CARMA_BENCH_SHARE_GPU") == "1"
+    if share:
+        # k_pt_row spreads a ladder over several workgroups that meet at a rendezvous and needs them all resident:
+        # true on a GPU of its own, not when two processes time-share one (the launch would abort with an error)
+        os.environ["CARMA_PT_KERNEL"] = "ladder"
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
