@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64) void k_logdens_carma_scan(const double* __restr
     double2* xch = reinterpret_cast<double2*>(smem4);
     double* sh = reinterpret_cast<double*>(xch + ScanLds<P>::NPAIR * 64);
     const int lane = threadIdx.x;
-    const long e = blockIdx.x;
+    const long e = blockIdx.x;                               // one workgroup per evaluation: the grid is B wide
+    (void)B;
     const double ll = scan_logdensity<P, SMAX>(theta + e * d, q, series, n, pr, ignore_prior, lane, xch, sh);
     if (lane == 0) out[e] = ll;
 }

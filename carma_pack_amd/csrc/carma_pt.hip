@@ -284,7 +284,9 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
     __syncthreads();
 
     CARMA_STAMP_DECL;
+#if defined(CARMA_STAMPS)
     unsigned long long st5 = 0, st6 = 0, st7 = 0;
+#endif
     for (int it = 0; it < L.niter; it++) {
         const uint64_t iter = L.iter0 + (uint64_t)it;
         double znorm2 = 0.0;
