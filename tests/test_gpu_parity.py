@@ -262,7 +262,7 @@ def test_series_lengths_around_chunk_boundaries(cpa, p, q):
         dup = np.array([np.min(np.abs(r[:, None] - r[None, :]) + np.eye(p)) == 0.0 for r in roots])
         from mp_truth import loglik_truth
         arb = lambda i: loglik_truth(t, y, yerr, th[i % 12], p, q)[0]   # noqa: E731
-        for B in (12, 1100, 3000):       # three-wave pipeline / two-wave row kernel / G-lane producer-consumer
+        for B in (12, 1100, 3000):       # four-wave pipeline / two-wave row kernel / G-lane producer-consumer
             big = np.tile(th, (B // 12 + 1, 1))[:B]
             got = ctx.logdensity(big, ignore_prior=True)
             assert np.array_equal(got, np.tile(got[:12], B // 12 + 1)[:B], equal_nan=True), (n, B)
