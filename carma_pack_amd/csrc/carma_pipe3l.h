@@ -69,7 +69,9 @@ struct Pipe3LGeom {
     static constexpr int FLAG_OFF = CONST_OFF + SLOT;           // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
     static constexpr int ENTRIES = FLAG_OFF + 2;
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 81.8 KiB
-    static constexpr double LIM_RE = 200.0;                     // |Re omega| dt_acc: scale factors within e^+-200 (squares e^+-400)
+    static constexpr double LIM_RE = 200.0;                     // |Re omega| dt_acc: scale factors within e^+-200; S carries their
+                                                                // squares (5e173 at most: room for any variance below 1e130;
+                                                                // 100 instead of 200 costs 3 % per step in extra re-bases)
     static constexpr double LIM_IM = 256.0;                     // |Im omega| dt_acc: the phase product rounds to 3e-14 rad at most,
                                                                 // what the stepwise products accumulate over such a window anyway
 };
