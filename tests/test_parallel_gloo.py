@@ -30,6 +30,14 @@ def test_philox_matches_device_rng():
     assert np.array_equal(u, np.array(mine))
 
 
+def test_vectorised_philox_is_the_scalar_one():
+    chains = np.array([0, 1, 37, 2 ** 31 + 5, 4000000000])
+    for it in (0, 5, 2 ** 33 + 7):
+        a = par.philox_uniform_chains(0x1234ABCD5678, chains, it, par.RNG_SWAP, 3)
+        b = np.array([par.philox_uniform(0x1234ABCD5678, int(c), it, par.RNG_SWAP, 3) for c in chains])
+        assert np.array_equal(a, b)
+
+
 def test_shard_slice_covers_everything():
     for n in (0, 1, 7, 1024, 1025):
         for w in (1, 2, 3, 8):
