@@ -343,12 +343,27 @@ CARMA_DEV void filter_reset(const GrpT& g, const Model<P>& m, FilterConsts<P>& f
 }
 
 
+// compile-time loop: f(IntC<J>{}) for J = J0 .. N-1 (DPP lane selectors are instruction immediates)
+template <int J>
+struct IntC {
+    static constexpr int value = J;
+};
+template <int J, int N, class F>
+CARMA_DEV void static_for(F&& f)
+{
+    if constexpr (J < N) {
+        f(IntC<J>{});
+        static_for<J + 1, N>(f);
+    }
+}
+
 // Where the transition factors rho_j(k) = exp(omega_j dt_k) of a group come from.
 // RhoInline: every lane computes its own factor one step ahead and shares it through the group's
 // second exchange array.  (carma_ring.h has the variant fed by a producer wave.)
 template <int P, class GrpT>
 struct RhoInline {
     static constexpr bool kRing = false;
+    static constexpr bool kPaired = false;
     static constexpr int kChunk = 1 << 30;
     CARMA_DEV void chunk_begin(int) const {}
     CARMA_DEV double4 record_s(int) const { return double4{}; }
@@ -368,6 +383,55 @@ struct RhoInline {
     }
     // called once the group's LDS reads are in flight: independent work that hides their latency
     CARMA_DEV void prepare(int, double dt_next) { cexp_step(w.re, w.im, dt_next, &rho_next.re, &rho_next.im); }
+};
+
+// RhoPair: RhoInline for the G <= 8 loop (filter_loop_real) with the exp/sincos work SHARED inside a root pair.  The two
+// lanes of a complex-conjugate pair would evaluate the same exponential and the same sine / cosine every step (their
+// factors are conjugates), and the partner lane of an odd p's last, single real root is idle.  So lanes (2i, 2i+1)
+// take turns: the loop runs two steps per trip; before a trip the even lane evaluates the pair's factor for its first
+// step (phase 0), the odd lane the one for its second step (phase 1), both publish once, and in either phase every
+// lane reads a pair's factor from the slot of the phase's owner -- conjugated for the other member, which is a
+// source modifier because the phase is a compile-time constant.  Half the exp/sincos evaluations, ceil(p/2) + 1 LDS
+// reads per step instead of p.  A quadratic factor with two REAL roots (positive discriminant) puts two different
+// roots into a pair: filter_run uses this source only when no group of the wave holds one.
+template <int P, class GrpT>
+struct RhoPair {
+    static constexpr bool kRing = false;
+    static constexpr bool kPaired = true;
+    static constexpr int kChunk = 1 << 30;
+    CARMA_DEV void chunk_begin(int) const {}
+    CARMA_DEV double4 record_s(int) const { return double4{}; }
+    CARMA_DEV void fetch_s(int, Cx&, Cx (&)[P]) const {}
+    CARMA_DEV void fetch_own_s(int, Cx&) const {}
+    const GrpT& g;
+    Cx w;                  // own root (idle lanes: the last root, see model_from_theta)
+    Cx val;                // the factor this lane evaluated last
+    // dt1 / dt2: time steps of the coming trip's first / second step
+    CARMA_DEV void begin2(double dt1, double dt2) { cexp_step(w.re, w.im, (g.lane() & 1) ? dt2 : dt1, &val.re, &val.im); }
+    template <int PH>
+    CARMA_DEV void publish() const
+    {
+        if constexpr (PH == 0) g.publish2(val.re, val.im);
+    }
+    template <int PH>
+    CARMA_DEV void fetch(Cx& rho, Cx (&rj)[P]) const
+    {
+        constexpr double se = PH ? -1.0 : 1.0, so = -se;      // sign of the imaginary part for the even / odd member
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const Cx v = g.peek2(j + PH);
+            rj[j] = Cx{v.re, se * v.im};
+            if (j + 1 < P) rj[j + 1] = Cx{v.re, so * v.im};
+        }
+        const int r = g.lane();
+        const Cx v = g.peek2((r & ~1) + PH);                  // own pair
+        rho = Cx{v.re, (r & 1) ? so * v.im : se * v.im};
+    }
+    template <int PH>
+    CARMA_DEV void prepare(double dt1, double dt2)
+    {
+        if constexpr (PH == 1) begin2(dt1, dt2);
+    }
 };
 
 // Update loop (kfilter.cpp:189-215) + log-likelihood sum (carpack.hpp:167-171), given Reset's
@@ -527,7 +591,10 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
     double4 rprev = series[0];
     double4 rcur = series[n > 1 ? 1 : 0];
     double4 rnxt = series[n > 2 ? 2 : n - 1];
-    src.begin(1, rcur.x);
+    if constexpr (RhoSrc::kPaired)
+        src.begin2(rcur.x, rnxt.x);
+    else
+        src.begin(1, rcur.x);
     CARMA_STAMP_DECL;
     // n-1 passes; pass kk closes var_{kk-1}, mean_{kk-1} and applies Update kk.  The body is one
     // basic block (no branch on the pass index), so the var/mean butterflies and the reciprocal are
@@ -546,7 +613,8 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
             rec_n = src.record_s(0);
         }
     }
-    auto pass = [&](const int kk, const int s_in_chunk) __attribute__((always_inline)) {
+    auto pass = [&](const int kk, const int s_in_chunk, auto phase) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phase)::value;          // RhoPair: step of the trip (0, 1); unused otherwise
         CARMA_STAMP(st0);
         double4 rnn = rnxt;
         if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
@@ -557,7 +625,10 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
         for (int j = 0; j < P; j++) rj[j] = rj_n[j];
         if constexpr (RhoSrc::kRing) rprev = rec_n;              // series record kk-1
         g.publishk(k);
-        src.publish(kk);
+        if constexpr (RhoSrc::kPaired)
+            src.template publish<PH>();
+        else
+            src.publish(kk);
 #pragma unroll
         for (int i = 0; i < (P + 1) / 2; i++) g.peekk2(i, kj[2 * i], kj[2 * i + 1]);
         if constexpr (RhoSrc::kRing) {
@@ -571,11 +642,16 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
                 src.fetch_s(s_in_chunk + 1, rho_n, rj_n);
                 rec_n = src.record_s(s_in_chunk + 1);
             }
+        } else if constexpr (RhoSrc::kPaired) {
+            src.template fetch<PH>(rho, rj);
         } else {
             src.fetch(kk, rho, rj);
         }
         g.done_reading();                                        // pins the LDS issue order
-        src.prepare(kk + 1, rnxt.x);
+        if constexpr (RhoSrc::kPaired)
+            src.template prepare<PH>(rnxt.x, rnn.x);             // steps kk+1, kk+2: the next trip
+        else
+            src.prepare(kk + 1, rnxt.x);
         CARMA_STAMP(st1);
         // var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z: DPP butterflies, bit-identical in the group
         const double pv = g.sum(pvr), pm = g.sum(pmr);
@@ -628,15 +704,26 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
         CARMA_STAMP_ACC(sb, st1, st2);
         CARMA_STAMP_ACC(sc, st2, st3);
     };
-    for (int kk0 = 1; kk0 < n; kk0 += RhoSrc::kChunk) {
-        if (RhoSrc::kRing && n - kk0 >= RhoSrc::kChunk) {
-            // full chunk: constant trip count, unrolled so that ring offsets become immediates
-#pragma unroll 4
-            for (int s = 0; s < (RhoSrc::kRing ? RhoSrc::kChunk : 1); s++) pass(kk0 + s, s);
-        } else {
-            const int kend = (n - kk0 < RhoSrc::kChunk) ? n : kk0 + RhoSrc::kChunk;
+    if constexpr (RhoSrc::kPaired) {
+        // two steps per trip: the phase of the pair-shared factors is a compile-time constant in either half
+        int kk = 1;
 #pragma unroll 1
-            for (int kk = kk0; kk < kend; kk++) pass(kk, kk - kk0);
+        for (; kk + 1 < n; kk += 2) {
+            pass(kk, 0, IntC<0>{});
+            pass(kk + 1, 0, IntC<1>{});
+        }
+        if (kk < n) pass(kk, 0, IntC<0>{});
+    } else {
+        for (int kk0 = 1; kk0 < n; kk0 += RhoSrc::kChunk) {
+            if (RhoSrc::kRing && n - kk0 >= RhoSrc::kChunk) {
+                // full chunk: constant trip count, unrolled so that ring offsets become immediates
+#pragma unroll 4
+                for (int s = 0; s < (RhoSrc::kRing ? RhoSrc::kChunk : 1); s++) pass(kk0 + s, s, IntC<0>{});
+            } else {
+                const int kend = (n - kk0 < RhoSrc::kChunk) ? n : kk0 + RhoSrc::kChunk;
+#pragma unroll 1
+                for (int kk = kk0; kk < kend; kk++) pass(kk, kk - kk0, IntC<0>{});
+            }
         }
     }
     {   // last point: var_{n-1}, mean_{n-1}
@@ -671,20 +758,6 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
 // and two LDS reads (its own factor and the series record, both prefetched), against ~55 + 24 + 12
 // LDS instructions in the G = 8 loop.  Same recursion, same operation order per element as
 // filter_loop_real, so the results agree to rounding (fma contraction differs).
-// compile-time loop: f(IntC<J>{}) for J = J0 .. N-1 (DPP lane selectors are instruction immediates)
-template <int J>
-struct IntC {
-    static constexpr int value = J;
-};
-template <int J, int N, class F>
-CARMA_DEV void static_for(F&& f)
-{
-    if constexpr (J < N) {
-        f(IntC<J>{});
-        static_for<J + 1, N>(f);
-    }
-}
-
 template <int P, int G, bool WRITE_MV, class GrpT, class RhoSrc>
 CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterConsts<P>& fc, RhoSrc& src,
                                  const double4* __restrict__ series, int n, double* mean_out, double* var_out)
@@ -819,10 +892,18 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
     double ll = filter_loop<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
 #else
     double ll;
-    if constexpr (G == 16)
+    if constexpr (G == 16) {
         ll = filter_loop_row<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
-    else
-        ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
+    } else {
+        // pair-shared factors unless some group of the wave has a quadratic factor with two real roots
+        const bool real_pair = (g.lane() < (P & ~1)) && (m.w.im == 0.0);
+        if (g.wave_all(!real_pair)) {
+            RhoPair<P, GrpT> srcp{g, m.w, Cx{1.0, 0.0}};
+            ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, srcp, series, n, mean_out, var_out);
+        } else {
+            ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
+        }
+    }
 #endif
     *singular = fc.sing;
     return ll;

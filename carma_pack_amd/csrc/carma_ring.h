@@ -133,6 +133,7 @@ __device__ __forceinline__ void ring_produce_row(const Grp<16>& g, const double*
 template <int P, int G>
 struct RhoRing {
     static constexpr bool kRing = true;
+    static constexpr bool kPaired = false;
     static constexpr int kChunk = RingGeom<P>::C;
     const Grp<G>& g;
     const Cx* ring;

@@ -60,6 +60,8 @@ struct Grp {
         if (G >= 16) v = fmax(v, dpp_mirror(v));
         return v;
     }
+    // true when b holds in every lane of the WAVE (a scalar: branches on it are uniform)
+    CARMA_DEV static bool wave_all(bool b) { return __ballot(!b) == 0ull; }
     // value held by the neighbouring lane (lane ^ 1): the other member of a root pair
     CARMA_DEV static double partner(double v) { return dpp_xor1(v); }
     // value of v held by lane J of this group, J a compile-time constant: DPP, no LDS round trip.

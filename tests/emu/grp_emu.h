@@ -79,6 +79,8 @@ struct Grp {
         return o;
     }
     // same butterfly partners as the DPP controls in grp_device.h
+    // device: the whole wave; here a group is its own wave
+    bool wave_all(bool b) const { return sum(b ? 0.0 : 1.0) == 0.0; }
     double sum(double v) const
     {
         if (G >= 2) v += xchg(v, r ^ 1);
