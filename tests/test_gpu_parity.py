@@ -464,3 +464,41 @@ def test_corotating_frame_windows_and_rebases(cpa, p, q):
     assert np.array_equal(shuffled, got[perm], equal_nan=True)
     for i in (0, 17, 63):
         assert np.array_equal(ctx.logdensity(th[i:i + 1], ignore_prior=True), got[i:i + 1], equal_nan=True)
+
+
+@pytest.mark.parametrize("p,q", [(4, 1), (5, 3), (7, 2)])
+def test_pair_shared_factors_and_real_pairs(cpa, p, q):
+    """Throughput-regime kernels share the exp/sincos of a root pair between its two lanes (RhoPair) unless a group
+    of the wave holds a quadratic factor with two REAL roots.  Batches of complex-pair thetas, of real-pair thetas and
+    mixtures of both (so that a theta sits in waves of either kind) against the oracle; a theta's result must not
+    depend on which kind of wave evaluates it."""
+    t, y, yerr = irregular_series(120, seed=70 + p)
+    rng = np.random.default_rng(700 + 10 * p + q)
+    cplx = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(32)])
+    real = cplx.copy()
+    # log-quadratic coefficients (a, b) with b^2 > 4a: two distinct real roots -(b +- sqrt(b^2 - 4a))/2
+    # (one factor only: a model with all of its roots real and clustered is ill-conditioned beyond what any kernel --
+    # or the oracle -- resolves, which is not what this test is about)
+    r1 = 10.0 ** rng.uniform(-2.0, -0.5, 32)
+    r2 = r1 * rng.uniform(3.0, 20.0, 32)
+    real[:, 3] = np.log(r1 * r2)
+    real[:, 4] = np.log(r1 + r2)
+    ctx = cpa.Context(t, y, yerr, p, q)
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    from mp_truth import loglik_truth
+    B = 20000                                                   # throughput kernel
+    res = {}
+    for name, pool in (("complex", cplx), ("real", real), ("mixed", np.concatenate([cplx, real])[rng.permutation(64)])):
+        want = m.logdensity_batch(pool, ignore_prior=True, nthreads=8)
+        big = np.tile(pool, (B // pool.shape[0] + 1, 1))[:B]
+        got = ctx.logdensity(big, ignore_prior=True)
+        assert np.array_equal(got, np.tile(got[:pool.shape[0]], B // pool.shape[0] + 1)[:B], equal_nan=True), name
+        assert_parity(got[:pool.shape[0]], want, RTOL, "%s p=%d q=%d" % (name, p, q), max_arbitrated=6, arb_factor=5.0,
+                      arbiter=lambda i, pool=pool: loglik_truth(t, y, yerr, pool[i], p, q)[0])
+        res[name] = dict(zip(map(bytes, pool), got[:pool.shape[0]]))
+    # the same theta in an all-complex wave (pair-shared factors) and in a mixed wave (one evaluation per lane)
+    for key, v in res["complex"].items():
+        w = res["mixed"][key]
+        assert v == w or abs(v - w) <= 1e-12 * abs(w), (v, w)
+    for key, v in res["real"].items():
+        assert v == res["mixed"][key] or (np.isnan(v) and np.isnan(res["mixed"][key]))
