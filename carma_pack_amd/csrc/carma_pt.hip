@@ -15,6 +15,7 @@
 // RAM(T-2), ...): here all RAM steps of an iteration run concurrently and the swap sweep follows.
 // Both are compositions of kernels that leave the tempered joint posterior invariant.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "grp_device.h"
 #include "carma_pt_core.h"
@@ -193,7 +194,15 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
     int nthr = 0, pc = 0;
     const size_t lds = pt_lds_bytes(P, L.d, L.T, &nthr, &pc);
     if constexpr (P >= 2) {
-        if (pc && L.n >= 32) {
+        // The producer/consumer variant halves the instruction stream of the chain waves but doubles the wave count: it
+        // wins while a CU holds at most one ladder (12.3k vs 8.0k it/s at 16 x 256) and loses once the ladders queue up
+        // for the SIMDs (3.1k vs 4.0k it/s at 16 x 1024, tools/mcmc_bigR_probe.py; the plain chain waves share the
+        // exp/sincos inside root pairs, RhoPair).  CARMA_PT_PLAIN=0/1 overrides.
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        bool plain = L.R > (long)ncu;
+        if (const char* fp = getenv("CARMA_PT_PLAIN")) plain = fp[0] == '1';
+        if (pc && L.n >= 32 && !plain) {
             if (nthr <= 256)
                 return launch_pt_k<P, G, 256, true>(L, nthr, lds, series, pr, temps, theta, logpost, chol, naccept, nswap,
                                                     samples, sample_lp, st);
