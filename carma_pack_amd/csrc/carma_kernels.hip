@@ -292,9 +292,10 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
         // very few evaluations in flight (BASELINE configs 2, 3: 1024): one evaluation per DPP row, the
         // cross-lane traffic of a step folded into FP64 DPP operands (filter_loop_row), rho producer wave
         return rows <= 256 ? launch_pc(&k_logdens_carma_pc<P, 16, 1>, rows, 1) : launch_pc(&k_logdens_carma_pc<P, 16, 2>, rows, 2);
-    } else if (waves <= 1024 && n >= 8) {
+    } else if (waves <= 512 && n >= 8) {
         // few evaluations in flight: one wave's instruction stream is the run time, so split it
-        // (consumer + rho producer, carma_ring.h)
+        // (consumer + rho producer, carma_ring.h).  Beyond 512 waves (two rounds of workgroups) the plain kernel
+        // with pair-shared exp/sincos is ahead: 104 vs 111 us at 6144 evaluations (tools/midrange_probe.py)
         return waves <= 256 ? launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1) : launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);
     } else if (waves <= 2048) {
         hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n,
