@@ -306,8 +306,9 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
         CARMA_STAMP(st2);
         // the wave pipeline of carma_pipe3l.h on the proposals; the mean wave hands the log-density back
         if (wave >= 2) {
-            // the producers are done two chunks before the recursion waves: the random numbers of the NEXT iteration
-            // (proposal variates, swap uniforms; functions of key and iteration only) are drawn in that time
+            // the producers are done two chunks before the recursion waves: in that time they draw random numbers that
+            // are functions of key and iteration only -- P0 the NEXT iteration's proposal variates, P1 the logs of the
+            // swap uniforms of THIS iteration's exchange
             pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n, ring, [&](int pw) {
                 if (pw == 0) {
                     s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
