@@ -1,4 +1,4 @@
-"""GPU test of one temperature ladder sharded over ranks (BASELINE config 4's partitioning,
+"""GPU test of the N>1 helpers with the real kernels behind them: batch sharding (`sharded_logdensity`) and one temperature ladder sharded over ranks (BASELINE config 4's partitioning,
 carma_pack_amd/parallel.py `LadderShard`) with the real sampler behind it.
 
 The GPU box has one device, so both ranks of the world_size-2 group run on cuda:0 and the process
@@ -44,6 +44,13 @@ def _worker(rank, world, port, q, resident):
         from carma_pack_amd import parallel as par
         t, y, e = _series()
         ctx = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std())
+        # batch sharding with the real kernels: every rank evaluates its slice, all ranks get the full result, and it
+        # is the single-process result bit for bit (an evaluation does not depend on its neighbours in the launch)
+        from carma_pack_amd.synth import prior_like_theta
+        rng = np.random.default_rng(5)
+        thetas = np.array([prior_like_theta(rng, P, Q, t, y) for _ in range(37)])
+        full = par.sharded_logdensity(lambda x: ctx.logdensity(x, ignore_prior=True), thetas, dist)
+        assert np.array_equal(full, ctx.logdensity(thetas, ignore_prior=True), equal_nan=True)
         sh = par.LadderShard(ctx, TG, R, adapt_iters=NITER, seed=SEED, dist=dist, device="cuda:0" if resident else "cpu")
         assert (sh._th is not None) == resident
         sh.start()
