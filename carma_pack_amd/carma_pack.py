@@ -265,21 +265,68 @@ class CarmaSample(MCMCSample):
         dev = -2.0 * loglik
         return float(np.mean(dev) + 0.5 * np.var(dev))
 
+    def _psd_frequencies(self, nfreq=1000):
+        """Log-spaced grid between 1 / (time span) and 0.5 / (smallest time step) (reference :583-594)."""
+        dt_min = np.diff(self.time).min()
+        dt_max = self.time.max() - self.time.min()
+        return np.exp(np.linspace(np.log(1.0 / dt_max), np.log(0.5 / dt_min), num=nfreq))
+
+    @staticmethod
+    def _subsample(nsamples, nsamples0):
+        """The evenly spaced sample indices the reference uses when nsamples < all (:572-578)."""
+        if nsamples is None or nsamples >= nsamples0:
+            return np.arange(nsamples0)
+        return (np.arange(nsamples) * (nsamples0 / nsamples)).astype(int)
+
+    def _psd_samples(self, frequencies, index):
+        """sigma^2 |delta(2 pi i f)|^2 / |alpha(2 pi i f)|^2 for every (frequency, sample) pair (reference :601-618),
+        by Horner's rule on the whole [nfreq, nsamples] grid."""
+        sig = np.squeeze(self._samples["sigma"][index], axis=-1) if self._samples["sigma"].ndim > 1 else self._samples["sigma"][index]
+        ar, ma = self._samples["ar_coefs"][index], self._samples["ma_coefs"][index]
+        om = (2.0j * np.pi * np.asarray(frequencies, dtype=float))[:, None]
+        ar_poly = np.zeros((om.shape[0], ar.shape[0]), dtype=complex)
+        for k in range(ar.shape[1]):                    # ar_coefs: highest order first
+            ar_poly = ar_poly * om + ar[None, :, k]
+        ma_poly = np.zeros_like(ar_poly)
+        for k in range(ma.shape[1] - 1, -1, -1):        # ma_coefs: lowest order first
+            ma_poly = ma_poly * om + ma[None, :, k]
+        return sig[None, :] ** 2 * np.abs(ma_poly) ** 2 / np.abs(ar_poly) ** 2
+
+    def _psd_credint(self, percentile, nsamples, frequencies, chunk=64):
+        index = self._subsample(nsamples, self._samples["sigma"].shape[0])
+        lower = (100.0 - percentile) / 2.0
+        out = np.empty((frequencies.size, 3))
+        for f0 in range(0, frequencies.size, chunk):     # bounded memory: chunk x nsamples complex values at a time
+            psd = self._psd_samples(frequencies[f0:f0 + chunk], index)
+            out[f0:f0 + chunk] = np.percentile(psd, [lower, 50.0, 100.0 - lower], axis=1).T
+        return out
+
+    def plot_power_spectrum(self, percentile=68.0, nsamples=None, plot_log=True, color="b", alpha=0.5, sp=None,
+                            doShow=True):
+        """Posterior median and `percentile` credibility band of the power spectrum on 1000 log-spaced frequencies
+        (reference :548-648).  Returns the reference's tuple (lower PSD, upper PSD, median PSD, frequencies).  The
+        numbers are computed for every (frequency, sample) pair at once; drawing happens only when a subplot is
+        passed or doShow is true (matplotlib is imported lazily -- plotting is not part of the hot path)."""
+        frequencies = self._psd_frequencies()
+        ci = self._psd_credint(percentile, nsamples, frequencies)
+        if sp is not None or doShow:
+            import matplotlib.pyplot as plt
+            if sp is None:
+                sp = plt.figure().add_subplot(111)
+            (sp.loglog if plot_log else sp.plot)(frequencies, ci[:, 1], color=color)
+            sp.fill_between(frequencies, ci[:, 2], ci[:, 0], facecolor=color, alpha=alpha)
+            sp.set_xlim(frequencies.min(), frequencies.max())
+            sp.set_xlabel("Frequency")
+            sp.set_ylabel("Power Spectrum")
+            if doShow:
+                plt.show()
+        return ci[:, 0], ci[:, 2], ci[:, 1], frequencies
+
     def power_spectrum_band(self, percentile=68.0, nsamples=None, freq=None):
-        """Posterior median and credibility band of the PSD (numerical part of
-        plot_power_spectrum, reference :548-648)."""
-        sig, ar, ma = self._samples["sigma"], self._samples["ar_coefs"], self._samples["ma_coefs"]
-        n = sig.shape[0] if nsamples is None else min(nsamples, sig.shape[0])
-        idx = np.random.permutation(sig.shape[0])[:n]
-        if freq is None:
-            dt = np.diff(self.time)
-            freq = np.logspace(np.log10(1.0 / (self.time.max() - self.time.min())), np.log10(0.5 / dt.min()), 1000)
-        s = 2.0j * np.pi * freq
-        psd = np.empty((n, freq.size))
-        for i, k in enumerate(idx):
-            psd[i] = power_spectrum(freq, sig[k].item() if np.ndim(sig[k]) else sig[k], ar[k], ma[k])
-        lo, hi = (100.0 - percentile) / 2.0, 100.0 - (100.0 - percentile) / 2.0
-        return np.percentile(psd, lo, axis=0), np.percentile(psd, hi, axis=0), np.median(psd, axis=0), freq
+        """plot_power_spectrum's numbers on a caller-chosen frequency grid, without any drawing."""
+        frequencies = self._psd_frequencies() if freq is None else np.asarray(freq, dtype=float)
+        ci = self._psd_credint(percentile, nsamples, frequencies)
+        return ci[:, 0], ci[:, 2], ci[:, 1], frequencies
 
     def makeKalmanFilter(self, bestfit):
         """KalmanFilterp for a point estimate ('map', 'median', 'mean' or a sample index),
@@ -358,6 +405,29 @@ class Car1Sample(CarmaSample):
         self._samples["ar_coefs"] = np.c_[np.ones_like(omega), omega]
         self._samples["ma_coefs"] = np.ones((trace.shape[0], 1))
         self._samples["sigma"] = np.sqrt(2.0 * omega * trace[:, 0] ** 2)
+
+    def makeKalmanFilter(self, bestfit):
+        """KalmanFilter1 for a point estimate (reference :925-948): 'map', 'median', anything else = posterior mean
+        (of sigma^2, mu and log omega -- as the reference does); an integer picks one sample (as CarmaSample)."""
+        sig, mu_s, lw = (np.ravel(self._samples[k]) for k in ("sigma", "mu", "log_omega"))
+        if bestfit == "map":
+            i = int(np.argmax(self._samples["logpost"]))
+            sigsqr, mu, log_omega = sig[i] ** 2, mu_s[i], lw[i]
+        elif bestfit == "median":
+            sigsqr, mu, log_omega = np.median(sig) ** 2, np.median(mu_s), np.median(lw)
+        elif isinstance(bestfit, (int, np.integer)):
+            i = int(bestfit)
+            sigsqr, mu, log_omega = sig[i] ** 2, mu_s[i], lw[i]
+        else:
+            sigsqr, mu, log_omega = np.mean(sig ** 2), np.mean(mu_s), np.mean(lw)
+        kf = carmcmcLib.KalmanFilter1(carmcmcLib.vecD(self.time), carmcmcLib.vecD(self.y - mu),
+                                      carmcmcLib.vecD(self.ysig), float(sigsqr), float(np.exp(log_omega)))
+        return kf, float(mu)
+
+    def _psd_samples(self, frequencies, index):
+        """sigma^2 / (omega^2 + (2 pi f)^2) (reference :1004-1013)."""
+        sig, lw = np.ravel(self._samples["sigma"])[index], np.ravel(self._samples["log_omega"])[index]
+        return sig[None, :] ** 2 / (np.exp(lw)[None, :] ** 2 + (2.0 * np.pi * np.asarray(frequencies)[:, None]) ** 2)
 
 
 # ------------------------------------------------------------------------------------------------

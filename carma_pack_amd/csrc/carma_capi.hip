@@ -95,6 +95,37 @@ std::vector<double> pack_series(const std::vector<double>& t, const std::vector<
     return s;
 }
 
+// AR roots as the kernels expect them: complex-conjugate pairs adjacent (negative imaginary part first), real roots
+// after them -- the order CARp::ARRoots emits (src/carpack.cpp:137-172).  The result of the filter does not depend on
+// the order of the roots, so roots handed over in another order (carma_pack.py's get_ar_roots puts a real root wherever
+// its centroid is zero) are re-ordered here; a set that is not closed under conjugation is not a real-valued process
+// and is rejected.  out = p (re, im) pairs.
+int normalize_roots(int p, const double* om, double* out)
+{
+    std::vector<int> used(p, 0);
+    int k = 0;
+    for (int i = 0; i < p; i++) {
+        if (used[i] || om[2 * i + 1] == 0.0) continue;
+        const double re = om[2 * i], im = om[2 * i + 1], tol = 1e-12 * std::hypot(re, im);
+        int mate = -1;
+        for (int j = i + 1; j < p && mate < 0; j++)
+            if (!used[j] && std::fabs(om[2 * j] - re) <= tol && std::fabs(om[2 * j + 1] + im) <= tol) mate = j;
+        if (mate < 0) return CARMA_EINVAL;
+        used[i] = used[mate] = 1;
+        out[2 * k] = out[2 * k + 2] = re;
+        out[2 * k + 1] = -std::fabs(im);
+        out[2 * k + 3] = std::fabs(im);
+        k += 2;
+    }
+    for (int i = 0; i < p; i++) {
+        if (used[i]) continue;
+        out[2 * k] = om[2 * i];
+        out[2 * k + 1] = 0.0;
+        k++;
+    }
+    return CARMA_OK;
+}
+
 int select_device(int device)
 {
     int cnt = 0;
@@ -306,7 +337,10 @@ static int kfilter_common(const double* time, const double* y, const double* yer
     std::vector<double> s = pack_series(t, yy, ee);
     std::vector<double> par(2 * CARMA_PMAX + CARMA_PMAX, 0.0);
     if (p > 1) {
-        for (int i = 0; i < 2 * p; i++) par[i] = omega_re_im[i];
+        if (normalize_roots(p, omega_re_im, par.data()) != CARMA_OK) {
+            set_error("carma_kfilter_carma: the AR roots must be real or come in complex-conjugate pairs");
+            return CARMA_EINVAL;
+        }
         for (int i = 0; i < p && i < nma; i++) par[2 * CARMA_PMAX + i] = ma[i];   // zero padded (kfilter.hpp:318-320)
     }
     double *d_s = nullptr, *d_par = nullptr, *d_mv = nullptr;
@@ -372,7 +406,10 @@ static int predict_common(const double* time, const double* y, const double* yer
     std::vector<double> s = pack_series(t, yy, ee);
     std::vector<double> par(2 * CARMA_PMAX + CARMA_PMAX, 0.0);
     if (p > 1) {
-        for (int i = 0; i < 2 * p; i++) par[i] = omega_re_im[i];
+        if (normalize_roots(p, omega_re_im, par.data()) != CARMA_OK) {
+            set_error("carma_predict_carma: the AR roots must be real or come in complex-conjugate pairs");
+            return CARMA_EINVAL;
+        }
         for (int i = 0; i < p && i < nma; i++) par[2 * CARMA_PMAX + i] = ma[i];
     }
     double *d_s = nullptr, *d_par = nullptr, *d_io = nullptr;

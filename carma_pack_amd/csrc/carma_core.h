@@ -12,18 +12,17 @@
 //   * log-likelihood sum           src/include/carpack.hpp:167-171
 //   * CAR(1) Reset/Update          src/kfilter.cpp:19-48
 //
-// Layout: lane r (< P) of a group owns ROW r of the p x p Hermitian matrix D = P - V
-// (prediction covariance minus stationary covariance), its own root omega_r, rotated MA
-// coefficient b_r, state x_r and c_r = (V b^H)_r.  Algebraically identical to the reference
+// Layout: lane r (< P) of a group owns ROW r of the p x p matrix D = P - V (prediction covariance
+// minus stationary covariance, in REAL modal coordinates: see filter_loop_real), its own root omega_r,
+// rotated MA coefficient b_r, state z_r and c_r = (V b^H)_r.  Algebraically identical to the reference
 // recursion but restructured so that the stationary matrix V never has to be kept:
 //     u      = P b^H            = D b^H + c
 //     var_k  = Re(b P b^H)+e_k  = s0 + Re(b D b^H) + e_k,      s0 = Re(b V b^H)
 //     D     <- (rho rho^H) o (D - u u^H / var)                 (kfilter.cpp:197,204)
 //     x     <- rho o (x + u innov / var)                        (kfilter.cpp:194,201)
-// Per step every lane needs all u_j and rho_j: one 32-byte publish + P reads through the
-// group's exchange slots (LDS on the GPU); var/mean need one 2-value butterfly all-reduce.
 // sum log(var) is accumulated as a mantissa product + integer exponent sum, so the loop has no
-// log(); 1/var is the only division.
+// log(); 1/var is the only division.  The per-evaluation constants (b, c, s0, sigma^2) come from
+// closed forms instead of the reference's Vandermonde solve: see struct Model.
 #pragma once
 #include "carma_types.h"
 #include "carma_math.h"
@@ -86,40 +85,81 @@ CARMA_DEV Cx quad_root(double lq1, double lq2, int which)
     }
     return r;
 }
-// both members of the pair from one evaluation of the exponentials and the square root
-CARMA_DEV void quad_roots(double lq1, double lq2, Cx& r0, Cx& r1)
+// compile-time loop: f(IntC<J>{}) for J = J0 .. N-1 (DPP lane selectors are instruction immediates)
+template <int J>
+struct IntC {
+    static constexpr int value = J;
+};
+template <int J, int N, class F>
+CARMA_DEV void static_for(F&& f)
 {
-    double q1 = exp(lq1), q2 = exp(lq2);
-    double disc = q2 * q2 - 4.0 * q1;
-    const double sq = sqrt(fabs(disc));
-    if (disc > 0) {
-        r0 = {-0.5 * (q2 + sq), 0.0};
-        r1 = {-0.5 * (q2 - sq), 0.0};
-    } else {
-        const double im = -0.5 * sq;
-        r0 = {-0.5 * q2, im};
-        r1 = {-0.5 * q2, -im};
+    if constexpr (J < N) {
+        f(IntC<J>{});
+        static_for<J + 1, N>(f);
     }
 }
 
+// Root number i of a polynomial given by its m log quadratic-factor coefficients lq[0..m): the AR polynomial
+// (carpack.cpp:137-172) and the MA polynomial (carpack.cpp:522-552) share this parameterisation.
+CARMA_DEV Cx poly_root(const double* lq, int m, int i)
+{
+    if ((m & 1) && i == m - 1) return Cx{-exp(lq[m - 1]), 0.0};
+    const int pair = i >> 1;
+    return quad_root(lq[2 * pair], lq[2 * pair + 1], i & 1);
+}
+
 // Model quantities of one evaluation, as held by lane r of its group.
+//
+// Everything the recursion needs beyond the roots follows from three closed forms (alpha = monic AR polynomial with
+// roots omega_k, beta = MA polynomial, real coefficients, beta(0) = 1):
+//     b_r     = beta(omega_r)                                             rotated MA coefficient   kfilter.cpp:162
+//     kappa_r = beta(-omega_r) / (alpha'(omega_r) alpha(-omega_r))        (V b^H)_r = sigma^2 kappa_r
+//     Variance(omega, beta, sigma = 1) = sum_r b_r kappa_r                carpack.cpp:377-409
+// The middle one is the partial-fraction identity  sum_j beta(omega_j) / (alpha'(omega_j) (s + omega_j)) = -beta(-s) /
+// alpha(-s)  applied to  (V b^H)_r = -sigma^2 J_r sum_j conj(J_j b_j) / (omega_r + conj(omega_j)),  J_r = 1 /
+// alpha'(omega_r)  (kfilter.cpp:144-172; the root set is closed under conjugation).  The reference forms these
+// quantities through an LU solve of the Vandermonde system and p-term sums that cancel catastrophically when roots
+// cluster (the prior admits roots 1e-4 apart, carpack.cpp:330); the products above have no cancellation beyond the
+// root differences themselves.  Against 50-digit arithmetic on 27 000 prior-like parameter vectors this set-up is never
+// further from the exact value than the reference's own arithmetic and 2-7 orders of magnitude closer on the
+// ill-conditioned ones (tests/tools/proto/setup_v2.py).
 template <int P>
 struct Model {
-    Cx w;            // omega_r (own AR root)
+    Cx w;            // omega_r (own AR root; idle lanes of the group hold a copy of the last root)
     Cx wall[P];      // all roots (replicated)
-    double beta[P];  // MA coefficients, zero padded (replicated)
+    Cx b;            // b_r
+    Cx kap;          // kappa_r
     double sigsqr;   // driving-noise variance
+    double s0;       // Re(b V b^H): the stationary variance of the process
     double mu, scale;
     bool valid;      // prior bounds satisfied (or ignored)
+    bool sing;       // repeated AR root: singular eigenvector matrix (arma::solve throws, carpack.hpp:154-164)
 };
 
 // Root omega_rr of the AR polynomial encoded in theta (carpack.cpp:137-172), rr < P.
 template <int P>
 CARMA_DEV Cx own_ar_root(const double* theta, int rr)
 {
-    if ((P & 1) && rr == P - 1) return Cx{-exp(theta[3 + P - 1]), 0.0};
-    const int pair = rr >> 1;
-    return quad_root(theta[3 + 2 * pair], theta[3 + 2 * pair + 1], rr & 1);
+    return poly_root(theta + 3, P, rr);
+}
+
+// kappa_r and the repeated-root flag from the roots and beta(-omega_r)
+template <int P, class GrpT>
+CARMA_DEV void model_kappa(const GrpT& g, Model<P>& m, const Cx bm)
+{
+    const int r = g.lane();
+    const int rr = r < P ? r : P - 1;
+    Cx ap = {1.0, 0.0}, am = {1.0, 0.0};      // alpha'(omega_r) = prod_{l != r} (omega_r - omega_l),  alpha(-omega_r)
+#pragma unroll
+    for (int l = 0; l < P; l++) {
+        const Cx dl = csub(m.w, m.wall[l]);
+        const Cx sl = {-(m.w.re + m.wall[l].re), -(m.w.im + m.wall[l].im)};
+        ap = (l != rr) ? cmul(ap, dl) : ap;
+        am = cmul(am, sl);
+    }
+    const bool zero = (ap.re == 0.0 && ap.im == 0.0);
+    m.sing = g.sum((r < P && zero) ? 1.0 : 0.0) != 0.0;
+    m.kap = cdiv(bm, cmul(ap, am));
 }
 
 // theta -> Model  (ARRoots, ExtractMA, ExtractSigsqr, CheckPriorBounds)
@@ -129,75 +169,47 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
 {
     const int r = g.lane();
     const int rr = r < P ? r : P - 1;
-    // --- own AR root (carpack.cpp:137-172)
-    m.w = own_ar_root<P>(theta, rr);
+    // --- roots.  Slot s < P is AR root s (carpack.cpp:137-172), slot P + k is MA root k (carpack.cpp:522-552); lane l
+    // evaluates slot l, and slot l + G in a second pass when the group is too small for all of them
+    const bool ma0 = (r >= P) && (r - P < q);
+    const Cx root0 = ma0 ? poly_root(theta + 3 + P, q, r - P) : own_ar_root<P>(theta, rr);
 #pragma unroll
     for (int j = 0; j < P; j++) {
-        m.wall[j].re = g.bcast_u(m.w.re, j);
-        m.wall[j].im = g.bcast_u(m.w.im, j);
+        m.wall[j].re = g.bcast_u(root0.re, j);
+        m.wall[j].im = g.bcast_u(root0.im, j);
     }
-    // --- MA coefficients (carpack.cpp:522-580, polycoefs :742-756); identical in every lane
-#pragma unroll
-    for (int i = 0; i < P; i++) m.beta[i] = 0.0;
-    if (q == 0) {
-        m.beta[0] = 1.0;
-    } else {
-        Cx cf[P];  // coefficients of prod (x - root_i), cf[0] = 1
-#pragma unroll
-        for (int i = 0; i < P; i++) cf[i] = {0.0, 0.0};
-        cf[0] = {1.0, 0.0};
-        auto fold = [&](const Cx root, const int i) __attribute__((always_inline)) {   // cf *= (x - root), root number i
-#pragma unroll
-            for (int k = P - 1; k >= 1; k--) {
-                if (k <= i + 1) cf[k] = csub(cf[k], cmul(root, cf[k - 1]));
-            }
-        };
-#pragma unroll
-        for (int i0 = 0; i0 < P - 1; i0 += 2) {        // one quadratic factor (two roots) at a time
-            if (i0 + 1 < q) {
-                Cx r0, r1;
-                quad_roots(theta[3 + P + i0], theta[3 + P + i0 + 1], r0, r1);
-                fold(r0, i0);
-                if (i0 + 1 < P - 1) fold(r1, i0 + 1);
-            } else if (i0 < q) {                       // odd q: the last root is real (carpack.cpp:548-552)
-                fold(Cx{-exp(theta[3 + P + q - 1]), 0.0}, i0);
-            }
-        }
-        double cq = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; i++) cq = (i == q) ? cf[i].re : cq;
-#pragma unroll
-        for (int i = 0; i < P; i++) {      // beta_i = pc[q-i]/pc[q], i <= q
-            double v = 0.0;
-#pragma unroll
-            for (int j = 0; j < P; j++) v = (j == q - i) ? cf[j].re : v;
-            m.beta[i] = (i <= q) ? v / cq : 0.0;
-        }
+    m.w = (r < P) ? root0 : m.wall[P - 1];
+    constexpr int NMA = P > 1 ? P - 1 : 1;       // q <= P - 1
+    constexpr int MA0 = G - P;                   // MA roots held by the first pass
+    Cx root1 = {-1.0, 0.0};
+    if constexpr (NMA > MA0) {
+        const bool ma1 = MA0 + r < q;
+        root1 = poly_root(theta + 3 + P, q, ma1 ? MA0 + r : 0);
     }
-    // --- sigma^2 = theta0^2 / Variance(omega, beta, 1)   (carpack.cpp:377-409)
-    {
-        Cx dp = {1.0, 0.0};
-#pragma unroll
-        for (int l = 0; l < P; l++) {
-            Cx a = csub(m.wall[l], m.w);
-            Cx b = {m.wall[l].re + m.w.re, -m.wall[l].im + m.w.im};
-            Cx f = cmul(a, b);
-            dp = (l != rr) ? cmul(dp, f) : dp;
+    // --- b_r = beta(omega_r) = prod_k (mu_k - omega_r) / mu_k,  beta(-omega_r) = prod_k (mu_k + omega_r) / mu_k;
+    //     prod_k mu_k is real (conjugate pairs and real roots)
+    Cx pb = {1.0, 0.0}, pm = {1.0, 0.0}, pmu = {1.0, 0.0};
+    static_for<0, NMA>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        Cx mu;
+        if constexpr (k < MA0) {
+            mu = {g.bcast_u(root0.re, P + k), g.bcast_u(root0.im, P + k)};
+        } else {
+            mu = {g.bcast_u(root1.re, k - MA0), g.bcast_u(root1.im, k - MA0)};
         }
-        Cx denom = cscale(dp, -2.0 * m.w.re);
-        Cx s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, pw1 = {1.0, 0.0}, pw2 = {1.0, 0.0};
-        Cx nw = {-m.w.re, -m.w.im};
-#pragma unroll
-        for (int l = 0; l < P; l++) {
-            s1 = cadd(s1, cscale(pw1, m.beta[l]));
-            s2 = cadd(s2, cscale(pw2, m.beta[l]));
-            pw1 = cmul(pw1, m.w);
-            pw2 = cmul(pw2, nw);
+        if (k < q) {
+            pb = cmul(pb, csub(mu, m.w));
+            pm = cmul(pm, cadd(mu, m.w));
+            pmu = cmul(pmu, mu);
         }
-        Cx term = cdiv(cmul(s1, s2), denom);
-        double var1 = g.sum(r < P ? term.re : 0.0);
-        m.sigsqr = theta[0] * theta[0] / var1;
-    }
+    });
+    const double rmu = 1.0 / pmu.re;
+    m.b = cscale(pb, rmu);
+    model_kappa<P>(g, m, cscale(pm, rmu));
+    // --- sigma^2 = theta0^2 / Variance(omega, beta, 1)   (carpack.cpp:377-409, carpack.hpp:316-319, 391-395)
+    const double var1 = g.sum(r < P ? (m.b.re * m.kap.re - m.b.im * m.kap.im) : 0.0);
+    m.sigsqr = theta[0] * theta[0] / var1;
+    m.s0 = theta[0] * theta[0];                  // = sigma^2 Variance(1): var_0 = sigma_y^2 + yerr_0^2 (kfilter.cpp:180-182)
     m.scale = theta[1];
     m.mu = theta[2];
     // --- prior bounds (carpack.cpp:314-374, unique_roots :709-732)
@@ -223,6 +235,33 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
         double ysigma = theta[0], ms = theta[1];
         if (nviol != 0.0 || (ysigma > pr.max_stdev) || (ysigma < 0) || (ms < 0.5) || (ms > 2.0)) m.valid = false;
     }
+}
+
+// (sigma^2, roots, MA coefficients) -> Model: the KalmanFilterp constructor (kfilter.hpp:303-334).  om_re_im = p
+// (re, im) pairs in the order ARRoots emits (conjugate pairs adjacent, the C ABI checks it), ma = p coefficients
+// (zero padded, kfilter.hpp:318-320).
+template <int P, int G, class GrpT>
+CARMA_DEV void model_from_roots(const GrpT& g, const double* om_re_im, const double* ma, double sigsqr, Model<P>& m)
+{
+    const int r = g.lane();
+    const int rr = r < P ? r : P - 1;
+    m.w = {om_re_im[2 * rr], om_re_im[2 * rr + 1]};
+#pragma unroll
+    for (int j = 0; j < P; j++) m.wall[j] = {om_re_im[2 * j], om_re_im[2 * j + 1]};
+    Cx b = {0.0, 0.0}, bm = {0.0, 0.0};
+    const Cx nw = {-m.w.re, -m.w.im};
+#pragma unroll
+    for (int i = P - 1; i >= 0; i--) {           // Horner: beta(omega_r), beta(-omega_r)
+        b = cadd(cmul(b, m.w), Cx{ma[i], 0.0});
+        bm = cadd(cmul(bm, nw), Cx{ma[i], 0.0});
+    }
+    m.b = b;
+    model_kappa<P>(g, m, bm);
+    m.sigsqr = sigsqr;
+    m.s0 = sigsqr * g.sum(r < P ? (m.b.re * m.kap.re - m.b.im * m.kap.im) : 0.0);
+    m.mu = 0.0;
+    m.scale = 1.0;
+    m.valid = true;
 }
 
 // Running -0.5*sum(log var) - 0.5*sum(innov^2/var) without a log in the loop.
@@ -258,7 +297,8 @@ struct LogLikAcc {
     }
 };
 
-// Per-evaluation constants produced by Reset, as held by lane r of the group.
+// Per-evaluation constants of the recursion (the part of Reset, kfilter.cpp:138-186, that the loop keeps), as held by
+// lane r of the group.
 template <int P>
 struct FilterConsts {
     Cx b_own;     // rotated MA coefficient b_r
@@ -267,95 +307,21 @@ struct FilterConsts {
     Cx ball[P];   // b_j for all j
     double s0;    // Re(b V b^H)
     bool sing;    // singular Vandermonde system (two equal roots)
-    Cx Jown;      // J_r, last column of E^{-1}
-    Cx Jall[P];   // J_j for all j
 };
 
-// Reset (kfilter.cpp:138-186).
-// Lane r holds the powers of its own root (column r of the Vandermonde matrix E_ir = omega_r^i) for the
-// rotated MA coefficient b_r; the solve E J = e_{p-1} is done in closed form (see below; the first
-// version of this file ran a lane-distributed LU with partial pivoting, 6.4k cycles against 1k).
 template <int P, int G, class GrpT>
 CARMA_DEV void filter_reset(const GrpT& g, const Model<P>& m, FilterConsts<P>& fc)
 {
-    const int r = g.lane();
-    const bool act = r < P;
-    Cx a[P], rhs[P];
-    {
-        Cx pw = {1.0, 0.0};
+    const bool act = g.lane() < P;
+    fc.b_own = m.b;
+    fc.b_msk = {act ? m.b.re : 0.0, act ? m.b.im : 0.0};
+    fc.c_own = cscale(m.kap, m.sigsqr);
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            a[i] = pw;
-            pw = cmul(pw, m.w);
-        }
-    }
-    Cx b_own = {0.0, 0.0};   // rotated MA coefficient b_r = sum_i beta_i omega_r^i (kfilter.cpp:162)
-#pragma unroll
-    for (int i = 0; i < P; i++) b_own = cadd(b_own, cscale(a[i], m.beta[i]));
-
-    // J = E^{-1} e_{p-1} (kfilter.cpp:144-160).  E is the Vandermonde matrix of the roots, and the last
-    // column of its inverse has the closed form J_r = 1 / prod_{l != r} (omega_r - omega_l) (the
-    // leading coefficients of the Lagrange basis), which replaces the LU solve: p-1 complex products
-    // and one reciprocal per lane, accurate to a few ulp whatever the conditioning of E (the reference's
-    // LAPACK LU loses cond(E) eps; tests arbitrate such cases against 50-digit arithmetic).
-    // Singular E <=> two equal roots <=> a zero product: the reference's arma::solve throws, -> -inf.
-    Cx dprod = {1.0, 0.0};
-    const int rr = r < P ? r : P - 1;
-#pragma unroll
-    for (int l = 0; l < P; l++) {
-        const Cx f = csub(m.w, m.wall[l]);
-        dprod = (l != rr) ? cmul(dprod, f) : dprod;
-    }
-    const bool zero = (dprod.re == 0.0 && dprod.im == 0.0);
-    const bool sing = g.sum((act && zero) ? 1.0 : 0.0) != 0.0;
-    const Cx Jown = cdiv(Cx{1.0, 0.0}, dprod);
-#pragma unroll
-    for (int j = 0; j < P; j++) rhs[j] = {g.bcast_u(Jown.re, j), g.bcast_u(Jown.im, j)};
-    // rhs[] now holds J (replicated).  b for all lanes:
-    Cx ball[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-        ball[j].re = g.bcast_u(b_own.re, j);
-        ball[j].im = g.bcast_u(b_own.im, j);
-    }
-    // own row of V (kfilter.cpp:165-172) folded straight into c_r = sum_j V_rj conj(b_j)
-    Cx Jr = {0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < P; j++) Jr = csel(j == r, rhs[j], Jr);
-    Cx c_own = {0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-        Cx num = cmulc(cscale(Jr, -m.sigsqr), rhs[j]);
-        Cx den = {m.w.re + m.wall[j].re, m.w.im - m.wall[j].im};
-        Cx v = cdiv(num, den);
-        c_own = cadd(c_own, cmulc(v, ball[j]));
-    }
-    fc.s0 = g.sum(act ? (b_own.re * c_own.re - b_own.im * c_own.im) : 0.0);
-    fc.b_own = b_own;
-    fc.b_msk = {act ? b_own.re : 0.0, act ? b_own.im : 0.0};
-    fc.c_own = c_own;
-#pragma unroll
-    for (int j = 0; j < P; j++) fc.ball[j] = ball[j];
-    fc.sing = sing;
-    fc.Jown = Jown;
-#pragma unroll
-    for (int j = 0; j < P; j++) fc.Jall[j] = rhs[j];
+    for (int j = 0; j < P; j++) fc.ball[j] = {g.bcast_u(m.b.re, j), g.bcast_u(m.b.im, j)};
+    fc.s0 = m.s0;
+    fc.sing = m.sing;
 }
 
-
-// compile-time loop: f(IntC<J>{}) for J = J0 .. N-1 (DPP lane selectors are instruction immediates)
-template <int J>
-struct IntC {
-    static constexpr int value = J;
-};
-template <int J, int N, class F>
-CARMA_DEV void static_for(F&& f)
-{
-    if constexpr (J < N) {
-        f(IntC<J>{});
-        static_for<J + 1, N>(f);
-    }
-}
 
 // Where the transition factors rho_j(k) = exp(omega_j dt_k) of a group come from.
 // RhoInline: every lane computes its own factor one step ahead and shares it through the group's
@@ -433,102 +399,6 @@ struct RhoPair {
         if constexpr (PH == 1) begin2(dt1, dt2);
     }
 };
-
-// Update loop (kfilter.cpp:189-215) + log-likelihood sum (carpack.hpp:167-171), given Reset's
-// constants.  One LDS all-gather per step carries everything the lanes owe each other:
-//   slot_r = { u_r, Re(b_r w_r), Re(b_r x_r) }      (+ rho_r in the second array)
-// Every lane adds the P partial sums in the same order, so var_k / mean_k are bit-identical across
-// the group without a butterfly, and the reduction shares the round trip of the gain exchange.
-// While the reads are in flight the lane forms the state-independent products and (RhoInline)
-// the next step's exp/sincos.  Step k consumes var_{k-1}, innov_{k-1}:
-//   s = 1/var;  x <- rho o (x + u s innov);  D <- rho rho^H o (D - u u^H s);  chi2 += innov^2 s.
-template <int P, int G, bool WRITE_MV, class GrpT, class RhoSrc>
-CARMA_DEV double filter_loop(const GrpT& g, const Model<P>& m, const FilterConsts<P>& fc, RhoSrc& src,
-                             const double4* __restrict__ series, int n, double* mean_out, double* var_out)
-{
-    const int r = g.lane();
-    const Cx b_msk = fc.b_msk, c_own = fc.c_own;
-    const double s0 = fc.s0;
-    Cx ball[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) ball[j] = fc.ball[j];
-
-    Cx D[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) D[j] = {0.0, 0.0};
-    Cx x = {0.0, 0.0};
-    Cx u = c_own;              // (P b^H)_r with P = V                    kfilter.cpp:173
-    double pvr = 0.0, pmr = 0.0;
-    LogLikAcc acc;
-    acc.init();
-    // Series records are fetched ahead of use (scalar loads share the LDS wait counter, so a load
-    // issued right before its use would expose its latency on every LDS wait).
-    double4 rprev = series[0];                       // record k-1: y, yerr^2 for var_{k-1}
-    double4 rcur = series[n > 1 ? 1 : 0];            // record k  : dt_k
-    double4 rnxt = series[n > 2 ? 2 : n - 1];        // record k+1
-    src.begin(1, rcur.x);
-    double var = 0.0, innov = 0.0;
-    for (int k = 1; k <= n; k++) {
-        const bool last = (k == n);                  // extra pass: only closes var_{n-1}, mean_{n-1}
-        const double4 rnn = series[(k + 2 < n) ? k + 2 : n - 1];
-        g.publish(u.re, u.im, pvr, pmr);
-        if (!last) src.publish(k);
-        double4 o[P];
-#pragma unroll
-        for (int j = 0; j < P; j++) o[j] = g.peek(j);
-        Cx rho, rj[P];
-        if (!last) src.fetch(k, rho, rj);
-        g.done_reading();
-        if (!last) src.prepare(k + 1, rnxt.x);
-        // var_{k-1}, mean_{k-1} (kfilter.cpp:180-182, 207-210), innovation (:184, :213)
-        double pv = o[0].z, pm = o[0].w;
-#pragma unroll
-        for (int j = 1; j < P; j++) {
-            pv += o[j].z;
-            pm += o[j].w;
-        }
-        var = s0 + pv + rprev.z * m.scale;
-        innov = (rprev.y - m.mu) - pm;
-        acc.add_var(var);
-        if (WRITE_MV && r == 0) {
-            mean_out[k - 1] = pm;
-            var_out[k - 1] = var;
-        }
-        const double s = recip(var);
-        const double si = s * innov;
-        acc.chi2 += innov * si;
-        if (last) break;
-        // state: x <- rho o (x + g innov)      (kfilter.cpp:191-194, 200-201)
-        x = cmul(rho, Cx{x.re + u.re * si, x.im + u.im * si});
-        Cx w0, w1;                                   // two accumulators: halves the dependent chain
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-            const Cx uj = {o[j].x, o[j].y};
-            const Cx t = cmulc(u, uj);                   // u_r conj(u_j)           (independent of s)
-            const Cx R = cmulc(rho, rj[j]);              // rho_r conj(rho_j)       (independent of s)
-            const Cx d = {fma(-t.re, s, D[j].re), fma(-t.im, s, D[j].im)};      // kfilter.cpp:197
-            D[j] = cmul(R, d);                           // kfilter.cpp:204 (minus V on both sides)
-            // w += D_rj conj(b_j)                       (D b^H)_r
-            Cx& w = (j & 1) ? w1 : w0;
-            if (j < 2) {
-                w.re = fma(D[j].re, ball[j].re, D[j].im * ball[j].im);
-                w.im = fma(D[j].im, ball[j].re, -(D[j].re * ball[j].im));
-            } else {
-                w.re = fma(D[j].re, ball[j].re, fma(D[j].im, ball[j].im, w.re));
-                w.im = fma(D[j].im, ball[j].re, fma(-D[j].re, ball[j].im, w.im));
-            }
-        }
-        const Cx w = (P > 1) ? cadd(w0, w1) : w0;
-        u = cadd(w, c_own);
-        // b_msk is zero in the idle lanes of a group, so their partial sums vanish
-        pvr = b_msk.re * w.re - b_msk.im * w.im;     // Re(b_r w_r)
-        pmr = b_msk.re * x.re - b_msk.im * x.im;     // Re(b_r x_r)
-        rprev = rcur;
-        rcur = rnxt;
-        rnxt = rnn;
-    }
-    return acc.total();
-}
 
 // Diagnostic build only (-DCARMA_STAMPS): where a step spends its cycles (shares, not run time).
 #if defined(CARMA_STAMPS) && defined(__HIPCC__)
@@ -888,9 +758,6 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
     FilterConsts<P> fc;
     filter_reset<P, G>(g, m, fc);
     RhoInline<P, GrpT> src{g, m.w, Cx{1.0, 0.0}};
-#ifdef CARMA_COMPLEX_LOOP
-    double ll = filter_loop<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
-#else
     double ll;
     if constexpr (G == 16) {
         ll = filter_loop_row<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
@@ -904,7 +771,6 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
             ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
         }
     }
-#endif
     *singular = fc.sing;
     return ll;
 }

@@ -14,15 +14,11 @@
 // series (24 B/datum, shared by every evaluation and L2/scalar-cache resident) + 8(d+1) B/eval.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-#include <cstring>
-
 #include "grp_device.h"
 #include "carma_core.h"
 #include "carma_ring.h"
 #include "carma_predict.h"
 #include "carma_pipe3l.h"
-#include "carma_scan_dev.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -91,22 +87,6 @@ __global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* 
 #endif
 }
 
-// Time-parallel filter (carma_scan.h): one evaluation per wave, every lane a block of SMAX consecutive data.
-template <int P, int SMAX>
-__global__ __launch_bounds__(64) void k_logdens_carma_scan(const double* __restrict__ theta, int B, int d, int q,
-                                                           const double4* __restrict__ series, int n, Prior pr,
-                                                           int ignore_prior, double* __restrict__ out)
-{
-    extern __shared__ double4 smem4[];
-    double2* xch = reinterpret_cast<double2*>(smem4);
-    double* sh = reinterpret_cast<double*>(xch + ScanLds<P>::NPAIR * 64);
-    const int lane = threadIdx.x;
-    const long e = blockIdx.x;                               // one workgroup per evaluation: the grid is B wide
-    (void)B;
-    const double ll = scan_logdensity<P, SMAX>(theta + e * d, q, series, n, pr, ignore_prior, lane, xch, sh);
-    if (lane == 0) out[e] = ll;
-}
-
 // Smallest launches (<= 1024 evaluations): covariance wave + mean wave + two producer waves per 4 evaluations, in a
 // co-rotating frame (carma_pipe3l.h).  256 threads, 82 KiB of LDS: one workgroup per CU.
 template <int P>
@@ -121,14 +101,8 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     long e = ((long)blockIdx.x * 64 + lane64) / 16;
     const bool live = e < B;
     if (!live) e = B - 1;
-#ifdef CARMA_DBG
-    const long long dbg_k0 = clock64();
-#endif
     if (wave >= 2) {
         pipe3l_produce<P>(g, wave - 2, theta + e * d, series, n, ring, [](int) {});
-#ifdef CARMA_DBG
-        if (blockIdx.x == 0 && lane64 == 0) printf("P%d total %lld\n", wave - 2, clock64() - dbg_k0);
-#endif
         return;
     }
     Model<P> m;
@@ -137,20 +111,11 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     filter_reset<P, 16>(g, m, fc);
     RowConsts<P> rc;
     row_consts<P>(g, m, fc, rc);
-#ifdef CARMA_DBG
-    if (blockIdx.x == 0 && lane64 == 0) printf("wave %d setup %lld\n", wave, clock64() - dbg_k0);
-#endif
     if (wave == 0) {
         pipe3l_cov<P>(g, m, rc, series, n, ring);
-#ifdef CARMA_DBG
-        if (blockIdx.x == 0 && lane64 == 0) printf("A total %lld\n", clock64() - dbg_k0);
-#endif
         return;
     }
     double ll = pipe3l_mean<P>(g, m, rc, series, n, ring);
-#ifdef CARMA_DBG
-    if (blockIdx.x == 0 && lane64 == 0) printf("B total %lld\n", clock64() - dbg_k0);
-#endif
     ll += log_prior(m.scale, pr.measerr_dof);
     const double ninf = -1.0 / 0.0;
     if (fc.sing || !m.valid) ll = ninf;
@@ -176,17 +141,7 @@ __global__ __launch_bounds__(64) void k_kfilter_carma(const double* __restrict__
     const int tid = threadIdx.x;
     Grp<G> g{xch, tid & 63, xch2};
     Model<P> m;
-    const int r = g.lane() < P ? g.lane() : P - 1;
-    m.w = {om_re_im[2 * r], om_re_im[2 * r + 1]};
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-        m.wall[j] = {om_re_im[2 * j], om_re_im[2 * j + 1]};
-        m.beta[j] = ma[j];
-    }
-    m.sigsqr = sigsqr;
-    m.mu = 0.0;
-    m.scale = 1.0;
-    m.valid = true;
+    model_from_roots<P, G>(g, om_re_im, ma, sigsqr, m);
     bool sing;
     // every group of the wave runs the same evaluation and stores the same values
     filter_run<P, G, true>(g, m, series, n, mean, var, &sing);
@@ -214,17 +169,7 @@ __global__ __launch_bounds__(64) void k_predict_carma(const double* __restrict__
     const bool live = e < M;
     if (!live) e = M - 1;
     Model<P> m;
-    const int r = g.lane() < P ? g.lane() : P - 1;
-    m.w = {om_re_im[2 * r], om_re_im[2 * r + 1]};
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-        m.wall[j] = {om_re_im[2 * j], om_re_im[2 * j + 1]};
-        m.beta[j] = ma[j];
-    }
-    m.sigsqr = sigsqr;
-    m.mu = 0.0;
-    m.scale = 1.0;
-    m.valid = true;
+    model_from_roots<P, G>(g, om_re_im, ma, sigsqr, m);
     double pm, pv;
     bool sing;
     predict_run<P, G>(g, m, series, n, tpred[e], &pm, &pv, &sing);
@@ -269,17 +214,6 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     // that) a later 81 KiB launch failed with hipErrorUnknown.  The call costs ~1 us on the host and
     // the launches are asynchronous.
     auto big_lds = [](const void* kf) { return hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
-    if constexpr (P <= 5) {
-        // time-parallel filter (carma_scan.h), opt-in while it is being evaluated: CARMA_LOGDENS_KERNEL=scan
-        const char* ek = getenv("CARMA_LOGDENS_KERNEL");
-        const bool want_scan = ek && strcmp(ek, "scan") == 0;
-        if (want_scan && n >= 2 && n <= 64 * 5 && B <= 4096) {
-            const size_t lds = ScanLds<P>::BYTES;
-            hipLaunchKernelGGL((k_logdens_carma_scan<P, 5>), dim3((unsigned)B), dim3(64), lds, st, theta, B, d, q, series, n, pr,
-                               ignore_prior, out);
-            return hipGetLastError();
-        }
-    }
     if (rows <= 256 && n >= 8) {
         // one workgroup per CU: covariance wave + mean wave + two producer waves, co-rotating frame (carma_pipe3l.h)
         const size_t lds = Pipe3LGeom<P>::BYTES;

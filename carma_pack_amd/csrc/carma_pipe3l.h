@@ -250,9 +250,6 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
         const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
-#ifdef CARMA_DBG
-        const long long dbg_t0 = clock64();
-#endif
         const int len = (n - c * C < C) ? n - c * C : C;
         if (len == C) {
             // yerr_j^2 is wave-uniform: sixteen scalar loads from the series itself, waited for ONCE (scalar-memory and
@@ -266,9 +263,6 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
 #pragma unroll 1
             for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u, series[j0 + s].z);
         }
-#ifdef CARMA_DBG
-        if (blockIdx.x == 0 && lane == 0 && (c <= 1 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "A", c, clock64() - dbg_t0, fm);
-#endif
     }
     __syncthreads();                                          // barrier nc
 }
@@ -329,9 +323,6 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
         const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
-#ifdef CARMA_DBG
-        const long long dbg_t0 = clock64();
-#endif
         const int len = (n - c * C < C) ? n - c * C : C;
         if (len == C) {
             // y_j: scalar loads, as yerr_j^2 in the covariance wave
@@ -344,9 +335,6 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
 #pragma unroll 1
             for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u, series[j0 + s].y);
         }
-#ifdef CARMA_DBG
-        if (blockIdx.x == 0 && lane == 0 && (c <= 1 || c == 4)) printf("%s chunk %d work %lld cycles flags %x\n", "B", c, clock64() - dbg_t0, fm);
-#endif
     }
     return acc.total();
 }

@@ -42,16 +42,12 @@ static void kfilter_one(const double* om_re, const double* om_im, const double* 
     constexpr int G = GroupOf<P>::value;
     run_group<G>([&](const Grp<G>& g) {
         Model<P> m;
-        int r = g.lane() < P ? g.lane() : P - 1;
-        m.w = {om_re[r], om_im[r]};
+        double om[2 * P];
         for (int j = 0; j < P; j++) {
-            m.wall[j] = {om_re[j], om_im[j]};
-            m.beta[j] = ma[j];
+            om[2 * j] = om_re[j];
+            om[2 * j + 1] = om_im[j];
         }
-        m.sigsqr = sigsqr;
-        m.mu = 0.0;
-        m.scale = 1.0;
-        m.valid = true;
+        model_from_roots<P, G>(g, om, ma, sigsqr, m);
         bool s;
         double l = filter_run<P, G, true>(g, m, series, n, mean, var, &s);
         if (g.lane() == 0) {
@@ -234,16 +230,12 @@ static void predict_one(const double* om_re, const double* om_im, const double* 
     constexpr int G = GroupOf<P>::value;
     run_group<G>([&](const Grp<G>& g) {
         Model<P> m;
-        int r = g.lane() < P ? g.lane() : P - 1;
-        m.w = {om_re[r], om_im[r]};
+        double om[2 * P];
         for (int j = 0; j < P; j++) {
-            m.wall[j] = {om_re[j], om_im[j]};
-            m.beta[j] = ma[j];
+            om[2 * j] = om_re[j];
+            om[2 * j + 1] = om_im[j];
         }
-        m.sigsqr = sigsqr;
-        m.mu = 0.0;
-        m.scale = 1.0;
-        m.valid = true;
+        model_from_roots<P, G>(g, om, ma, sigsqr, m);
         double a, b;
         bool s;
         predict_run<P, G>(g, m, series, n, tp, &a, &b, &s);
@@ -279,81 +271,4 @@ extern "C" void emu_predict_car1(double sigsqr, double omega, const double* seri
     for (int i = 0; i < M; i++) predict_car1(sigsqr, omega, s4, n, tpred[i], pmean + i, pvar + i);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Time-parallel filter (carma_scan.h): the three phases executed lane by lane on the host.
-#include "../../carma_pack_amd/csrc/carma_scan.h"
-
-template <int P>
-static double scan_loglik_host(const double* wre, const double* wim, const int* cpx, const double* h, const double* Vz,
-                               double mu, double scale, const double4* series, int n, int nlanes)
-{
-    constexpr int SMAX = 8;
-    ScanModel<P> m;
-    for (int i = 0; i < P; i++) {
-        m.wre[i] = wre[i];
-        m.wim[i] = wim[i];
-        m.cpx[i] = cpx[i] != 0;
-        m.h[i] = h[i];
-    }
-    for (int i = 0; i < P; i++)
-        for (int j = i; j < P; j++) m.Vz[sym_idx<P>(i, j)] = Vz[i * P + j];
-    m.s0 = 0.0;
-    for (int i = 0; i < P; i++) {
-        double a = 0.0;
-        for (int j = 0; j < P; j++) a += sym_get<P>(m.Vz, i, j) * m.h[j];
-        m.c[i] = a;
-        m.s0 += m.h[i] * a;
-    }
-    m.mu = mu;
-    m.scale = scale;
-    const int s = (n + nlanes - 1) / nlanes;
-    if (s > SMAX) return 0.0 / 0.0;
-    std::vector<ScanElem<P>> el(nlanes), nx(nlanes);
-    std::vector<std::array<ScanPhi<P>, SMAX>> phis(nlanes);
-    for (int l = 0; l < nlanes; l++) {
-        const int k0 = l * s, k1 = std::min(n, (l + 1) * s);
-        ScanPhi<P>(&ph)[SMAX] = *reinterpret_cast<ScanPhi<P>(*)[SMAX]>(phis[l].data());
-        if (k0 < k1)
-            scan_block_element<P, SMAX>(m, series, k0, k1, l == 0, el[l], ph);
-        else
-            scan_identity<P>(el[l]);
-    }
-    for (int d = 1; d < nlanes; d *= 2) {
-        for (int l = 0; l < nlanes; l++) {
-            if (l >= d)
-                scan_combine<P>(el[l - d], el[l], nx[l]);
-            else
-                nx[l] = el[l];
-        }
-        el.swap(nx);
-    }
-    double total = 0.0;
-    for (int l = 0; l < nlanes; l++) {
-        const int k0 = l * s, k1 = std::min(n, (l + 1) * s);
-        if (k0 >= k1) continue;
-        LogLikAcc acc;
-        acc.init();
-        double m0[P], C0[ScanDim<P>::NS];
-        for (int i = 0; i < P; i++) m0[i] = l ? el[l - 1].b[i] : 0.0;
-        for (int i = 0; i < ScanDim<P>::NS; i++) C0[i] = l ? el[l - 1].C[i] : 0.0;
-        const ScanPhi<P>(&ph)[SMAX] = *reinterpret_cast<const ScanPhi<P>(*)[SMAX]>(phis[l].data());
-        scan_block_loglik<P, SMAX>(m, series, k0, k1, l == 0, m0, C0, ph, acc);
-        total += acc.total();
-    }
-    return total;
-}
-
-extern "C" double emu_scan_loglik(int p, const double* wre, const double* wim, const int* cpx, const double* h,
-                                  const double* Vz, double mu, double scale, const double* series, int n, int nlanes)
-{
-    const double4* s4 = reinterpret_cast<const double4*>(series);
-    switch (p) {
-        case 2: return scan_loglik_host<2>(wre, wim, cpx, h, Vz, mu, scale, s4, n, nlanes);
-        case 3: return scan_loglik_host<3>(wre, wim, cpx, h, Vz, mu, scale, s4, n, nlanes);
-        case 4: return scan_loglik_host<4>(wre, wim, cpx, h, Vz, mu, scale, s4, n, nlanes);
-        case 5: return scan_loglik_host<5>(wre, wim, cpx, h, Vz, mu, scale, s4, n, nlanes);
-        case 6: return scan_loglik_host<6>(wre, wim, cpx, h, Vz, mu, scale, s4, n, nlanes);
-        default: return 0.0 / 0.0;
-    }
-}
 

@@ -5,14 +5,15 @@ import numpy as np
 from carma_pack_amd.synth import irregular_series, log_quads_from_roots, prior_like_theta, theta_batch  # noqa: F401,E402
 
 
-def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=6, arb_factor=3.0):
+def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=40, arb_factor=1.0):
     """north_star bar: |got-want| <= 1e-10 |want| where finite; identical -inf/NaN pattern.
 
-    Where cond(EigenMat) >~ 1e6 two correct double-precision implementations of kfilter.cpp differ
-    by more than 1e-10 (SURVEY.md §7 "1e-10 parity vs conditioning").  If `arbiter(i)` is given it
-    returns the 50-digit value of entry i (tests/mp_truth.py); such an entry passes when the GPU is
-    within 1e-10 of the exact value or no further from it than arb_factor (3) x the oracle is ("no worse
-    than the reference").  At most `max_arbitrated` entries may need arbitration."""
+    Where roots cluster (cond(EigenMat) >~ 1e6; the prior admits roots 1e-4 apart) the REFERENCE's arithmetic --
+    an LU solve of the Vandermonde system and p-term sums that cancel -- is itself 1e-10 ... 1e-3 away from the exact
+    value of its own formulas, so its restatement cannot be the yardstick there.  If `arbiter(i)` is given it returns
+    the 50-digit value of entry i (tests/mp_truth.py); an entry that differs from the oracle by more than rtol passes
+    only when the GPU is within rtol of the exact value or NO FURTHER from it than the oracle is (arb_factor 1.0:
+    "never worse than the reference").  `max_arbitrated` only bounds the time spent in 50-digit arithmetic."""
     got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
     assert got.shape == want.shape
     fin = np.isfinite(want)

@@ -36,7 +36,7 @@ def test_emu_orders(p, q):
     for ign in (False, True):
         got = emu.logdensity_carma(t, y, yerr, p, q, th, pr, ignore_prior=ign)
         assert_parity(got, m.logdensity_batch(th, ignore_prior=ign), 1e-10, "emu p=%d q=%d" % (p, q),
-                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arbitrated=2)
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
 
 
 @pytest.mark.parametrize("p,q", [(2, 1), (3, 0), (4, 3), (5, 3), (6, 2), (7, 6)])
@@ -55,7 +55,7 @@ def test_emu_row_loop(p, q, golden_dir):
     from mp_truth import loglik_truth
     got = emu.logdensity_carma_row(t, y, yerr, p, q, th, pr)
     assert_parity(got, m.logdensity_batch(th), 1e-10, "emu row p=%d q=%d" % (p, q),
-                  arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arbitrated=2)
+                  arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
     ref = emu.logdensity_carma(t, y, yerr, p, q, th, pr)
     fin = np.isfinite(ref)
     assert np.array_equal(fin, np.isfinite(got))

@@ -190,3 +190,35 @@ def test_simulate_is_a_draw_from_the_dense_gp_conditional(cm, golden_dir):
     maxlag = 30
     acf = np.array([np.sum(zc[k:] * zc[:nsim - k]) for k in range(1, maxlag + 1)]) / np.sum(zc * zc)
     assert np.sum(np.abs(acf) > 1.96 / np.sqrt(nsim)) <= 5, acf            # binomial(30, 0.05): P(>5) < 1 %
+
+
+def test_car1_sample_predict_simulate_assess_fit(cm):
+    """CarmaModel(p=1).run_mcmc(...).predict / simulate / assess_fit (carma_pack.py:687-837 on a Car1Sample, whose
+    makeKalmanFilter builds a KalmanFilter1, :925-948) against the oracle's CAR(1) Predict and Filter."""
+    import oracle as orc
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "car1_n100.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    model = cm.CarmaModel(t, y, yerr, p=1)
+    sample = model.run_mcmc(200, nburnin=100, seed=5)
+    assert isinstance(sample, cm.Car1Sample)
+    for bestfit in ("map", "median", "mean"):
+        kf, mu = sample.makeKalmanFilter(bestfit)
+        tp = np.r_[t[0] - 3.0, 0.5 * (t[10] + t[11]), t[40], t[-1] + 7.5]            # backcast, interpolation, datum, forecast
+        pm, pv = sample.predict(tp, bestfit=bestfit)
+        wm, wv = orc.predict_car1(t, y - mu, yerr, kf._sigsqr, kf._omega, tp)
+        np.testing.assert_allclose(pm - mu, wm, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(pv, wv, rtol=1e-9)
+        m1, v1 = sample.predict(float(tp[3]), bestfit=bestfit)                        # scalar in, scalars out
+        assert m1 == pm[3] and v1 == pv[3]
+    fit = sample.assess_fit(bestfit="map", nplot=32)
+    kf, mu = sample.makeKalmanFilter("map")
+    om, ov = orc.kfilter_car1(t, y - mu, yerr, kf._sigsqr, kf._omega)
+    np.testing.assert_allclose(fit["std_resid"], (y - mu - om) / np.sqrt(ov), rtol=1e-8, atol=1e-10)
+    assert fit["mean"].shape == (32,) and np.all(fit["var"] > 0) and abs(fit["resid_acf"][0] - 1.0) < 1e-12
+    np.random.seed(3)
+    ts = np.r_[t[-1] + 1.0, t[-1] + 2.0, 0.5 * (t[3] + t[4])]
+    draws = np.array([sample.simulate(ts, bestfit="map") for _ in range(300)])
+    assert draws.shape == (300, 3)
+    pm, pv = sample.predict(np.sort(ts)[:1], bestfit="map")                           # first time visited: plain conditional
+    z = (draws[:, 0].mean() - pm[0]) / np.sqrt(pv[0] / 300)
+    assert abs(z) < 4.5 and 0.7 < draws[:, 0].var() / pv[0] < 1.4

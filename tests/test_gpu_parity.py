@@ -238,7 +238,7 @@ def test_launch_shapes_agree(cpa, p, q):
         # every copy of a theta gives the same bits, wherever it sits in the launch
         assert np.array_equal(got, np.tile(got[:48], B // 48 + 1)[:B], equal_nan=True), name
         res[name] = got[:48]
-        assert_parity(res[name], want, RTOL, "%s p=%d q=%d" % (name, p, q), arbiter=arb, max_arbitrated=3)
+        assert_parity(res[name], want, RTOL, "%s p=%d q=%d" % (name, p, q), arbiter=arb)
     fin = np.isfinite(want)
     for name in ("p3", "p3b", "row", "row2", "pc", "pc2", "plain"):
         assert np.array_equal(np.isfinite(res[name]), fin)
@@ -275,7 +275,7 @@ def test_series_lengths_around_chunk_boundaries(cpa, p, q):
                 # (random prior-like CARMA(7,4) models on a few dozen points reach cond ~ 1e6, where the
                 # reference itself is 1e-10 off the 50-digit value: same order of magnitude required)
                 assert_parity(got[:12][ok], want[ok], RTOL, "p=%d q=%d n=%d B=%d" % (p, q, n, B),
-                              arbiter=lambda i: arb(np.flatnonzero(ok)[i]), max_arbitrated=3, arb_factor=5.0)
+                              arbiter=lambda i: arb(np.flatnonzero(ok)[i]))
 
 
 @pytest.mark.parametrize("p,q,n", [(7, 6, 10000), (6, 2, 3001), (2, 1, 513), (3, 0, 1000), (4, 3, 64)])
@@ -290,7 +290,7 @@ def test_long_series_vs_oracle(cpa, p, q, n):
     arb = lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0]   # noqa: E731
     got = ctx.logdensity(th, ignore_prior=True)
     want = m.logdensity_batch(th, ignore_prior=True, nthreads=8)
-    worst = assert_parity(got, want, RTOL, "p=%d q=%d n=%d" % (p, q, n), arbiter=arb, max_arbitrated=3)
+    worst = assert_parity(got, want, RTOL, "p=%d q=%d n=%d" % (p, q, n), arbiter=arb)
     print("p=%d q=%d n=%d worst rel err %.2e" % (p, q, n, worst))
 
 
@@ -390,27 +390,6 @@ def test_edge_cases_nan_inf_tiny_series(cpa, readme):
         cpa.Context(t[:1], y[:1], yerr[:1], 2, 1)
 
 
-def test_scan_kernel_opt_in(cpa, readme, monkeypatch):
-    """The experimental time-parallel kernel (carma_scan.h, CARMA_LOGDENS_KERNEL=scan): same answers as the
-    default kernels on ordinary parameter vectors; its known weakness (rounding amplified by the signal-to-
-    noise ratio) is bounded here at 1e-7 over the whole 1024-theta bench batch."""
-    g = readme
-    t, y, yerr = g["t"], g["y"], g["yerr"]
-    th = theta_batch(np.random.default_rng(2), 1024, 5, 3, t, y, theta_center=g["theta"][0])
-    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_var_stdev(y))
-    ref = ctx.logdensity(th)
-    monkeypatch.setenv("CARMA_LOGDENS_KERNEL", "scan")
-    got = ctx.logdensity(th)
-    again = ctx.logdensity(th)
-    monkeypatch.delenv("CARMA_LOGDENS_KERNEL")
-    assert np.array_equal(got, again, equal_nan=True)
-    fin = np.isfinite(ref)
-    assert np.array_equal(np.isfinite(got), fin)
-    rel = np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])
-    print("scan kernel: median rel diff %.1e, 99%% %.1e, max %.1e" % (np.median(rel), np.quantile(rel, 0.99), rel.max()))
-    assert np.median(rel) < 1e-13 and rel.max() < 1e-7
-
-
 @pytest.mark.parametrize("p,q", [(2, 0), (3, 1), (5, 3), (6, 2), (7, 5)])
 def test_corotating_frame_windows_and_rebases(cpa, p, q):
     """The latency-regime pipeline (carma_pipe3l.h) keeps the covariance deviation in a frame that co-rotates with
@@ -454,10 +433,11 @@ def test_corotating_frame_windows_and_rebases(cpa, p, q):
     for other in (row, plain):
         assert np.array_equal(np.isfinite(other), fin)
         assert np.max(np.abs(got[fin] - other[fin]) / np.abs(other[fin])) < 1e-11
-    # (2) against the oracle: random roots this wide include ill-conditioned clusters on which every kernel and the
-    # oracle itself lose digits in the set-up (arbitrated elsewhere); here most entries must meet the bar outright
-    rel = np.abs(got[fin] - want[fin]) / np.abs(want[fin])
-    assert np.mean(rel <= RTOL) >= 0.9 and rel.max() < 1e-6, (np.mean(rel <= RTOL), rel.max())
+    # (2) against the oracle, at the bar of every other parity test: 1e-10, or -- where the reference's own arithmetic
+    # loses digits on clustered roots -- no further from the 50-digit value than the oracle
+    from mp_truth import loglik_truth
+    assert_parity(got, want, RTOL, "co-rotating p=%d q=%d" % (p, q),
+                  arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
     # independence of the neighbours: alone, and in any position of a shuffled batch
     perm = rng.permutation(64)
     shuffled = ctx.logdensity(th[perm], ignore_prior=True)
@@ -493,7 +473,7 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
         big = np.tile(pool, (B // pool.shape[0] + 1, 1))[:B]
         got = ctx.logdensity(big, ignore_prior=True)
         assert np.array_equal(got, np.tile(got[:pool.shape[0]], B // pool.shape[0] + 1)[:B], equal_nan=True), name
-        assert_parity(got[:pool.shape[0]], want, RTOL, "%s p=%d q=%d" % (name, p, q), max_arbitrated=6, arb_factor=5.0,
+        assert_parity(got[:pool.shape[0]], want, RTOL, "%s p=%d q=%d" % (name, p, q),
                       arbiter=lambda i, pool=pool: loglik_truth(t, y, yerr, pool[i], p, q)[0])
         res[name] = dict(zip(map(bytes, pool), got[:pool.shape[0]]))
     # the same theta in an all-complex wave (pair-shared factors) and in a mixed wave (one evaluation per lane)
@@ -502,3 +482,27 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
         assert v == w or abs(v - w) <= 1e-12 * abs(w), (v, w)
     for key, v in res["real"].items():
         assert v == res["mixed"][key] or (np.isnan(v) and np.isnan(res["mixed"][key]))
+
+
+@pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
+def test_prior_like_sweep_never_worse_than_reference(cpa, p):
+    """Every order (p, q < p) x 200 random PRIOR-LIKE parameter vectors -- the nastiest inputs the sampler can meet:
+    roots down to 1e-4 apart, where the reference's LU solve and cancelling sums lose up to 13 digits.  Bar: 1e-10
+    against the oracle, and wherever the two differ by more the GPU must be within 1e-10 of the 50-digit value of the
+    reference's formulas or no further from it than the oracle (factor 1.0).  (tests/tools/parity_sweep.py is the
+    1000-per-order version, profiles/r02/parity_sweep_*.txt its output.)"""
+    from mp_truth import loglik_truth
+    narb = 0
+    for q in range(p):
+        t, y, yerr = irregular_series(150, seed=100 * p + q)
+        rng = np.random.default_rng(7000 + 10 * p + q)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(200)])
+        ctx = cpa.Context(t, y, yerr, p, q)
+        m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+        want = m.logdensity_batch(th, nthreads=os.cpu_count() or 8)
+        got = ctx.logdensity(th)
+        fin = np.isfinite(want)
+        narb += int(np.sum(np.abs(got[fin] - want[fin]) > RTOL * np.abs(want[fin])))
+        assert_parity(got, want, RTOL, "sweep p=%d q=%d" % (p, q),
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
+    print("p=%d: %d of %d evaluations arbitrated against 50-digit arithmetic" % (p, narb, 200 * p))

@@ -15,7 +15,7 @@ from helpers import irregular_series, prior_like_theta
 from mp_truth import loglik_truth
 
 ntheta = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-tot = bad = worse = better = 0
+tot = bad = arbitrated = worse3 = worse1 = better3 = within = 0
 orders = [int(v) for v in os.environ.get("SWEEP_P", "2,3,4,5,6,7").split(",")]
 for p in orders:
     for q in range(0, p):
@@ -30,18 +30,24 @@ for p in orders:
         assert np.array_equal(np.isfinite(got), fin), (p, q)
         rel = np.abs(got[fin] - want[fin]) / np.abs(want[fin])
         idx = np.flatnonzero(fin)[rel > 1e-10]
-        nw = nb = 0
-        for i in idx[:10]:
+        n3 = n1 = nb = nin = 0
+        worst_g = worst_o = 0.0
+        for i in idx:                       # every entry above 1e-10 is arbitrated against 50-digit arithmetic
             T = float(loglik_truth(t, y, yerr, th[i], p, q)[0])
             eg, eo = abs(got[i] - T) / abs(T), abs(want[i] - T) / abs(T)
-            if eg > max(1e-10, 3 * eo):
-                nw += 1
-                if os.environ.get("SWEEP_VERBOSE"):
-                    print("   theta %d: gpu err %.1e  reference err %.1e" % (i, eg, eo))
-            if eg < eo / 3:
-                nb += 1
-        better += nb
-        tot += fin.sum(); bad += idx.size; worse += nw
-        print("p=%d q=%d: finite %4d  median %.1e  99%% %.1e  max %.1e  >1e-10: %d (GPU worse than 3x reference on %d of the first %d)" % (
-            p, q, fin.sum(), np.median(rel), np.quantile(rel, 0.99), rel.max(), idx.size, nw, min(10, idx.size)), flush=True)
-print("total finite %d, above 1e-10: %d (%.3f%%), of the arbitrated ones GPU >3x worse than the reference: %d, >3x better: %d" % (tot, bad, 100.0 * bad / tot, worse, better))
+            worst_g, worst_o = max(worst_g, eg), max(worst_o, eo)
+            n3 += eg > max(1e-10, 3 * eo)
+            n1 += eg > max(1e-10, eo)
+            nb += eg < eo / 3
+            nin += eg <= 1e-10
+            if os.environ.get("SWEEP_VERBOSE"):
+                print("   theta %d: gpu err %.1e  reference err %.1e" % (i, eg, eo))
+        tot += fin.sum(); bad += idx.size; arbitrated += idx.size
+        worse3 += n3; worse1 += n1; better3 += nb; within += nin
+        print("p=%d q=%d: finite %4d  median %.1e  99%% %.1e  max %.1e  >1e-10 vs oracle: %2d | vs 50-digit value: GPU worst %.1e "
+              "oracle worst %.1e, GPU within 1e-10: %d, worse than the oracle: %d (>3x: %d), >3x better: %d" % (
+                  p, q, fin.sum(), np.median(rel), np.quantile(rel, 0.99), rel.max(), idx.size, worst_g, worst_o, nin, n1, n3, nb),
+              flush=True)
+print("total finite %d, differing from the oracle by more than 1e-10: %d (%.3f%%); of these, against the 50-digit value: GPU within "
+      "1e-10 on %d, GPU further away than the oracle on %d (more than 3x further: %d), GPU more than 3x closer: %d" % (
+          tot, bad, 100.0 * bad / tot, within, worse1, worse3, better3))

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.a
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle as orc
 from carma_pack_amd.synth import theta_batch
-from scan_real import real_model, phi
+from real_modal import real_model, phi
 
 
 def loglik_std(t, y, yerr, theta, p, q):
