@@ -68,6 +68,15 @@ def _load():
     L.carma_pt_stats.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
     L.carma_pt_iterations_done.argtypes = [C.c_void_p]
     L.carma_pt_iterations_done.restype = C.c_long
+    L.carma_comm_unique_id.argtypes = [C.c_void_p]
+    L.carma_comm_create.restype = C.c_void_p
+    L.carma_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.carma_comm_destroy.argtypes = [C.c_void_p]
+    L.carma_comm_destroy.restype = None
+    L.carma_comm_rank.argtypes = [C.c_void_p]
+    L.carma_comm_size.argtypes = [C.c_void_p]
+    L.carma_pt_iterate_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_void_p]
+    L.carma_pt_boundary_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     return L
 
 
@@ -80,7 +89,8 @@ EXPORTS = [
     "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logprior", "carma_kfilter_carma",
     "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
-    "carma_pt_stats", "carma_pt_iterations_done",
+    "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
+    "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_boundary_stats",
 ]
 
 
@@ -243,6 +253,59 @@ class Context:
 
     def pt_iterations_done(self):
         return lib.carma_pt_iterations_done(self._h)
+
+    def pt_boundary_stats(self):
+        """(proposed, accepted) swaps across this block's boundaries (carma_pt_iterate_sharded)."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(lib.carma_pt_boundary_stats(self._h, C.byref(a), C.byref(b)), "carma_pt_boundary_stats")
+        return a.value, b.value
+
+
+class Comm:
+    """RCCL communicator owned by libcarma_mi355.so (carma_comm_*): one rank per process / GPU.
+
+    ``Comm.unique_id()`` on rank 0 -> 128 bytes to broadcast with the host program's own bootstrap -> every rank
+    ``Comm(id, nranks, rank, device)`` (collective)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib.carma_comm_unique_id(buf), "carma_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, unique_id, nranks, rank, device=None):
+        self.device = default_device() if device is None else int(device)
+        self._id = C.create_string_buffer(bytes(unique_id), 128)
+        self._h = lib.carma_comm_create(self._id, int(nranks), int(rank), self.device)
+        if not self._h:
+            raise CarmaError("carma_comm_create failed: " + last_error())
+        self.rank, self.size = int(rank), int(nranks)
+
+    @classmethod
+    def from_torch(cls, dist, device=None):
+        """Bootstrap over an initialised torch.distributed process group (any backend)."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(box[0], world, rank, device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.carma_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pt_iterate_sharded(contexts, niter, comm=None):
+    """carma_pt_iterate_sharded: `contexts` = this process's consecutive ladder blocks (normally one)."""
+    arr = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+    check(lib.carma_pt_iterate_sharded(arr, len(contexts), int(niter), comm._h if comm is not None else None),
+          "carma_pt_iterate_sharded")
 
 
 def kfilter_carma(time, y, yerr, sigsqr, omega, ma, device=None):

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <vector>
 
 #include "carma_launch.h"
@@ -9,7 +10,32 @@
 
 namespace carma {
 
-struct PtState;
+// Parallel-tempering sampler state of one context (carma_pt_host.hip, carma_shard.hip)
+struct PtState {
+    int T = 0, R = 0;
+    unsigned T_global = 0, slot0 = 0, replica0 = 0;
+    int maxiter = 0;
+    uint64_t seed = 0;
+    unsigned long long iter = 0;
+    std::vector<double> temps;
+    double *d_temps = nullptr, *d_theta = nullptr, *d_lp = nullptr, *d_chol = nullptr;
+    bool ext_state = false;
+    unsigned *d_nacc = nullptr, *d_nswap = nullptr;
+    double *d_samples = nullptr, *d_slp = nullptr;
+    long cap = 0;
+    bool started = false;
+    unsigned long long stat_iters = 0;
+    // row-variant kernel (k_pt_row): ladders spread over wpl workgroups, swap through global staging
+    bool use_row = false;
+    int wpl = 0;
+    double *d_stage_th = nullptr, *d_stage_lp = nullptr;
+    unsigned *d_counter = nullptr, *d_abort = nullptr;
+    double* d_backup = nullptr;         // chain state before the chunk in flight (theta, logpost, chol): abort recovery
+    // ladder sharded across ranks (carma_shard.hip): boundary staging and statistics
+    double *d_send = nullptr, *d_recv = nullptr;       // [R][d+1] each
+    unsigned* d_bnd_swaps = nullptr;                   // [1] accepted boundary swaps (this block's side)
+    unsigned long long bnd_proposed = 0;
+};
 
 struct Ctx {
     int device = 0;
@@ -29,5 +55,10 @@ void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 int select_device(int device);
 void pt_state_free(Ctx* c);
+// Enqueue `niter` iterations of the sampler kernel on `st` (no synchronisation).  thin > 0: save the coldest chain
+// every `thin` iterations starting at sample index *save_offset (advanced).
+int pt_enqueue(Ctx* c, long niter, int do_exchange, int thin, long* save_offset, hipStream_t st);
+// after the stream has been synchronised: did a cross-workgroup rendezvous of the row kernel time out?
+int pt_check_abort(Ctx* c, bool* aborted);
 
 }  // namespace carma

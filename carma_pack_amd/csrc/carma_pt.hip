@@ -233,8 +233,9 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
 // resident: the host only picks this kernel when the whole grid fits the chip), and every workgroup
 // replays the same hot->cold decisions (exchange_decide, same counter-based uniforms) for its ladder.
 // Staging is double buffered, so a workgroup can run at most one exchange ahead of the slowest one.
-// A barrier that does not complete within ~seconds sets abort_flag and the launch ends (reported as an
-// error by the host) instead of hanging the GPU.
+// The launch is cooperative (the runtime guarantees co-residency of the grid).  A barrier that nevertheless does not
+// complete within ~seconds sets abort_flag and the launch ends -- the host restores the chunk and re-runs it with the
+// ladder kernel -- instead of hanging the GPU.
 template <int P>
 __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
                                                 const double* __restrict__ temps, double* __restrict__ theta,
@@ -485,11 +486,10 @@ long pt_row_capacity(int p, int d, int T, int n)
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    // One workgroup per CU: beyond that the ladder kernel (8 chains per wave) has the better throughput,
-    // and a grid no larger than the CU count is resident as a whole with a wide margin (128 threads,
-    // < 40 KiB of LDS, ~140 VGPRs fit any CU several times over).  No occupancy query: on this stack
-    // hipOccupancyMaxActiveBlocksPerMultiprocessor returned hipErrorUnknown for a kernel that had not
-    // been launched yet, and HIP's last-error is sticky across later successful calls.
+    // One workgroup per CU: beyond that the ladder kernel (8 chains per wave) has the better throughput.  Whether
+    // the grid really is co-resident is checked by the cooperative launch itself (launch_pt_row_p).
+    int coop = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return 0;
     return (long)ncu;
 }
 
@@ -502,9 +502,15 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt_row<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(256), lds, st, L, S, series, pr, temps,
-                       theta, logpost, chol, naccept, nswap, samples, sample_lp);
-    return hipGetLastError();
+    // COOPERATIVE launch: the swap step is a rendezvous of the ladder's workgroups through global memory, so the whole
+    // grid has to be resident at once.  The runtime checks that (hipErrorCooperativeLaunchTooLarge otherwise, and the
+    // host falls back to the ladder kernel) and schedules the grid as a gang, instead of this code assuming it.
+    PtLaunch La = L;
+    PtRowSync Sa = S;
+    Prior pra = pr;
+    void* args[] = {&La, &Sa, (void*)&series, &pra, (void*)&temps, &theta, &logpost, &chol, &naccept, &nswap, &samples, &sample_lp};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(256),
+                                      args, (unsigned)lds, st);
 }
 
 hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const double4* series, const Prior& pr,

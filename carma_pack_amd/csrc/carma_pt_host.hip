@@ -18,27 +18,6 @@
 
 namespace carma {
 
-struct PtState {
-    int T = 0, R = 0;
-    unsigned T_global = 0, slot0 = 0, replica0 = 0;
-    int maxiter = 0;
-    uint64_t seed = 0;
-    unsigned long long iter = 0;
-    std::vector<double> temps;
-    double *d_temps = nullptr, *d_theta = nullptr, *d_lp = nullptr, *d_chol = nullptr;
-    bool ext_state = false;
-    unsigned *d_nacc = nullptr, *d_nswap = nullptr;
-    double *d_samples = nullptr, *d_slp = nullptr;
-    long cap = 0;
-    bool started = false;
-    unsigned long long stat_iters = 0;
-    // row-variant kernel (k_pt_row): ladders spread over wpl workgroups, swap through global staging
-    bool use_row = false;
-    int wpl = 0;
-    double *d_stage_th = nullptr, *d_stage_lp = nullptr;
-    unsigned *d_counter = nullptr, *d_abort = nullptr;
-};
-
 void pt_state_free(Ctx* c)
 {
     PtState* s = c->pt;
@@ -57,6 +36,10 @@ void pt_state_free(Ctx* c)
     if (s->d_stage_lp) (void)hipFree(s->d_stage_lp);
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_abort) (void)hipFree(s->d_abort);
+    if (s->d_backup) (void)hipFree(s->d_backup);
+    if (s->d_send) (void)hipFree(s->d_send);
+    if (s->d_recv) (void)hipFree(s->d_recv);
+    if (s->d_bnd_swaps) (void)hipFree(s->d_bnd_swaps);
     delete s;
     c->pt = nullptr;
 }
@@ -143,9 +126,60 @@ static void draw_start(const Ctx* c, std::mt19937_64& rng, double* theta)
     for (int i = 0; i < q; i++) theta[3 + p + i] = std::fabs(norm(rng));
 }
 
-static int pt_launch_chunks(Ctx* c, long niter, int do_exchange, int thin, long* save_offset)
+static PtLaunch pt_launch_args(const Ctx* c, long ch, int do_exchange, int thin, long save_offset)
+{
+    const PtState* s = c->pt;
+    PtLaunch L{};
+    L.d = c->d;
+    L.q = c->q;
+    L.n = c->n;
+    L.T = s->T;
+    L.R = s->R;
+    L.maxiter = s->maxiter;
+    L.iter0 = s->iter;
+    L.niter = (int)ch;
+    L.do_exchange = do_exchange;
+    L.save_thin = thin;
+    L.save_offset = save_offset;
+    L.sample_cap = s->cap;
+    L.seed0 = (unsigned)(s->seed & 0xffffffffu);
+    L.seed1 = (unsigned)(s->seed >> 32);
+    L.slot0 = s->slot0;
+    L.T_global = s->T_global;
+    L.replica0 = s->replica0;
+    return L;
+}
+
+// one launch of `ch` iterations on `st`
+static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save_offset, hipStream_t st)
 {
     PtState* s = c->pt;
+    const PtLaunch L = pt_launch_args(c, ch, do_exchange, thin, save_offset ? *save_offset : 0);
+    hipError_t e;
+    if (s->use_row) {
+        e = hipMemsetAsync(s->d_counter, 0, sizeof(unsigned) * s->R, st);
+        if (e != hipSuccess) return hip_fail(e, "reset pt counters");
+        PtRowSync S{s->d_stage_th, s->d_stage_lp, s->d_counter, s->d_abort, s->wpl};
+        e = launch_pt_row(c->p, L, S, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
+                          s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
+        if (e == hipErrorCooperativeLaunchTooLarge) {      // the grid is not co-resident on this device: ladder kernel
+            (void)hipGetLastError();
+            s->use_row = false;
+        }
+    }
+    if (!s->use_row) {
+        e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
+                      s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
+    }
+    if (e != hipSuccess) return hip_fail(e, "launch pt kernel");
+    s->iter += ch;
+    s->stat_iters += ch;
+    if (thin > 0 && save_offset) *save_offset += ch / thin;
+    return CARMA_OK;
+}
+
+int pt_enqueue(Ctx* c, long niter, int do_exchange, int thin, long* save_offset, hipStream_t st)
+{
     const int chunk0 = chunk_iters(c);
     long left = niter;
     while (left > 0) {
@@ -154,51 +188,87 @@ static int pt_launch_chunks(Ctx* c, long niter, int do_exchange, int thin, long*
             ch = std::max<long>(thin, (ch / thin) * thin);   // whole thinning intervals per launch
             ch = std::min(ch, left);
         }
-        PtLaunch L{};
-        L.d = c->d;
-        L.q = c->q;
-        L.n = c->n;
-        L.T = s->T;
-        L.R = s->R;
-        L.maxiter = s->maxiter;
-        L.iter0 = s->iter;
-        L.niter = (int)ch;
-        L.do_exchange = do_exchange;
-        L.save_thin = thin;
-        L.save_offset = save_offset ? *save_offset : 0;
-        L.sample_cap = s->cap;
-        L.seed0 = (unsigned)(s->seed & 0xffffffffu);
-        L.seed1 = (unsigned)(s->seed >> 32);
-        L.slot0 = s->slot0;
-        L.T_global = s->T_global;
-        L.replica0 = s->replica0;
-        hipError_t e;
-        if (s->use_row) {
-            e = hipMemsetAsync(s->d_counter, 0, sizeof(unsigned) * s->R, c->stream);
-            if (e != hipSuccess) return hip_fail(e, "reset pt counters");
-            PtRowSync S{s->d_stage_th, s->d_stage_lp, s->d_counter, s->d_abort, s->wpl};
-            e = launch_pt_row(c->p, L, S, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta,
-                              s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->stream);
-        } else {
-            e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
-                          s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->stream);
-        }
-        if (e != hipSuccess) return hip_fail(e, "launch pt kernel");
-        s->iter += ch;
-        s->stat_iters += ch;
-        if (thin > 0 && save_offset) *save_offset += ch / thin;
+        int rc = pt_enqueue_one(c, ch, do_exchange, thin, save_offset, st);
+        if (rc != CARMA_OK) return rc;
         left -= ch;
     }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return hip_fail(e, "pt kernel");
-    if (s->use_row) {
-        unsigned aborted = 0;
-        e = hipMemcpy(&aborted, s->d_abort, sizeof(unsigned), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return hip_fail(e, "pt abort flag");
-        if (aborted) {
-            set_error("pt kernel: a cross-workgroup swap barrier timed out (workgroups of a ladder not co-resident?)");
-            return CARMA_EHIP;
+    return CARMA_OK;
+}
+
+int pt_check_abort(Ctx* c, bool* aborted)
+{
+    PtState* s = c->pt;
+    *aborted = false;
+    if (!s->use_row) return CARMA_OK;
+    unsigned flag = 0;
+    hipError_t e = hipMemcpy(&flag, s->d_abort, sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "pt abort flag");
+    *aborted = flag != 0;
+    return CARMA_OK;
+}
+
+// chain state <-> backup (theta, logpost, chol), asynchronous on st
+static hipError_t pt_backup(Ctx* c, bool restore, hipStream_t st)
+{
+    PtState* s = c->pt;
+    const size_t nchain = (size_t)s->T * s->R, d = c->d;
+    double* b = s->d_backup;
+    struct Part { double* p; size_t n; } parts[3] = {{s->d_theta, nchain * d}, {s->d_lp, nchain}, {s->d_chol, nchain * d * d}};
+    for (auto& pt : parts) {
+        hipError_t e = restore ? hipMemcpyAsync(pt.p, b, sizeof(double) * pt.n, hipMemcpyDeviceToDevice, st)
+                               : hipMemcpyAsync(b, pt.p, sizeof(double) * pt.n, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+        b += pt.n;
+    }
+    return hipSuccess;
+}
+
+// Run `niter` iterations and wait for them.  The ladder kernel's launches are all enqueued first; the row kernel
+// (cross-workgroup rendezvous) is run chunk by chunk with the chain state saved in front of every chunk: should a
+// rendezvous ever time out (the launch is cooperative, so the grid is co-resident by construction; the time-out only
+// guards against a wedged GPU), the chunk is restored and re-run -- like everything after it -- with the ladder kernel.
+static int pt_launch_chunks(Ctx* c, long niter, int do_exchange, int thin, long* save_offset)
+{
+    PtState* s = c->pt;
+    if (!s->use_row) {
+        int rc = pt_enqueue(c, niter, do_exchange, thin, save_offset, c->stream);
+        if (rc != CARMA_OK) return rc;
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(e, "pt kernel");
+        return CARMA_OK;
+    }
+    const int chunk0 = chunk_iters(c);
+    long left = niter;
+    while (left > 0) {
+        long ch = std::min<long>(left, chunk0);
+        if (thin > 0) {
+            ch = std::max<long>(thin, (ch / thin) * thin);
+            ch = std::min(ch, left);
         }
+        if (!s->use_row) return pt_launch_chunks(c, left, do_exchange, thin, save_offset);     // after a fall-back
+        const unsigned long long iter_before = s->iter, stat_before = s->stat_iters;
+        const long off_before = save_offset ? *save_offset : 0;
+        hipError_t e = pt_backup(c, false, c->stream);
+        if (e != hipSuccess) return hip_fail(e, "pt state backup");
+        int rc = pt_enqueue_one(c, ch, do_exchange, thin, save_offset, c->stream);
+        if (rc != CARMA_OK) return rc;
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(e, "pt kernel");
+        bool aborted = false;
+        rc = pt_check_abort(c, &aborted);
+        if (rc != CARMA_OK) return rc;
+        if (aborted) {
+            e = pt_backup(c, true, c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(s->d_abort, 0, sizeof(unsigned), c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return hip_fail(e, "pt state restore");
+            s->iter = iter_before;
+            s->stat_iters = stat_before;
+            if (save_offset) *save_offset = off_before;
+            s->use_row = false;           // acceptance / swap counters of the aborted chunk stay counted: statistics only
+            continue;
+        }
+        left -= ch;
     }
     return CARMA_OK;
 }
@@ -276,6 +346,7 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
             if (e == hipSuccess) e = hipMalloc(&s->d_counter, sizeof(unsigned) * nreplicas);
             if (e == hipSuccess) e = hipMalloc(&s->d_abort, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(s->d_abort, 0, sizeof(unsigned));
+            if (e == hipSuccess) e = hipMalloc(&s->d_backup, sizeof(double) * nchain * (d + 1 + (size_t)d * d));
         }
     }
     if (e != hipSuccess) {

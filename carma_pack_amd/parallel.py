@@ -182,8 +182,25 @@ class LadderShard(object):
             self.b.pt_set_chains(th, lp)
         self.nswap_boundary += int(acc.sum())
 
+    def attach_comm(self, comm):
+        """Switch to the native exchange: `comm` = carma_pack_amd._lib.Comm over the same ranks.  From now on
+        iterate() is ONE call into the C ABI (carma_pt_iterate_sharded): per iteration the sampler kernel, the RCCL
+        send/recv of the boundary chains and the swap kernel are enqueued on the sampler's stream -- no host
+        synchronisation, no host RNG, no host<->device copy until the last iteration is done.  Same Philox keys and
+        decisions as the torch.distributed path below, which stays as the stand-in for process groups that RCCL cannot
+        serve (gloo in the CPU test-suite, two ranks sharing one GPU)."""
+        if comm.size != self.world or comm.rank != self.rank:
+            raise ValueError("communicator does not span the ladder's ranks")
+        self._comm = comm
+
     def iterate(self, niter):
         """niter x (local RAM steps + local swap sweep, then alternating even/odd boundary swaps)."""
+        if getattr(self, "_comm", None) is not None:
+            from . import _lib
+            _lib.pt_iterate_sharded([self.b], niter, self._comm)
+            self.iteration += int(niter)
+            self.nprop_boundary, self.nswap_boundary = self.b.pt_boundary_stats()
+            return
         for _ in range(int(niter)):
             self.b.pt_iterate(1, do_exchange=True)
             if self.world > 1:

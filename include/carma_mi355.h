@@ -39,6 +39,7 @@ extern "C" {
 #define CARMA_PMAX 7
 
 typedef struct carma_ctx carma_ctx;
+typedef struct carma_comm carma_comm;
 
 /* Library / device queries. */
 const char* carma_version(void);
@@ -145,6 +146,33 @@ int carma_pt_sample(carma_ctx* h, int nsamples, int thin, double* samples, doubl
 /* acceptance rate per chain [R][T]; swap_rate[r][i] = accepted swaps between temperatures i and i-1 */
 int carma_pt_stats(carma_ctx* h, double* accept_rate, double* swap_rate, int reset);
 long carma_pt_iterations_done(const carma_ctx* h);
+
+/*
+ * ONE temperature ladder sharded across the GPUs of a node (one process per GPU): the reference has no counterpart --
+ * its ExchangeStep (src/include/steps.hpp:318-362, wired hot -> cold in src/carmcmc.cpp:147-157) swaps two chains of
+ * the same process; here the two chains of a pair may live on different GPUs and travel over RCCL / xGMI.
+ *
+ * carma_comm_*: an RCCL communicator owned by this library (bound at run time to librccl.so.1; no link-time
+ * dependency).  Rank 0 calls carma_comm_unique_id and hands the 128 bytes to the other ranks by whatever bootstrap the
+ * host program has (torch.distributed broadcast, MPI, a file); every rank then calls carma_comm_create (collective).
+ *
+ * carma_pt_iterate_sharded: `shards` = the nlocal (normally 1) contexts of this process, each created with
+ * carma_pt_create + carma_pt_shard for a contiguous block of temperature slots, consecutive blocks in ascending order;
+ * the blocks of all ranks tile the ladder in rank order with the same nlocal everywhere.  Per iteration: the sampler
+ * kernel advances every block (RAM steps + swaps inside the block), then the chains on either side of every ACTIVE
+ * block boundary (even boundaries on even iterations, odd on odd) are exchanged for all replicas: pack kernel ->
+ * ncclSend/ncclRecv of R (d+1) + 1 doubles -> swap kernel, all on the sampler's stream with no host synchronisation;
+ * both sides draw the same Philox uniform (seed, hotter chain's global slot, iteration) and take the same decision.
+ * Returns after the last iteration has completed.  comm may be NULL when the process owns the whole ladder as one block.
+ */
+int carma_comm_unique_id(void* out128);
+carma_comm* carma_comm_create(const void* id128, int nranks, int rank, int device);
+void carma_comm_destroy(carma_comm* comm);
+int carma_comm_rank(const carma_comm* comm);
+int carma_comm_size(const carma_comm* comm);
+int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, carma_comm* comm);
+/* boundary swaps this block took part in: proposed = R per active boundary and iteration; accepted */
+int carma_pt_boundary_stats(carma_ctx* h, unsigned long long* proposed, unsigned long long* accepted);
 
 #ifdef __cplusplus
 }

@@ -100,3 +100,74 @@ def test_ladder_sharded_over_two_ranks():
     host = _run(resident=False)
     for a, b in zip(res, host):
         assert a[1] == b[1] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+def _native_worker(q, nblocks_T, rccl):
+    """One process owning the whole ladder as consecutive blocks; boundaries go through carma_pt_iterate_sharded."""
+    import carma_pack_amd as cpa
+    from carma_pack_amd import _lib, parallel as par
+    t, y, e = _series()
+    temps = par.ladder_temperatures(TG)
+    comm = _lib.Comm(_lib.Comm.unique_id(), 1, 0, device=0) if rccl else None
+    ctxs, slot0 = [], 0
+    for Tl in nblocks_T:
+        c = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std())
+        c.pt_create(Tl, R, NITER, seed=SEED, temperatures=temps[slot0:slot0 + Tl])
+        c.pt_shard(TG, slot0, 0)
+        c.pt_start(None)
+        ctxs.append(c)
+        slot0 += Tl
+    _lib.pt_iterate_sharded(ctxs, NITER // 2, comm)
+    _lib.pt_iterate_sharded(ctxs, NITER - NITER // 2, comm)        # resumable: two calls == one
+    out = []
+    for c in ctxs:
+        th, lp = c.pt_get_chains()
+        out.append((th, lp, c.pt_boundary_stats(), c.pt_iterations_done()))
+    q.put(out)
+    if comm is not None:
+        comm.close()
+
+
+def _run_native(nblocks_T, rccl=True):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_worker, args=(q, nblocks_T, rccl))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    return out
+
+
+def test_native_rccl_exchange_walks_the_same_trajectory():
+    """carma_pt_iterate_sharded (pack kernel -> ncclSend/ncclRecv -> swap kernel on the sampler's stream, no host work
+    per iteration) against the torch.distributed stand-in above: same seed, same blocks (3 + 2 temperatures) -> the same
+    chain states bit for bit and the same boundary-swap count.  The box has one GPU, so the two blocks live in one
+    process and the boundary rows travel through RCCL send/recv to the process's own rank -- the same code path, and
+    the same RCCL kernels, as between two GPUs."""
+    ref = _run(resident=True)
+    (r0, sw0, pr0, s0, th0, lp0), (r1, sw1, pr1, s1, th1, lp1) = ref
+    nat = _run_native([3, 2])
+    (nth0, nlp0, (npr0, nsw0), it0), (nth1, nlp1, (npr1, nsw1), it1) = nat
+    assert it0 == it1 == NITER
+    assert np.array_equal(nth0, th0) and np.array_equal(nlp0, lp0)
+    assert np.array_equal(nth1, th1) and np.array_equal(nlp1, lp1)
+    assert (npr0, nsw0) == (pr0, sw0) and (npr1, nsw1) == (pr1, sw1)
+    # one block per temperature (BASELINE config 4's layout: 5 blocks of 1): both kinds of boundary, every iteration
+    one = _run_native([1, 1, 1, 1, 1])
+    import oracle as orc
+    t, y, e = _series()
+    m = orc.OracleModel(t, y, e, P, Q, max_stdev=10.0 * y.std())
+    th = np.concatenate([o[0] for o in one], axis=1).reshape(-1, 3 + P + Q)
+    lp = np.concatenate([o[1] for o in one], axis=1).ravel()
+    from helpers import assert_parity
+    from mp_truth import loglik_truth
+    assert_parity(lp, m.logdensity_batch(th), 1e-10, "one temperature per block",
+                  arbiter=lambda i: loglik_truth(t, y, e, th[i], P, Q)[0])
+    prop = [o[2][0] for o in one]
+    acc = [o[2][1] for o in one]
+    assert prop == [R * NITER // 2, R * NITER, R * NITER, R * NITER, R * NITER // 2]     # inner blocks: a boundary every iteration
+    assert all(0 < a < p_ for a, p_ in zip(acc, prop))
+    # boundary k is counted once by either side: blocks 0 and 4 see one boundary, the inner blocks two
+    assert acc[0] + acc[2] + acc[4] == acc[1] + acc[3]
