@@ -5,7 +5,9 @@ shared library is missing the import fails, and without a gfx950 device every co
 raises ``CarmaDeviceError``.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -27,11 +29,48 @@ class CarmaDeviceError(CarmaError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One process, ONE HIP runtime.  The PyTorch wheel bundles its own libamdhip64.so (soname libamdhip64.so.7, like
+    the system's); whichever copy is mapped first serves every later request for that soname, but `import torch` asks
+    for it by file name and would map a SECOND runtime if this library had already pulled in /opt/rocm's.  Two runtimes
+    in one process cannot share streams or device pointers (the `_dev` entry points take torch's) and cooperative
+    launches fail outright (measured: hipErrorUnknown).  So when PyTorch is installed and not yet imported, its copy is
+    mapped first -- without importing torch.  CARMA_HIP_RUNTIME=system keeps the system runtime."""
+    if "torch" in sys.modules or os.environ.get("CARMA_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def _share_rccl_with_torch():
+    """Same for RCCL (bound by the library at run time as librccl.so.1): map PyTorch's copy first when there is one, so
+    that it -- and the HIP runtime it was built against -- is the one carma_comm_* finds."""
+    if os.environ.get("CARMA_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "carma_pack_amd: %s not found -- build it with ./build.sh (or __graft_entry__.build()); "
             "there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     L.carma_version.restype = C.c_char_p
     L.carma_last_error.restype = C.c_char_p
@@ -269,11 +308,13 @@ class Comm:
 
     @staticmethod
     def unique_id():
+        _share_rccl_with_torch()
         buf = C.create_string_buffer(128)
         check(lib.carma_comm_unique_id(buf), "carma_comm_unique_id")
         return buf.raw
 
     def __init__(self, unique_id, nranks, rank, device=None):
+        _share_rccl_with_torch()
         self.device = default_device() if device is None else int(device)
         self._id = C.create_string_buffer(bytes(unique_id), 128)
         self._h = lib.carma_comm_create(self._id, int(nranks), int(rank), self.device)

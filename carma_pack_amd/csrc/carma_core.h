@@ -334,7 +334,6 @@ struct RhoInline {
     CARMA_DEV void chunk_begin(int) const {}
     CARMA_DEV double4 record_s(int) const { return double4{}; }
     CARMA_DEV void fetch_s(int, Cx&, Cx (&)[P]) const {}
-    CARMA_DEV void fetch_own_s(int, Cx&) const {}
     CARMA_DEV double4 record(int) const { return double4{}; }
     const GrpT& g;
     Cx w;            // own root
@@ -368,7 +367,6 @@ struct RhoPair {
     CARMA_DEV void chunk_begin(int) const {}
     CARMA_DEV double4 record_s(int) const { return double4{}; }
     CARMA_DEV void fetch_s(int, Cx&, Cx (&)[P]) const {}
-    CARMA_DEV void fetch_own_s(int, Cx&) const {}
     const GrpT& g;
     Cx w;                  // own root (idle lanes: the last root, see model_from_theta)
     Cx val;                // the factor this lane evaluated last
@@ -616,137 +614,6 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
     return acc.total();
 }
 
-// The real-coordinate update loop for ONE EVALUATION PER DPP ROW (G = 16; latency regime).
-//
-// gfx950 can apply a DPP row broadcast (row_newbcast:j -- lane j of each 16-lane row to the whole
-// row) to the first source of a VOP2 FP64 instruction, so with one evaluation per row
-//     d_j   = D_j - t k_j               is   v_fmac_f64_dpp D_j, k(lane j), -t
-//     N_j   = c_j d_j - s_j d_{j^1}     is   two v_fmac_f64_dpp on the lanes' OWN (c, s)
-//     var   = s0 + e + sum_j h_j w_j    is   p v_fmac_f64_dpp on w
-// and neither the gain, nor the other lanes' transition factors, nor the var/mean partial sums
-// travel through LDS or a butterfly: per pass the wave issues ~65 FP64 + 12 v_mov_dpp instructions
-// and two LDS reads (its own factor and the series record, both prefetched), against ~55 + 24 + 12
-// LDS instructions in the G = 8 loop.  Same recursion, same operation order per element as
-// filter_loop_real, so the results agree to rounding (fma contraction differs).
-template <int P, int G, bool WRITE_MV, class GrpT, class RhoSrc>
-CARMA_DEV double filter_loop_row(const GrpT& g, const Model<P>& m, const FilterConsts<P>& fc, RhoSrc& src,
-                                 const double4* __restrict__ series, int n, double* mean_out, double* var_out)
-{
-    static_assert(G == 16, "one evaluation per 16-lane DPP row");
-    const int r = g.lane();
-    const bool act = r < P;
-    const bool cpx = (m.w.im != 0.0) && (r < (P & ~1));
-    const bool odd = r & 1;
-    const double c_im_partner = g.partner(fc.c_own.im);
-    const double h_own = !act ? 0.0 : (cpx ? (odd ? 2.0 * fc.b_own.im : 2.0 * fc.b_own.re) : fc.b_own.re);
-    const double c_own = cpx ? (odd ? c_im_partner : fc.c_own.re) : fc.c_own.re;
-    double hall[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) hall[j] = g.bcast_u(h_own, j);
-    const double s0 = fc.s0;
-
-    double D[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) D[j] = 0.0;
-    double z = 0.0, w = 0.0;
-    double k = c_own;
-    LogLikAcc acc;
-    acc.init();
-    double4 rprev = series[0];
-    double4 rcur = series[n > 1 ? 1 : 0];
-    double4 rnxt = series[n > 2 ? 2 : n - 1];
-    src.begin(1, rcur.x);
-    Cx rho_n = {1.0, 0.0};
-    double4 rec_n = rprev;
-    if constexpr (RhoSrc::kRing) {
-        if (n > 1) {
-            src.chunk_begin(1);
-            src.fetch_own_s(0, rho_n);
-            rec_n = src.record_s(0);
-        }
-    }
-    auto pass = [&](const int kk, const int s_in_chunk) __attribute__((always_inline)) {
-        double4 rnn = rnxt;
-        if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
-        Cx rho = rho_n;
-        if constexpr (RhoSrc::kRing) {
-            rprev = rec_n;
-            if (s_in_chunk == RhoSrc::kChunk - 1) {
-                if (kk + 1 < n) {
-                    src.chunk_begin(kk + 1);
-                    src.fetch_own_s(0, rho_n);
-                    rec_n = src.record_s(0);
-                }
-            } else {
-                src.fetch_own_s(s_in_chunk + 1, rho_n);
-                rec_n = src.record_s(s_in_chunk + 1);
-            }
-        } else {
-            rho = src.rho_next;
-            src.prepare(kk + 1, rnxt.x);
-        }
-        // var_{kk-1} = s0 + e + h.w, innov_{kk-1} = (y - mu) - h.z     (kfilter.cpp:180-184, 207-213)
-        double var, innov;
-        g.template row_sums<P>(var, innov, rprev.z, m.scale, s0, rprev.y, m.mu, w, z, hall);
-        acc.add_var(var);
-        if (WRITE_MV && r == 0) {
-            mean_out[kk - 1] = (rprev.y - m.mu) - innov;
-            var_out[kk - 1] = var;
-        }
-        const double s = recip(var);
-        const double si = s * innov;
-        acc.chi2 += innov * si;
-        // gain: z += k si (kfilter.cpp:191-194); covariance d_j = D_j - (k s) k_j (:197)
-        double nt;
-        g.template row_gain<P>(nt, z, D, k, s, si);
-        // state transition (kfilter.cpp:200-201)
-        const double zp = g.partner(z);
-        z = fma(rho.re, z, -(rho.im * zp));           // explicit contraction: same bits in every variant of this loop
-        // transition of the covariance (kfilter.cpp:204): N_j = c_j d_j - s_j d_{j^1}, then the row mix
-        double mm[P];
-        g.template row_colmix<P>(mm, rho.re, rho.im, D);
-        double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-            const double mp = g.partner(mm[j]);
-            D[j] = fma(rho.re, mm[j], -(rho.im * mp));
-            if (j & 1)
-                w1 = fma(D[j], hall[j], w1);
-            else
-                w0 = fma(D[j], hall[j], w0);
-        }
-        // (h.k = h D h^T + s0 would save this add, but sums the individually large h_r c_r of an
-        // ill-conditioned model instead of their well-conditioned total s0: measurably worse parity)
-        w = w0 + w1;                                 // (D h^T)_r
-        k = w + c_own;
-        rprev = rcur;
-        rcur = rnxt;
-        rnxt = rnn;
-    };
-    for (int kk0 = 1; kk0 < n; kk0 += RhoSrc::kChunk) {
-        if (RhoSrc::kRing && n - kk0 >= RhoSrc::kChunk) {
-#pragma unroll 4
-            for (int s = 0; s < (RhoSrc::kRing ? RhoSrc::kChunk : 1); s++) pass(kk0 + s, s);
-        } else {
-            const int kend = (n - kk0 < RhoSrc::kChunk) ? n : kk0 + RhoSrc::kChunk;
-#pragma unroll 1
-            for (int kk = kk0; kk < kend; kk++) pass(kk, kk - kk0);
-        }
-    }
-    {   // last point: var_{n-1}, mean_{n-1}
-        if constexpr (RhoSrc::kRing) rprev = series[n - 1];
-        double var, innov;
-        g.template row_sums<P>(var, innov, rprev.z, m.scale, s0, rprev.y, m.mu, w, z, hall);
-        acc.add_var(var);
-        if (WRITE_MV && r == 0) {
-            mean_out[n - 1] = (rprev.y - m.mu) - innov;
-            var_out[n - 1] = var;
-        }
-        acc.chi2 += innov * (recip(var) * innov);
-    }
-    return acc.total();
-}
-
 // Kalman filter of one evaluation (Reset + n-1 Updates) -> log-likelihood sum (no prior).
 // y is centred with m.mu and yerr^2 scaled with m.scale on the fly (carpack.hpp:150-153).
 // If WRITE_MV, lane 0 of the group also stores the one-step means/variances.
@@ -759,17 +626,13 @@ CARMA_DEV double filter_run(const GrpT& g, const Model<P>& m, const double4* __r
     filter_reset<P, G>(g, m, fc);
     RhoInline<P, GrpT> src{g, m.w, Cx{1.0, 0.0}};
     double ll;
-    if constexpr (G == 16) {
-        ll = filter_loop_row<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
+    // pair-shared factors unless some group of the wave has a quadratic factor with two real roots
+    const bool real_pair = (g.lane() < (P & ~1)) && (m.w.im == 0.0);
+    if (g.wave_all(!real_pair)) {
+        RhoPair<P, GrpT> srcp{g, m.w, Cx{1.0, 0.0}};
+        ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, srcp, series, n, mean_out, var_out);
     } else {
-        // pair-shared factors unless some group of the wave has a quadratic factor with two real roots
-        const bool real_pair = (g.lane() < (P & ~1)) && (m.w.im == 0.0);
-        if (g.wave_all(!real_pair)) {
-            RhoPair<P, GrpT> srcp{g, m.w, Cx{1.0, 0.0}};
-            ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, srcp, series, n, mean_out, var_out);
-        } else {
-            ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
-        }
+        ll = filter_loop_real<P, G, WRITE_MV>(g, m, fc, src, series, n, mean_out, var_out);
     }
     *singular = fc.sing;
     return ll;

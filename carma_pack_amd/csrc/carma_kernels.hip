@@ -14,6 +14,8 @@
 // series (24 B/datum, shared by every evaluation and L2/scalar-cache resident) + 8(d+1) B/eval.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "grp_device.h"
 #include "carma_core.h"
 #include "carma_ring.h"
@@ -60,12 +62,8 @@ __global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* 
     const bool live = e < B;
     if (!live) e = B - 1;
     if (role == 1) {
-        if constexpr (G == 16) {
-            ring_produce_row<P>(g, theta + e * d, series, n, ring);
-        } else {
-            const int r = g.lane();
-            ring_produce<P, G>(g, own_ar_root<P>(theta + e * d, r < P ? r : P - 1), series, n, ring);
-        }
+        const int r = g.lane();
+        ring_produce<P, G>(g, own_ar_root<P>(theta + e * d, r < P ? r : P - 1), series, n, ring);
         return;
     }
     CARMA_STAMP_DECL;
@@ -189,6 +187,17 @@ __global__ __launch_bounds__(64) void k_predict_car1(double sigsqr, double omega
 }
 
 // ---------------------------------------------------------------------------------------------
+// Largest launch (in workgroups of four evaluations) that takes the wave pipeline of carma_pipe3l.h: three workgroups
+// per CU (measured, tools/tput_probe.py).  CARMA_TUNE_P3L_ROWS overrides it for such measurements; read once.
+static long p3l_max_rows()
+{
+    static const long v = [] {
+        const char* e = getenv("CARMA_TUNE_P3L_ROWS");
+        return e ? atol(e) : 768L;
+    }();
+    return v;
+}
+
 template <int P>
 static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, const double4* series, int n,
                                    const Prior& pr, int ignore_prior, double* out, hipStream_t st)
@@ -214,18 +223,15 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
     // that) a later 81 KiB launch failed with hipErrorUnknown.  The call costs ~1 us on the host and
     // the launches are asynchronous.
     auto big_lds = [](const void* kf) { return hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
-    if (rows <= 256 && n >= 8) {
-        // one workgroup per CU: covariance wave + mean wave + two producer waves, co-rotating frame (carma_pipe3l.h)
+    if (rows <= p3l_max_rows() && n >= 8) {
+        // covariance wave + mean wave + two producer waves per four evaluations, co-rotating frame (carma_pipe3l.h);
+        // 42 KiB of LDS: up to three workgroups per CU
         const size_t lds = Pipe3LGeom<P>::BYTES;
         hipError_t ea = big_lds(reinterpret_cast<const void*>(&k_logdens_carma_p3l<P>));
         if (ea != hipSuccess) return ea;
         hipLaunchKernelGGL((k_logdens_carma_p3l<P>), dim3((unsigned)rows), dim3(256), lds, st, theta, B, d, q, series, n, pr,
                            ignore_prior, out);
         return hipGetLastError();
-    } else if (rows <= 512 && n >= 8) {
-        // very few evaluations in flight (BASELINE configs 2, 3: 1024): one evaluation per DPP row, the
-        // cross-lane traffic of a step folded into FP64 DPP operands (filter_loop_row), rho producer wave
-        return rows <= 256 ? launch_pc(&k_logdens_carma_pc<P, 16, 1>, rows, 1) : launch_pc(&k_logdens_carma_pc<P, 16, 2>, rows, 2);
     } else if (waves <= 512 && n >= 8) {
         // few evaluations in flight: one wave's instruction stream is the run time, so split it
         // (consumer + rho producer, carma_ring.h).  Beyond 512 waves (two rounds of workgroups) the plain kernel

@@ -62,18 +62,31 @@ __device__ __forceinline__ void row_consts(const Grp<16>& g, const Model<P>& m, 
 
 template <int P>
 struct Pipe3LGeom {
-    static constexpr int C = 16, SLOT = 64;
+    static constexpr int C = 16;
+    // LDS entries (16 B each) per datum: only lanes 0..P-1 of a 16-lane row carry an evaluation's values, so a row gets
+    // ROWW = 8 entries (P <= 7) and the idle lanes 8..15 of all four rows share ONE dump entry.  42 KiB per workgroup
+    // instead of 82: three workgroups fit the 160 KiB of a CU, which is what lets launches of 1025..3072 evaluations
+    // (and sampler grids beyond one workgroup per CU) keep this kernel.
+    static constexpr int ROWW = 8, SLOT = 4 * ROWW + 1;
     static constexpr int RING_OFF = 0;                          // double2[3][C][SLOT]
     static constexpr int LINK_OFF = 3 * C * SLOT;               // double2 {k~_r, var}[2][C][SLOT]
     static constexpr int CONST_OFF = LINK_OFF + 2 * C * SLOT;   // double2 {h_r, c_r}[SLOT]
     static constexpr int FLAG_OFF = CONST_OFF + SLOT;           // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
     static constexpr int ENTRIES = FLAG_OFF + 2;
-    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 81.8 KiB
+    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 41.8 KiB
     static constexpr double LIM_RE = 200.0;                     // |Re omega| dt_acc: scale factors within e^+-200; S carries their
                                                                 // squares (5e173 at most: room for any variance below 1e130;
                                                                 // 100 instead of 200 costs 3 % per step in extra re-bases)
     static constexpr double LIM_IM = 256.0;                     // |Im omega| dt_acc: the phase product rounds to 3e-14 rad at most,
                                                                 // what the stepwise products accumulate over such a window anyway
+    static_assert(P < ROWW, "one row of entries per evaluation");
+    // entry of a lane inside a [SLOT] array
+    static __device__ __forceinline__ int entry(int lane)
+    {
+        const int l = lane & 15;
+        return l < ROWW ? (lane >> 4) * ROWW + l : 4 * ROWW;
+    }
+    static __device__ __forceinline__ int row_base(int lane) { return (lane >> 4) * ROWW; }
 };
 
 // DPP move of a double with an explicit `old` value for the lanes the pattern leaves unwritten
@@ -100,9 +113,9 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     const bool worker = sub < PPL;
     const Cx w = own_ar_root<P>(theta, jr);
     const int nc = (n + C - 1) / C;
-    if (pw == 0 && l >= P) {
+    if (pw == 0 && l >= P) {                                  // entries of the idle lanes: exact zeros
 #pragma unroll 4
-        for (int i = 0; i < 3 * C; i++) ring[(size_t)i * Geo::SLOT + lane] = Cx{0.0, 0.0};
+        for (int i = 0; i < 3 * C; i++) ring[(size_t)i * Geo::SLOT + Geo::entry(lane)] = Cx{0.0, 0.0};
     }
     // grid of this evaluation's re-base schedule: cells of width 2^-ex <= min over its roots of (LIM_RE / |Re omega|,
     // LIM_IM / |Im omega|).  Dyadic widths nest, so the re-base data of the evaluation with the finest grid contain
@@ -139,7 +152,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
         carry = fmax(carry, __shfl(M, (lane & ~15) + 15, 64));
         const unsigned long long fmask = __ballot(fl && j0 + l < n);      // bit 16 row + s: datum j0 + s of that row's evaluation
         if (pw == 0 && lane == 0) reinterpret_cast<unsigned long long*>(ring + Geo::FLAG_OFF)[c % 3] = fmask;
-        Cx* buf = ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT + (lane & ~15) + jr;
+        Cx* buf = ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT + Geo::row_base(lane) + jr;
         auto slot_of = [&](int it) { return it * 2 * PPL + pw * PPL + sub; };
         auto rotation = [&](int it, double& ec, double& es) {            // accumulated (E cos, E sin) of the lane's slot
             const int slot = slot_of(it);
@@ -163,7 +176,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
 #pragma unroll
             for (int it = 0; it < NIT; it++) rotation(it, ec0[it], es0[it]);
             __syncthreads();                                  // the covariance wave has published (h_r, c_r)
-            const double2* cst = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF) + (lane & ~15);
+            const double2* cst = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF) + Geo::row_base(lane);
             hc_own = cst[jr];
             hc_par = cst[jr ^ 1];
 #pragma unroll
@@ -196,7 +209,7 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     const int nc = (n + C - 1) / C;
     const bool act = (lane & 15) < P;
     const double h_row = act ? rc.h_own : 0.0, c_row = act ? rc.c_own : 0.0;     // idle lanes carry exact zeros
-    reinterpret_cast<double2*>(ring + Geo::CONST_OFF)[lane] = make_double2(h_row, c_row);
+    reinterpret_cast<double2*>(ring + Geo::CONST_OFF)[Geo::entry(lane)] = make_double2(h_row, c_row);
     __syncthreads();                                          // the producers finish chunk 0 with these constants
     const double one = 1.0;
     double S[P];
@@ -242,8 +255,8 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c
-        ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + lane;
-        link_b = reinterpret_cast<double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + lane;
+        ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + Geo::entry(lane);
+        link_b = reinterpret_cast<double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + Geo::entry(lane);
         hc_n = ring_b[0];
         j0 = c * C;
         const unsigned long long fm64 = flag_b[c % 3];
@@ -314,8 +327,8 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
     __syncthreads();                                          // barrier 0
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c + 1: wave A has finished chunk c
-        ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + lane;
-        link_b = reinterpret_cast<const double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + lane;
+        ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + Geo::entry(lane);
+        link_b = reinterpret_cast<const double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + Geo::entry(lane);
         hc_n = ring_b[0];
         lk_n = link_b[0];
         j0 = c * C;

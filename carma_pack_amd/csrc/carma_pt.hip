@@ -221,7 +221,7 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row variant: ONE CHAIN PER 16-LANE DPP ROW (filter_loop_row), 4 chains + their rho producer wave per
+// Row variant: ONE CHAIN PER 16-LANE DPP ROW (the wave pipeline of carma_pipe3l.h), 4 chains per
 // workgroup, a ladder of T chains spread over wpl = ceil(T/4) workgroups on different CUs.
 //
 // Why: with one ladder per workgroup (k_pt) a CU hosts 2 chain waves + 2 producer waves, and a Kalman
@@ -490,7 +490,11 @@ long pt_row_capacity(int p, int d, int T, int n)
     // the grid really is co-resident is checked by the cooperative launch itself (launch_pt_row_p).
     int coop = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return 0;
-    return (long)ncu;
+    static const long per_cu = [] {
+        const char* e = getenv("CARMA_TUNE_PT_ROW_WGS_PER_CU");      // measurements only; read once
+        return e ? atol(e) : 1L;
+    }();
+    return (long)ncu * per_cu;
 }
 
 template <int P>

@@ -81,53 +81,6 @@ __device__ __forceinline__ void ring_produce(const Grp<G>& g, const Cx w, const 
     }
 }
 
-// Producer for the row variant (one evaluation per 16-lane row, G = 16).  Only p of the 16 lanes of a
-// row own a root, so the row's lanes are packed as (pass offset, root) = (l / p, l % p) and one
-// exp/sincos evaluation covers 16/p consecutive passes: 6 evaluations per 16-pass chunk for p = 5.
-// The ring entries of the consumer's idle lanes (r >= p) are zeroed once, so those lanes carry
-// exact zeros instead of stale LDS through the recursion.
-template <int P>
-__device__ __forceinline__ void ring_produce_row(const Grp<16>& g, const double* __restrict__ theta,
-                                                 const double4* __restrict__ series, int n, Cx* __restrict__ ring)
-{
-    constexpr int C = RingGeom<P>::C;
-    constexpr int PPL = 16 / P;                            // passes per exp/sincos evaluation
-    const int lane = g.lane64, l = lane & 15;
-    const int sub = l / P, jr = l - sub * P;
-    const bool worker = sub < PPL;
-    const Cx w = own_ar_root<P>(theta, jr);
-    const int nchunks = (n - 1 + C - 1) / C;
-    double2* recs = reinterpret_cast<double2*>(ring + RingGeom<P>::REC_OFF);
-    if (l >= P) {
-#pragma unroll 4
-        for (int i = 0; i < 2 * C; i++) ring[(size_t)i * RingGeom<P>::SLOT + lane] = Cx{0.0, 0.0};
-    }
-    const int ls = lane < C ? lane : C - 1;
-    auto clampi = [n](int i) { return i < n ? i : n - 1; };
-    double4 rec_n = series[clampi(ls)];
-    double dt_n = series[clampi(1 + ls)].x;
-    for (int c = 0; c < nchunks; c++) {
-        Cx* buf = ring + (size_t)(c & 1) * C * RingGeom<P>::SLOT + (lane & ~15) + jr;
-        const double4 rec_c = rec_n;
-        const double dt_c = dt_n;
-        const int kk0 = 1 + c * C;
-        rec_n = series[clampi(kk0 + C + ls - 1)];
-        dt_n = series[clampi(kk0 + C + ls)].x;
-        if (lane < C && kk0 + lane < n) recs[(c & 1) * C + lane] = make_double2(rec_c.y, rec_c.z);
-#pragma unroll 1
-        for (int s0 = 0; s0 < C; s0 += PPL) {
-            const int slot = s0 + sub;
-            const double dt = __shfl(dt_c, slot < C ? slot : C - 1, 64);
-            if (worker && slot < C && kk0 + slot < n) {
-                Cx rho;
-                cexp_step(w.re, w.im, dt, &rho.re, &rho.im);
-                buf[(size_t)slot * RingGeom<P>::SLOT] = rho;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // Consumer side: the RhoSrc policy of filter_loop that takes the factors from the ring.
 // (Reading the entries one step ahead was measured slower: 141 vs 127 us per 1024-eval launch.)
 template <int P, int G>
@@ -160,12 +113,6 @@ struct RhoRing {
     }
     CARMA_DEV double4 record(int) const { return double4{}; }
     CARMA_DEV void fetch(int, Cx&, Cx (&)[P]) const {}
-    // own factor only (row variant: the others come by DPP)
-    CARMA_DEV void fetch_own_s(int s, Cx& rho) const
-    {
-        const double2 o = reinterpret_cast<const double2*>(cbuf + (size_t)s * RingGeom<P>::SLOT)[g.lane()];
-        rho = Cx{o.x, o.y};
-    }
     // factors of the pass in slot s of the current chunk
     CARMA_DEV void fetch_s(int s, Cx& rho, Cx (&rj)[P]) const
     {
@@ -196,11 +143,7 @@ __device__ __forceinline__ double ring_consume(const Grp<G>& g, const Model<P>& 
     if (blockIdx.x == 0 && threadIdx.x == 0) printf("reset %llu ticks\n", r1 - r0);
 #endif
     RhoRing<P, G> src{g, ring};
-    double ll;
-    if constexpr (G == 16)
-        ll = filter_loop_row<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
-    else
-        ll = filter_loop_real<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
+    const double ll = filter_loop_real<P, G, false>(g, m, fc, src, series, n, nullptr, nullptr);
     *singular = fc.sing;
     return ll;
 }

@@ -148,24 +148,9 @@ struct Grp {
         double2 v = xch2[gbase() + j];
         return Cx{v.x, v.y};
     }
-    // --- one evaluation per 16-lane DPP row (G = 16): the three DPP blocks of filter_loop_row, each a
-    // single inline-asm statement (carma_row_asm.h, generated by tools/gen_row_asm.py).  "x@j" is
-    // the value of x held by lane j of the row, applied as a DPP row broadcast on the fmac's source.
-    //   var = e scale + s0 + sum_j h_j w@j ;  innov = y - mu - sum_j h_j z@j
-    template <int P>
-    CARMA_DEV void row_sums(double& var, double& innov, double e, double scale, double s0, double y, double mu, double w,
-                            double z, const double (&h)[P]) const
-    {
-        static_assert(G == 16, "row broadcast");
-        RowAsm<P>::sums(var, innov, e, scale, s0, y, mu, w, z, h);
-    }
-    //   nt = -(k s) ;  z += k si ;  D_j += k@j nt
-    template <int P>
-    CARMA_DEV void row_gain(double& nt, double& z, double (&D)[P], double k, double s, double si) const
-    {
-        static_assert(G == 16, "row broadcast");
-        RowAsm<P>::gain(nt, z, D, k, s, si);
-    }
+    // --- one evaluation per 16-lane DPP row (G = 16): DPP blocks as single inline-asm statements (carma_row_asm.h,
+    // generated by tools/gen_row_asm.py).  "x@j" is the value of x held by lane j of the row, applied as a DPP row
+    // broadcast on the fmac's source.
     //   mm_j = c@j D_j - s@j D_{j^1}
     template <int P>
     CARMA_DEV void row_colmix(double (&mm)[P], double c, double s, const double (&D)[P]) const

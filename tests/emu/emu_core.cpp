@@ -24,7 +24,7 @@ static void logdens_one(const double* theta, int q, const double4* series, int n
     });
 }
 
-// one evaluation per 16-lane row (filter_loop_row)
+// one evaluation per 16-lane group: the set-up path of the wave pipeline (all roots in one pass) with the generic loop
 template <int P>
 static void logdens_row_one(const double* theta, int q, const double4* series, int n, const Prior& pr, int ignore_prior,
                             double* out)

@@ -124,25 +124,7 @@ struct Grp {
         sh->bar.wait();
     }
     Cx peek2(int j) const { return Cx{sh->xch2[j][0], sh->xch2[j][1]}; }
-    // row blocks of filter_loop_row (device: carma_row_asm.h)
-    template <int P>
-    void row_sums(double& var, double& innov, double e, double scale, double s0, double y, double mu, double w, double z,
-                  const double (&h)[P]) const
-    {
-        var = fma(e, scale, s0);
-        innov = y - mu;
-        for (int j = 0; j < P; j++) {
-            var = fma(xchg(w, j), h[j], var);
-            innov = fma(-xchg(z, j), h[j], innov);
-        }
-    }
-    template <int P>
-    void row_gain(double& nt, double& z, double (&D)[P], double k, double s, double si) const
-    {
-        nt = -(k * s);
-        z = fma(k, si, z);
-        for (int j = 0; j < P; j++) D[j] = fma(xchg(k, j), nt, D[j]);
-    }
+    // DPP row blocks (device: carma_row_asm.h)
     template <int P>
     void row_colmix(double (&mm)[P], double c, double s, const double (&D)[P]) const
     {

@@ -155,7 +155,7 @@ def test_ragged_and_empty_batches(cpa, readme):
     g = readme
     ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3, max_stdev=_pop_var_stdev(g["y"]))
     big = np.tile(g["theta"], (40, 1))                        # 1280 evals
-    full = ctx.logdensity(big)                                # two-wave row kernel (> 1024 evaluations)
+    full = ctx.logdensity(big)                                # two pipeline workgroups per CU (> 1024 evaluations)
     full1k = ctx.logdensity(big[:1024])                       # four-wave pipeline (<= 1024 evaluations)
     assert ctx.logdensity(np.empty((0, 11))).shape == (0,)
     for B in (1, 7, 8, 9, 63, 65, 1023, 1025, 1279):
@@ -220,9 +220,9 @@ def test_full_size_properties(cpa, readme):
 
 @pytest.mark.parametrize("p,q", [(2, 1), (3, 2), (4, 0), (5, 3), (6, 5), (7, 2)])
 def test_launch_shapes_agree(cpa, p, q):
-    """The four launch shapes -- four-wave co-rotating pipeline (<= 1024 evaluations), two-wave row variant (<= 2048,
-    one evaluation per DPP row), G-lane producer/consumer (<= 512 waves) and the throughput kernel -- against
-    the oracle and each other."""
+    """The three launch shapes -- four-wave co-rotating pipeline (up to 3072 evaluations: one, two or three workgroups
+    per CU), G-lane producer/consumer (up to 512 waves) and the throughput kernel -- against the oracle and each
+    other."""
     t, y, yerr = irregular_series(203, seed=50 + p)
     rng = np.random.default_rng(500 + 10 * p + q)
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(48)])
@@ -231,8 +231,13 @@ def test_launch_shapes_agree(cpa, p, q):
     want = m.logdensity_batch(th, nthreads=8)
     from mp_truth import loglik_truth
     arb = lambda i: loglik_truth(t, y, yerr, th[i % 48], p, q)[0]   # noqa: E731
+    G = 2 if p <= 2 else (4 if p <= 4 else 8)
+    pc_small, pc_big = 3100, min(4000, 512 * (64 // G))            # beyond the pipeline, within 512 waves
     res = {}
-    for name, B in (("p3", 48), ("p3b", 1000), ("row", 1100), ("row2", 1500), ("pc", 3000), ("pc2", 4000), ("plain", 20000)):
+    shapes = [("p3", 48), ("p3b", 1000), ("p3c", 1100), ("p3d", 2000), ("p3e", 3072), ("plain", 70000)]
+    if pc_big > pc_small:
+        shapes += [("pc", pc_small), ("pc2", pc_big)]
+    for name, B in shapes:
         big = np.tile(th, (B // 48 + 1, 1))[:B]
         got = ctx.logdensity(big)
         # every copy of a theta gives the same bits, wherever it sits in the launch
@@ -240,11 +245,12 @@ def test_launch_shapes_agree(cpa, p, q):
         res[name] = got[:48]
         assert_parity(res[name], want, RTOL, "%s p=%d q=%d" % (name, p, q), arbiter=arb)
     fin = np.isfinite(want)
-    for name in ("p3", "p3b", "row", "row2", "pc", "pc2", "plain"):
+    for name in res:
         assert np.array_equal(np.isfinite(res[name]), fin)
-    assert np.array_equal(res["p3"], res["p3b"], equal_nan=True)
-    assert np.array_equal(res["row"], res["row2"], equal_nan=True)
-    assert np.array_equal(res["pc"], res["pc2"], equal_nan=True)
+    for name in ("p3b", "p3c", "p3d", "p3e"):                       # one kernel, whatever the number of workgroups per CU
+        assert np.array_equal(res["p3"], res[name], equal_nan=True), name
+    if "pc" in res:
+        assert np.array_equal(res["pc"], res["pc2"], equal_nan=True)
 
 
 @pytest.mark.parametrize("p,q", [(2, 0), (5, 3), (7, 4)])
@@ -262,7 +268,7 @@ def test_series_lengths_around_chunk_boundaries(cpa, p, q):
         dup = np.array([np.min(np.abs(r[:, None] - r[None, :]) + np.eye(p)) == 0.0 for r in roots])
         from mp_truth import loglik_truth
         arb = lambda i: loglik_truth(t, y, yerr, th[i % 12], p, q)[0]   # noqa: E731
-        for B in (12, 1100, 3000):       # four-wave pipeline / two-wave row kernel / G-lane producer-consumer
+        for B in (12, 1100, 3200):       # four-wave pipeline, one and two workgroups per CU / G-lane producer-consumer
             big = np.tile(th, (B // 12 + 1, 1))[:B]
             got = ctx.logdensity(big, ignore_prior=True)
             assert np.array_equal(got, np.tile(got[:12], B // 12 + 1)[:B], equal_nan=True), (n, B)
@@ -428,9 +434,9 @@ def test_corotating_frame_windows_and_rebases(cpa, p, q):
     fin = np.isfinite(want)
     assert fin.sum() >= 48 and np.array_equal(np.isfinite(got), fin)
     # (1) against the stepwise-rotation kernels, which share the model set-up: only the recursion differs
-    row = ctx.logdensity(np.tile(th, (20, 1)), ignore_prior=True)[:64]          # two-wave row variant
-    plain = ctx.logdensity(np.tile(th, (400, 1)), ignore_prior=True)[:64]       # throughput kernel
-    for other in (row, plain):
+    pc = ctx.logdensity(np.tile(th, (50, 1)), ignore_prior=True)[:64]           # G-lane producer/consumer (3200 evaluations)
+    plain = ctx.logdensity(np.tile(th, (1100, 1)), ignore_prior=True)[:64]      # throughput kernel
+    for other in (pc, plain):
         assert np.array_equal(np.isfinite(other), fin)
         assert np.max(np.abs(got[fin] - other[fin]) / np.abs(other[fin])) < 1e-11
     # (2) against the oracle, at the bar of every other parity test: 1e-10, or -- where the reference's own arithmetic
