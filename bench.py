@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mcmc", action="store_true", help="skip the secondary MCMC iterations/s leg")
     ap.add_argument("--mcmc-iters", type=int, default=2000)
+    ap.add_argument("--no-throughput", action="store_true", help="skip the throughput-regime leg (B = 65536)")
+    ap.add_argument("--no-ladder", action="store_true", help="skip the ladder-sharded leg (BASELINE configs[3] shape)")
+    ap.add_argument("--ladder-iters", type=int, default=150)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,24 +164,118 @@ def main():
             "config": "configs[2] shape: CARMA(5,3), n=270, 16 temperatures x 64 walkers per GPU, RAM adapting",
         }
 
+    # ---- throughput regime: the same kernel family with the chip full (B = 65536 per launch) ----------------
+    tput = None
+    if not args.no_throughput:
+        BT = 65536
+        big = torch.from_numpy(np.tile(pool_h[0], (BT // B + 1, 1))[:BT].copy()).to(dev)
+        outb = torch.empty(BT, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            ctx.logdensity_dev(big.data_ptr(), BT, outb.data_ptr(), ignore_prior=False, stream=sh)
+        torch.cuda.synchronize()
+        barrier()
+        NT = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tq0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(NT):
+            ctx.logdensity_dev(big.data_ptr(), BT, outb.data_ptr(), ignore_prior=False, stream=sh)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        barrier()
+        tq = time.perf_counter() - tq0
+        if dist is not None:
+            tt = torch.tensor([tq], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tq = float(tt.item())
+        flops_per_eval_ = (n - 1) * (42 * p * p + 22 * p + 9)
+        k_us = 1e3 * e0.elapsed_time(e1) / NT
+        tput = {
+            "metric": "Kalman log-lik evals/sec with the chip full (same series, %d evaluations per launch)" % BT,
+            "evals_per_s": world * BT * NT / tq, "batch_per_gpu": BT, "launches": NT, "kernel": ctx.kernel_name(BT),
+            "kernel_avg_us": k_us,
+            "fp64_valu": {"achieved_tflops": flops_per_eval_ * BT / (k_us * 1e-6) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                          "frac": flops_per_eval_ * BT / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          "note": "algorithmic flop count of the reference's complex recursion (SURVEY.md 8d)"},
+        }
+
+    # ---- ONE ladder sharded across the ranks (BASELINE configs[3]: CARMA(7,6), n = 10^4, 8 temperatures) -------
+    # N = 1: the whole ladder on one GPU.  N > 1: contiguous temperature blocks per rank, boundary chains exchanged
+    # with RCCL send/recv on the sampler's stream (carma_pt_iterate_sharded).  Iterations/s of the whole ladder.
+    ladder = None
+    if not args.no_ladder and 8 % world == 0:
+        from carma_pack_amd import _lib, parallel as par
+        from carma_pack_amd.synth import config4_series
+        t4, y4, e4, _ = config4_series(10000, seed=4)
+        TG, R4 = 8, 128
+        ctx4 = cpa.Context(t4, y4, e4, 7, 6, device=dev_index)
+        sh4 = par.LadderShard(ctx4, TG, R4, adapt_iters=10 ** 9, seed=17, dist=dist if world > 1 else None, device="cpu")
+        comm = None
+        if world > 1 and not share:      # (two ranks sharing one GPU: RCCL refuses; the torch.distributed stand-in runs)
+            comm = _lib.Comm.from_torch(dist, device=dev_index)
+            sh4.attach_comm(comm)
+        sh4.start()
+        if world > 1:
+            sh4.iterate(10)
+        else:
+            ctx4.pt_iterate(10)
+        barrier()
+        tl0 = time.perf_counter()
+        if world > 1:
+            sh4.iterate(args.ladder_iters)
+        else:
+            ctx4.pt_iterate(args.ladder_iters)
+        barrier()
+        tl = time.perf_counter() - tl0
+        if dist is not None:
+            tt = torch.tensor([tl], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tl = float(tt.item())
+        prop, acc_b = (sh4.nprop_boundary, sh4.nswap_boundary) if world > 1 else (0, 0)
+        ladder = {
+            "metric": "MCMC iterations/s of ONE temperature ladder sharded across the ranks",
+            "iters_per_s": args.ladder_iters / tl, "chain_evals_per_s": TG * R4 * args.ladder_iters / tl,
+            "temperatures": TG, "temperatures_per_rank": TG // world, "replicas": R4, "iters": args.ladder_iters,
+            "scaling": "strong",
+            "transport": ("rccl send/recv of %d doubles per boundary and iteration" % (R4 * 17 + 1)) if comm is not None
+            else ("torch.distributed stand-in (ranks share a GPU)" if world > 1 else "none (one block)"),
+            "rccl_ranks": comm.size if comm is not None else 1,
+            "boundary_swap_rate_rank0": (acc_b / prop) if prop else None,
+            "config": "configs[3] shape: CARMA(7,6), n=10000 (0.1+|Cauchy| steps), 8 temperatures x %d replicas" % R4,
+        }
+        if comm is not None:
+            comm.close()
+
     if rank == 0:
         value = world * B * args.steps / elapsed
         bytes_per_eval = 24 * n + 8 * d + 8
         flops_per_eval = (n - 1) * (42 * p * p + 22 * p + 9)
         achieved_gbs = bytes_per_eval * B / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-        # (profiles/r01: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB per dispatch; gfx950
-        # FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound)
-        traffic_gbs_bytes, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_v10.json")
-        pmc_extra = None
-        if B == 1024 and os.path.exists(pmc):
-            pj = json.load(open(pmc))
+        # HBM bytes per launch: the newest committed rocprofv3 PMC summary (profiles/r*/pmc_*.json, written by
+        # tools/profile_round.sh + tools/summarize_prof.py from separate --pmc passes of this same command) whose
+        # dispatch record names the kernel this run actually launched; none -> null, never a stale figure.
+        # (gfx950 FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound.)
+        kernel_name = ctx.kernel_name(B)
+        traffic_gbs_bytes, traffic_src, pmc_extra = None, None, None
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")), key=os.path.getmtime, reverse=True)
+        for pmc in cands:
+            try:
+                pj = json.load(open(pmc))
+            except ValueError:
+                continue
+            disp = (pj.get("_dispatch") or {}).get("Kernel_Name", "")
+            grid = (pj.get("_dispatch") or {}).get("Grid_Size", "")
+            if kernel_name not in disp.replace(" ", "") or "FETCH_SIZE" not in pj or "WRITE_SIZE" not in pj:
+                continue
+            if str(grid) != str(((B + 3) // 4) * 256):            # same launch shape (workgroups x 256 threads)
+                continue
             traffic_gbs_bytes = (2.0 * pj["FETCH_SIZE"]["mean"] + pj["WRITE_SIZE"]["mean"]) * 1024.0
-            # what actually bounds the kernel: the instruction stream of its critical wave
             pmc_extra = {k: pj[k]["mean"] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
                                                      "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if k in pj}
-            traffic_src = "profiles/r01/pmc_v10.json (rocprofv3 --pmc, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch"
+            traffic_src = "%s (rocprofv3 --pmc of this command, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch" % os.path.relpath(pmc, ROOT)
+            break
+        fp64_tflops = flops_per_eval * B / (kernel_ms * 1e-3) / 1e12
         res = {
             "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
             "value": value,
@@ -205,25 +302,30 @@ def main():
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic_gbs_bytes,
                 "traffic_source": traffic_src,
-                "kernel": ("k_logdens_carma_p3l<5>" if B <= 1024 else "k_logdens_carma_pc<5,16,2>" if B <= 2048 else
-                           "k_logdens_carma_pc<5,8,PAIRS>" if B <= 8192 else "k_logdens_carma<5,8,4>"),
+                "kernel": kernel_name,
                 "kernel_avg_us": 1e3 * kernel_ms,
                 "kernel_bracketed_avg_us": 1e3 * float(np.mean(kdur_ms)),
                 "kernel_bracketed_min_us": 1e3 * float(kdur_ms.min()),
                 "algorithmic_bytes_per_launch": bytes_per_eval * B,
-                "note": "latency/FP64-VALU bound by construction (sequential n-step recursion); "
-                        "HBM roofline reported as north_star asks",
+                "binding_resource": "fp64_valu_issue",
+                "note": "HBM roofline reported as north_star asks; the kernel is bound by the FP64 VALU issue rate of one "
+                        "wave's dependent instruction stream (sequential n-step recursion): see fp64_valu",
                 "pmc_per_launch": pmc_extra,
                 "fp64_valu": {
                     "flops_per_eval": flops_per_eval,
-                    "achieved_tflops": flops_per_eval * B / (kernel_ms * 1e-3) / 1e12,
+                    "achieved_tflops": fp64_tflops,
                     "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                    "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
                 },
             },
             "finite_in_last_batch": n_finite,
         }
         if mcmc is not None:
             res["mcmc"] = mcmc
+        if tput is not None:
+            res["throughput"] = tput
+        if ladder is not None:
+            res["ladder_sharded"] = ladder
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(t, y, yerr, p, q, max_stdev, pool_h[0], args.cpu_seconds)
         print(json.dumps(res), flush=True)

@@ -12,7 +12,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcarma_mi355.so")
+# CARMA_LIB_PATH: another build of the same C ABI (A/B measurements of kernel variants); default: the in-tree build
+LIB_PATH = os.environ.get("CARMA_LIB_PATH") or os.path.join(_HERE, "libcarma_mi355.so")
 
 CARMA_OK, CARMA_EINVAL, CARMA_ENODEV, CARMA_ENOMEM, CARMA_EHIP = 0, -22, -19, -12, -5
 PMAX = 7
@@ -86,6 +87,7 @@ def _load():
     L.carma_ctx_set_prior.argtypes = [C.c_void_p, C.c_double]
     L.carma_logdensity_batch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
     L.carma_logdensity_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.carma_logdensity_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     L.carma_logprior.argtypes = [C.c_void_p, _dp]
     L.carma_logprior.restype = C.c_double
     L.carma_kfilter_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp,
@@ -125,7 +127,7 @@ lib = _load()
 EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
-    "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logprior", "carma_kfilter_carma",
+    "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_kfilter_carma",
     "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
@@ -227,6 +229,12 @@ class Context:
         check(lib.carma_logdensity_batch_dev(self._h, C.c_void_p(d_theta_ptr), int(B), int(bool(ignore_prior)),
                                              C.c_void_p(d_out_ptr), C.c_void_p(stream)),
               "carma_logdensity_batch_dev")
+
+    def kernel_name(self, B):
+        """Name of the kernel a launch of B evaluations takes (carma_logdensity_kernel_name)."""
+        buf = C.create_string_buffer(128)
+        check(lib.carma_logdensity_kernel_name(self._h, int(B), buf, 128), "carma_logdensity_kernel_name")
+        return buf.value.decode()
 
     def logprior(self, theta):
         theta = as_f64(theta)

@@ -311,6 +311,13 @@ int carma_logdensity_batch(carma_ctx* h, const double* theta, int B, int ignore_
     return CARMA_OK;
 }
 
+int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len)
+{
+    if (!h || !buf || len < 1 || B < 1) return CARMA_EINVAL;
+    const Ctx* c = reinterpret_cast<const Ctx*>(h);
+    return logdens_kernel_name(c->p, B, c->n, buf, len) > 0 ? CARMA_OK : CARMA_EINVAL;
+}
+
 double carma_logprior(const carma_ctx* h, const double* theta)
 {
     if (!h || !theta) return std::numeric_limits<double>::quiet_NaN();

@@ -14,6 +14,7 @@
 // series (24 B/datum, shared by every evaluation and L2/scalar-cache resident) + 8(d+1) B/eval.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "grp_device.h"
@@ -99,25 +100,40 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     long e = ((long)blockIdx.x * 64 + lane64) / 16;
     const bool live = e < B;
     if (!live) e = B - 1;
+    CARMA_MARK_DECL;
+    CARMA_MARK(0);
     if (wave >= 2) {
         pipe3l_produce<P>(g, wave - 2, theta + e * d, series, n, ring, [](int) {});
+        CARMA_MARK(3);
+        CARMA_MARK_DUMP("producer", wave - 2);
         return;
     }
     Model<P> m;
     model_from_theta<P, 16>(g, theta + e * d, q, pr, ignore_prior, m);
+    CARMA_MARK(1);
     FilterConsts<P> fc;
     filter_reset<P, 16>(g, m, fc);
     RowConsts<P> rc;
     row_consts<P>(g, m, fc, rc);
+    CARMA_MARK(2);
     if (wave == 0) {
         pipe3l_cov<P>(g, m, rc, series, n, ring);
+        CARMA_MARK(3);
+        CARMA_MARK_DUMP("covariance", 0);
         return;
     }
+    // the log prior is evaluated HERE, while the mean wave would otherwise wait for the pipeline to fill, not after the
+    // recursion (a serial chain of ~1000 cycles on the critical path of the launch)
+    double lpri = log_prior(m.scale, pr.measerr_dof);
+    asm volatile("" : "+v"(lpri));
     double ll = pipe3l_mean<P>(g, m, rc, series, n, ring);
-    ll += log_prior(m.scale, pr.measerr_dof);
+    CARMA_MARK(3);
+    ll += lpri;
     const double ninf = -1.0 / 0.0;
     if (fc.sing || !m.valid) ll = ninf;
     if (live && g.lane() == 0) out[e] = ll;
+    CARMA_MARK(4);
+    CARMA_MARK_DUMP("mean", 0);
 }
 
 __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ theta, int B,
@@ -198,16 +214,31 @@ static long p3l_max_rows()
     return v;
 }
 
+// Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
+enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4 };
+template <int P>
+static LdShape logdens_shape(long B, int n)
+{
+    constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
+    const long waves = (B + EPW - 1) / EPW;
+    const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
+    if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
+    // few evaluations in flight: one wave's instruction stream is the run time, so split it (consumer + rho producer,
+    // carma_ring.h).  Beyond 512 waves (two rounds of workgroups) the plain kernel with pair-shared exp/sincos is
+    // ahead: 104 vs 111 us at 6144 evaluations (tools/midrange_probe.py)
+    if (waves <= 256 && n >= 8) return LdShape::PC1;
+    if (waves <= 512 && n >= 8) return LdShape::PC2;
+    return waves <= 2048 ? LdShape::PLAIN1 : LdShape::PLAIN4;
+}
+
 template <int P>
 static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, const double4* series, int n,
                                    const Prior& pr, int ignore_prior, double* out, hipStream_t st)
 {
     constexpr int G = GroupOf<P>::value;
     constexpr int EPW = 64 / G;   // evaluations per wave
-    // Latency-bound path: spread waves over as many CUs as possible (1 wave/block) until the
-    // chip is covered, then pack 4 waves per block.
     const long waves = ((long)B + EPW - 1) / EPW;
-    const long rows = ((long)B + 3) / 4;      // waves with one evaluation per 16-lane DPP row
+    const long rows = ((long)B + 3) / 4;
     auto launch_pc = [&](auto kern, long npairs, int pairs) -> hipError_t {
         const size_t lds = (size_t)pairs * (128 * sizeof(double4) + RingGeom<P>::BYTES);
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -217,35 +248,54 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
                            series, n, pr, ignore_prior, out);
         return hipGetLastError();
     };
-    // Kernels with > 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize.  It is set
-    // before EVERY such launch: setting it once per process is not enough -- after a
-    // hipFuncSetAttribute / occupancy query on another kernel of the module (carma_pt_create does
-    // that) a later 81 KiB launch failed with hipErrorUnknown.  The call costs ~1 us on the host and
-    // the launches are asynchronous.
-    auto big_lds = [](const void* kf) { return hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
-    if (rows <= p3l_max_rows() && n >= 8) {
-        // covariance wave + mean wave + two producer waves per four evaluations, co-rotating frame (carma_pipe3l.h);
-        // 42 KiB of LDS: up to three workgroups per CU
-        const size_t lds = Pipe3LGeom<P>::BYTES;
-        hipError_t ea = big_lds(reinterpret_cast<const void*>(&k_logdens_carma_p3l<P>));
-        if (ea != hipSuccess) return ea;
-        hipLaunchKernelGGL((k_logdens_carma_p3l<P>), dim3((unsigned)rows), dim3(256), lds, st, theta, B, d, q, series, n, pr,
-                           ignore_prior, out);
-        return hipGetLastError();
-    } else if (waves <= 512 && n >= 8) {
-        // few evaluations in flight: one wave's instruction stream is the run time, so split it
-        // (consumer + rho producer, carma_ring.h).  Beyond 512 waves (two rounds of workgroups) the plain kernel
-        // with pair-shared exp/sincos is ahead: 104 vs 111 us at 6144 evaluations (tools/midrange_probe.py)
-        return waves <= 256 ? launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1) : launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);
-    } else if (waves <= 2048) {
-        hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n,
-                           pr, ignore_prior, out);
-    } else {
-        const long blocks = (waves + 3) / 4;
-        hipLaunchKernelGGL((k_logdens_carma<P, G, 4>), dim3((unsigned)blocks), dim3(256), 0, st, theta, B, d, q, series,
-                           n, pr, ignore_prior, out);
+    switch (logdens_shape<P>(B, n)) {
+        case LdShape::P3L:
+            // covariance wave + mean wave + two producer waves per four evaluations, co-rotating frame
+            // (carma_pipe3l.h); 42 KiB of LDS: up to three workgroups per CU
+            hipLaunchKernelGGL((k_logdens_carma_p3l<P>), dim3((unsigned)rows), dim3(256), Pipe3LGeom<P>::BYTES, st, theta, B, d, q,
+                               series, n, pr, ignore_prior, out);
+            return hipGetLastError();
+        case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);
+        case LdShape::PC2: return launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);
+        case LdShape::PLAIN1:
+            // spread the waves over as many CUs as possible (1 wave per workgroup) until the chip is covered
+            hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n, pr,
+                               ignore_prior, out);
+            return hipGetLastError();
+        case LdShape::PLAIN4:
+            hipLaunchKernelGGL((k_logdens_carma<P, G, 4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, theta, B, d, q,
+                               series, n, pr, ignore_prior, out);
+            return hipGetLastError();
     }
-    return hipGetLastError();
+    return hipErrorInvalidValue;
+}
+
+template <int P>
+static int logdens_name_p(long B, int n, char* buf, int len)
+{
+    constexpr int G = GroupOf<P>::value;
+    switch (logdens_shape<P>(B, n)) {
+        case LdShape::P3L: return snprintf(buf, len, "k_logdens_carma_p3l<%d>", P);
+        case LdShape::PC1: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,1>", P, G);
+        case LdShape::PC2: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,2>", P, G);
+        case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1>", P, G);
+        case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4>", P, G);
+    }
+    return -1;
+}
+
+int logdens_kernel_name(int p, long B, int n, char* buf, int len)
+{
+    switch (p) {
+        case 1: return snprintf(buf, len, "k_logdens_car1");
+        case 2: return logdens_name_p<2>(B, n, buf, len);
+        case 3: return logdens_name_p<3>(B, n, buf, len);
+        case 4: return logdens_name_p<4>(B, n, buf, len);
+        case 5: return logdens_name_p<5>(B, n, buf, len);
+        case 6: return logdens_name_p<6>(B, n, buf, len);
+        case 7: return logdens_name_p<7>(B, n, buf, len);
+        default: return -1;
+    }
 }
 
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,

@@ -72,7 +72,8 @@ struct Pipe3LGeom {
     static constexpr int LINK_OFF = 3 * C * SLOT;               // double2 {k~_r, var}[2][C][SLOT]
     static constexpr int CONST_OFF = LINK_OFF + 2 * C * SLOT;   // double2 {h_r, c_r}[SLOT]
     static constexpr int FLAG_OFF = CONST_OFF + SLOT;           // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
-    static constexpr int ENTRIES = FLAG_OFF + 2;
+    static constexpr int TAIL_OFF = FLAG_OFF + 2;               // double[2][C]: yerr^2 (wave A) and y (wave B) of the last, partial chunk
+    static constexpr int ENTRIES = TAIL_OFF + C;
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 41.8 KiB
     static constexpr double LIM_RE = 200.0;                     // |Re omega| dt_acc: scale factors within e^+-200; S carries their
                                                                 // squares (5e173 at most: room for any variance below 1e130;
@@ -273,8 +274,22 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
 #pragma unroll
             for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, ev[s]);
         } else {
+            // The last, shorter chunk runs as a rolled loop.  Its yerr_j^2 come through LDS (one vector load, lane s <->
+            // datum s, staged once; read back one pass ahead like the ring entries): a scalar load inside the pass made
+            // every LDS wait drain an L2 round trip as well -- 600 instead of 230 cycles per datum, 2 us per evaluation
+            // of a 270-point series.
+            double* tail = reinterpret_cast<double*>(ring + Geo::TAIL_OFF);
+            const int jt = j0 + (lane & 15);
+            const double ez = series[jt < n ? jt : n - 1].z;
+            if (lane < C) tail[lane] = ez;
+            g.sync();
+            double e_n = tail[0];
 #pragma unroll 1
-            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u, series[j0 + s].z);
+            for (int s = 0; s < len; s++) {
+                const double e = readlane_f64(e_n, 0);
+                e_n = tail[s + 1 < C ? s + 1 : s];
+                pass(s, true, (fm >> s) & 1u, e);
+            }
         }
     }
     __syncthreads();                                          // barrier nc
@@ -345,8 +360,19 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
 #pragma unroll
             for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, yv[s]);
         } else {
+            // last, shorter chunk: y_j staged through LDS (see the covariance wave)
+            double* tail = const_cast<double*>(reinterpret_cast<const double*>(ring + Geo::TAIL_OFF)) + C;
+            const int jt = j0 + (lane & 15);
+            const double yz = series[jt < n ? jt : n - 1].y;
+            if (lane < C) tail[lane] = yz;
+            g.sync();
+            double y_n = tail[0];
 #pragma unroll 1
-            for (int s = 0; s < len; s++) pass(s, true, (fm >> s) & 1u, series[j0 + s].y);
+            for (int s = 0; s < len; s++) {
+                const double yj = readlane_f64(y_n, 0);
+                y_n = tail[s + 1 < C ? s + 1 : s];
+                pass(s, true, (fm >> s) & 1u, yj);
+            }
         }
     }
     return acc.total();

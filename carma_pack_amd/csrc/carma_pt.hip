@@ -329,8 +329,10 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             if (wave == 0) {
                 pipe3l_cov<P>(g, m, rc, series, L.n, ring);
             } else {
+                double lpri = log_prior(m.scale, pr.measerr_dof);       // before the recursion: off the critical path
+                asm volatile("" : "+v"(lpri));
                 double ll = pipe3l_mean<P>(g, m, rc, series, L.n, ring);
-                ll += log_prior(m.scale, pr.measerr_dof);
+                ll += lpri;
                 if (fc.sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;
             }

@@ -69,3 +69,41 @@ def irregular_series(n, seed):
     y = 17.0 + 2.3 * np.sin(t / 7.0) + 1.1 * np.cos(t / 31.0) + 0.6 * rng.standard_normal(n)
     yerr = np.full(n, 0.45) * rng.uniform(0.8, 1.2, n)
     return t, y, yerr
+
+
+def config4_model():
+    """BASELINE configs[3]: CARMA(7,6) with three quasi-periodic pairs and one real root.  Returns
+    (ar_roots[7], ma_coefs[7], sigma_y)."""
+    from .carma_pack import get_ar_roots
+    # centroids in descending order: the prior bounds want them non-increasing (carpack.cpp:353-362)
+    ar_roots = get_ar_roots(np.array([1.0 / 50.0, 1.0 / 100.0, 1.0 / 300.0, 1.0 / 500.0]),
+                            np.array([1.0 / 2.0, 1.0 / 5.0, 1.0 / 25.0]))
+    ma_roots = -2.0 * np.pi * np.array([0.3 + 0.4j, 0.3 - 0.4j, 0.08 + 0.15j, 0.08 - 0.15j, 0.9 + 0.0j, 0.02 + 0.0j])
+    c = np.poly(ma_roots)                       # highest order first
+    ma_coefs = np.real(c / c[-1])[::-1]         # constant term 1, lowest order first
+    return ar_roots, ma_coefs, 2.3
+
+
+def config4_series(n=10000, seed=4):
+    """BASELINE configs[3] input: a long irregular series -- time steps 0.1 + |Cauchy| as the reference's
+    cpp_tests/generate_test_data.py:17-19 draws them, heteroscedastic errors as :13, and a CARMA(7,6) path drawn by
+    this package's own carma_process.  Returns (t, y, yerr, theta_true)."""
+    from .carma_pack import carma_process, carma_variance
+    rng = np.random.default_rng(seed)
+    ar_roots, ma_coefs, sigmay = config4_model()
+    yerr = 0.1 * sigmay * np.sqrt(10.0 / rng.chisquare(10.0, n))
+    t = np.cumsum(0.1 + np.abs(rng.standard_cauchy(n)))
+    t = t - t.min()
+    sigsqr = sigmay ** 2 / carma_variance(1.0, ar_roots, ma_coefs)
+    y = carma_process(t, sigsqr, ar_roots, ma_coefs, rng=rng) + rng.normal(0.0, yerr)
+    ma_roots = np.roots(ma_coefs[::-1])
+    # MA log-quadratic parameters in the reference's pairing (conjugate pairs first, real roots paired in order)
+    cp_ = sorted([r for r in ma_roots if r.imag < -1e-12], key=lambda r: r.real)
+    re_ = sorted([r.real for r in ma_roots if abs(r.imag) <= 1e-12])
+    lq = []
+    for r in cp_:
+        lq += [np.log(abs(r) ** 2), np.log(-2.0 * r.real)]
+    for a, b in zip(re_[0::2], re_[1::2]):
+        lq += [np.log(a * b), np.log(-(a + b))]
+    theta = np.concatenate([[sigmay, 1.0, 0.0], log_quads_from_roots(ar_roots), lq])
+    return t, y, yerr, theta

@@ -74,6 +74,10 @@ int carma_logdensity_batch(carma_ctx* h, const double* theta, int B, int ignore_
 int carma_logdensity_batch_dev(carma_ctx* h, const double* d_theta, int B, int ignore_prior,
                                double* d_out, void* stream);
 
+/* Which kernel a launch of B evaluations on this context takes (the launch shape depends on B: DESIGN.md section 3);
+ * the name as rocprofv3 lists it, without namespace and argument list.  For measurement scripts. */
+int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len);
+
 /* getLogPrior (carpack.hpp:118-126, wrapper :50,58,67); host arithmetic, one vector. */
 double carma_logprior(const carma_ctx* h, const double* theta);
 

@@ -32,7 +32,7 @@ def _json_line(out):
 
 def test_single_gpu_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5", "--mcmc-iters", "200",
-                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-seconds", "1", "--ladder-iters", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert KEYS | {"cpu_baseline"} <= set(j)
@@ -42,16 +42,25 @@ def test_single_gpu_line():
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 1024) < 1e-6 * 1024
+    # the kernel label comes from the library's own launch table, the counters from a profile of that very kernel
+    assert rf["kernel"] == "k_logdens_carma_p3l<5>" and rf["binding_resource"] == "fp64_valu_issue"
+    assert rf["traffic"] is None or (rf["traffic_source"] and rf["traffic"] < rf["algorithmic_bytes_per_launch"])
+    assert 0.0 < rf["fp64_valu"]["frac"] < 1.0
+    tp, ld = j["throughput"], j["ladder_sharded"]
+    assert tp["batch_per_gpu"] == 65536 and tp["kernel"] == "k_logdens_carma<5,8,4>" and tp["evals_per_s"] > j["value"]
+    assert ld["temperatures"] == 8 and ld["replicas"] == 128 and ld["rccl_ranks"] == 1 and ld["iters_per_s"] > 0
 
 
 def test_two_ranks_sharing_the_gpu():
     env = dict(os.environ, CARMA_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "50", "--warmup", "5", "--mcmc-iters", "200"],
+                        "--gpus", "2", "--steps", "50", "--warmup", "5", "--mcmc-iters", "200", "--ladder-iters", "6"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert KEYS <= set(j) and "cpu_baseline" not in j                      # CPU leg runs on rank 0 at N=1 only
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["finite_in_last_batch"] == 1024
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 2 * 1024) < 1e-6 * 2048          # whole-job aggregate
+    ld = j["ladder_sharded"]                                                 # one ladder of 8 temperatures, 4 per rank
+    assert ld["temperatures_per_rank"] == 4 and ld["scaling"] == "strong" and 0.0 < ld["boundary_swap_rate_rank0"] < 1.0

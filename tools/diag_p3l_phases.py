@@ -1,16 +1,18 @@
-"""Phase timings of the latency-regime pipeline (carma_pipe3l.h): cycles per chunk of every wave, set-up time, from the
-diagnostic build  DIAG_FLAGS=-DCARMA_DBG tools/build_diag.sh  (device printf of workgroup 0; third launch = warm)."""
+"""Phase timings of the latency-regime pipeline (carma_pipe3l.h) from the diagnostic build (tools/build_diag.sh,
+-DCARMA_STAMPS): core-clock marks of the four waves of workgroup 0 in a FULL launch of 1024 evaluations --
+marks: 1 model set up, 2 constants ready, 3 recursion done, 4 result stored.  Third launch = warm."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import carma_pack_amd._lib as L0
-L0.LIB_PATH = os.path.join(ROOT, "build_diag", "libcarma_mi355_diag.so")
-L0.lib = L0._load()
+os.environ["CARMA_LIB_PATH"] = os.path.join(ROOT, "build_diag", "libcarma_mi355_diag.so")
+import carma_pack_amd as cpa
 from carma_pack_amd.synth import theta_batch
 g = np.load(os.path.join(ROOT, 'tests/golden/carma53_readme.npz'))
 t, y, yerr = g['t'], g['y'], g['yerr']
-th = theta_batch(np.random.default_rng(2), 4, 5, 3, t, y, theta_center=g['theta'][0])
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-ctx = L0.Context(t[:n], y[:n], yerr[:n], 5, 3, max_stdev=10 * y.std())
-ctx.logdensity(th, ignore_prior=True); ctx.logdensity(th, ignore_prior=True); print("---- third"); print(ctx.logdensity(th, ignore_prior=True))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+th = theta_batch(np.random.default_rng(2), B, 5, 3, t, y, theta_center=g['theta'][0])
+ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=10 * y.std())
+for i in range(3):
+    print("---- launch %d" % i, flush=True)
+    ctx.logdensity(th, ignore_prior=True)
