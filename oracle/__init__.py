@@ -16,5 +16,6 @@ from .oracle import (  # noqa: F401
     predict_car1,
     predict_carma,
     sort_dedup,
+    truth_logdensity,
     variance,
 )

@@ -5,15 +5,23 @@ import numpy as np
 from carma_pack_amd.synth import irregular_series, log_quads_from_roots, prior_like_theta, theta_batch  # noqa: F401,E402
 
 
-def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=40, arb_factor=1.0):
+def loglik_truth(t, y, yerr, theta, p, q):
+    """(log-likelihood + log prior, log-likelihood) of the reference's formulas to > 20 digits: the arbiter of the parity
+    tests.  Quad-precision restatement in C (oracle/carma_truth_q.c), itself pinned against the 50-digit mpmath version
+    (tests/mp_truth.py) in tests/test_oracle_golden.py; ~100x faster, so EVERY entry that needs it can be arbitrated."""
+    import oracle as orc
+    return orc.truth_logdensity(t, y, yerr, theta, p, q)
+
+
+def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=10 ** 6, arb_factor=1.0):
     """north_star bar: |got-want| <= 1e-10 |want| where finite; identical -inf/NaN pattern.
 
     Where roots cluster (cond(EigenMat) >~ 1e6; the prior admits roots 1e-4 apart) the REFERENCE's arithmetic --
     an LU solve of the Vandermonde system and p-term sums that cancel -- is itself 1e-10 ... 1e-3 away from the exact
     value of its own formulas, so its restatement cannot be the yardstick there.  If `arbiter(i)` is given it returns
-    the 50-digit value of entry i (tests/mp_truth.py); an entry that differs from the oracle by more than rtol passes
-    only when the GPU is within rtol of the exact value or NO FURTHER from it than the oracle is (arb_factor 1.0:
-    "never worse than the reference").  `max_arbitrated` only bounds the time spent in 50-digit arithmetic."""
+    the exact value of entry i (helpers.loglik_truth: quad precision, > 20 digits); an entry that differs from the
+    oracle by more than rtol passes only when the GPU is within rtol of the exact value or NO FURTHER from it than the
+    oracle is (arb_factor 1.0: "never worse than the reference")."""
     got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
     assert got.shape == want.shape
     fin = np.isfinite(want)
@@ -30,10 +38,10 @@ def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=4
             truth = arbiter(int(i))
             eg, eo = abs(got[i] - truth), abs(want[i] - truth)
             assert eg <= max(rtol * abs(truth), arb_factor * eo), (
-                "%s: entry %d differs from the oracle by %.2e and is further from the 50-digit value "
+                "%s: entry %d differs from the oracle by %.2e and is further from the exact value "
                 "(gpu err %.2e, oracle err %.2e)" % (what, i, abs(got[i] - want[i]) / abs(want[i]),
                                                      eg / abs(truth), eo / abs(truth)))
-            print("%s: entry %d arbitrated: gpu err %.2e, oracle err %.2e vs 50-digit value" % (
+            print("%s: entry %d arbitrated: gpu err %.2e, oracle err %.2e vs the exact (quad-precision) value" % (
                 what, i, eg / abs(truth), eo / abs(truth)))
         ok = np.ones(rel.size, dtype=bool)
         ok[np.isin(idx, bad)] = False

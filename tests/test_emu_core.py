@@ -32,7 +32,7 @@ def test_emu_orders(p, q):
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(12)])
     m = orc.OracleModel(t, y, yerr, p, q)
     pr = (m.max_stdev, m.max_freq, m.min_freq)
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     for ign in (False, True):
         got = emu.logdensity_carma(t, y, yerr, p, q, th, pr, ignore_prior=ign)
         assert_parity(got, m.logdensity_batch(th, ignore_prior=ign), 1e-10, "emu p=%d q=%d" % (p, q),
@@ -52,7 +52,7 @@ def test_emu_row_loop(p, q, golden_dir):
         th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(8)])
     m = orc.OracleModel(t, y, yerr, p, q)
     pr = (m.max_stdev, m.max_freq, m.min_freq)
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     got = emu.logdensity_carma_row(t, y, yerr, p, q, th, pr)
     assert_parity(got, m.logdensity_batch(th), 1e-10, "emu row p=%d q=%d" % (p, q),
                   arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])

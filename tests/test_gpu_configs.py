@@ -1,0 +1,219 @@
+"""The five BASELINE.json configs at their stated shape, on one MI355X (-m gpu), each checked against the CPU oracle
+and against the reference's own criteria:
+
+  configs[0]  CAR(1), n=100, one chain                      (plumbing: oracle == golden is the CPU test; here GPU == oracle)
+  configs[1]  CARMA(5,3), n=270, 1024 batched evaluations    (test_gpu_parity.py::test_config2_batch_1024 + bench.py)
+  configs[2]  CARMA(5,3), n=270, full PT-MCMC: 25 000 burn-in + 50 000 samples, 16 temperatures x 64 walkers
+  configs[3]  CARMA(7,6), n=10 000, 8 temperatures x 128 replicas (one GPU holds the whole ladder; the ladder sharded
+              over blocks through carma_pt_iterate_sharded / RCCL is the second half of the test)
+  configs[4]  every (p, q), p <= 7, q < p on OGLE-LMC-LPV-00007: 28 x 100 evaluations in one mixed batch, and
+              choose_order(pmax=7, ntrials=100) against per-start scipy L-BFGS-B
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from helpers import assert_parity, prior_like_theta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import carma_pack_amd
+    assert carma_pack_amd._lib.lib.carma_device_count() >= 1
+    return carma_pack_amd
+
+
+def _pop_stdev(y):
+    return 10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)
+
+
+def test_config0_car1_plumbing(cpa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "car1_n100.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ctx = cpa.Context(t, y, yerr, 1, 0)
+    th = g["theta"][0]
+    ll = ctx.logdensity(th) - ctx.logprior(th)
+    assert abs(ll - g["dense_loglik"][0]) <= 1e-10 * abs(ll)          # closed-form dense GP (carma_unit_tests.cpp:305-336)
+    assert abs(ctx.logdensity(th) - orc.OracleModel(t, y, yerr, 1).logdensity(th)) <= 1e-12 * abs(ll)
+
+
+def test_config2_full_pt_mcmc(cpa, golden_dir):
+    """README run (README.md:65-71): run_mcmc(50000) = 25 000 burn-in + 50 000 samples; here 64 independent ladders of
+    16 temperatures at once (7.68e7 chain evaluations).  Checks: the reference's invariant stored log-posterior ==
+    LogDensity(sample) (carma_unit_tests.cpp:917-1114) on a stride of the 3.2 million samples, and its recovery
+    criterion |posterior mean - truth| < 3 posterior sd for log sigma_y, the error scale, mu, the AR parameters and the
+    MA coefficients (carma_unit_tests.cpp:1642-1656)."""
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ms = _pop_stdev(y)
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms)
+    T, R, nb, ns = 16, 64, 25000, 50000
+    t0 = time.perf_counter()
+    samples, lp = ctx.pt_run(T, R, ns, nb, 1, seed=2024)
+    dt = time.perf_counter() - t0
+    assert samples.shape == (R, ns, 11) and ctx.pt_iterations_done() == nb + ns and np.all(np.isfinite(lp))
+    print("config 2: %d iterations x %d chains in %.2f s = %.0f it/s" % (nb + ns, T * R, dt, (nb + ns) / dt))
+    m = orc.OracleModel(t, y, yerr, 5, 3, max_stdev=ms)
+    sub = samples[:, ::2503].reshape(-1, 11)                           # 64 x 20 samples
+    from helpers import loglik_truth
+    assert_parity(lp[:, ::2503].reshape(-1), m.logdensity_batch(sub, nthreads=os.cpu_count() or 8), 1e-10, "stored logpost",
+                  arbiter=lambda i: loglik_truth(t, y, yerr, sub[i], 5, 3)[0])
+    truth = g["theta"][0]
+    pooled = samples[:, ::5].reshape(-1, 11)
+    zs = {"log sigma_y": (np.log(pooled[:, 0]).mean() - np.log(truth[0])) / np.log(pooled[:, 0]).std(),
+          "scale": (pooled[:, 1].mean() - truth[1]) / pooled[:, 1].std(), "mu": (pooled[:, 2].mean() - truth[2]) / pooled[:, 2].std()}
+    for j in range(5):
+        zs["ar%d" % j] = (pooled[:, 3 + j].mean() - truth[3 + j]) / pooled[:, 3 + j].std()
+    from carma_pack_amd import carma_pack as cp
+    c = cp._poly_from_roots(cp._roots_from_log_quads(pooled[:, 8:11]))
+    ma = (c / c[:, 3:4])[:, ::-1].real
+    for j, b in enumerate((4.5, 1.25, 0.0)):                            # README MA polynomial 1 + 4.5 s + 1.25 s^2
+        zs["ma%d" % (j + 1)] = (ma[:, j + 1].mean() - b) / ma[:, j + 1].std()
+    print("z-scores:", {k: round(float(v), 2) for k, v in zs.items()})
+    assert all(abs(v) < 3.0 for v in zs.values()), zs
+    # every replica found the mode, the ladders mix
+    assert lp[:, -1000:].max(axis=1).min() > m.logdensity(truth) - 12.0
+    acc, swp = ctx.pt_stats()
+    assert 0.1 < acc[:, 0].mean() < 0.5 and swp[:, 1:].mean() > 0.05
+
+
+def _config3(cpa):
+    from carma_pack_amd.synth import config4_series
+    t, y, e, theta_true = config4_series(10000, seed=4)
+    return t, y, e, theta_true
+
+
+def test_config3_long_series_ladder(cpa):
+    """CARMA(7,6), n = 10 000 (0.1 + |Cauchy| time steps, own CARMA draw), 8 temperatures x 128 replicas on one GPU for
+    240 iterations: stored log-posterior == oracle LogDensity for EVERY one of the 1024 chains (hot chains included),
+    the ladder swaps, and the chains move uphill from their prior-like starts."""
+    t, y, e, theta_true = _config3(cpa)
+    ctx = cpa.Context(t, y, e, 7, 6)
+    m = orc.OracleModel(t, y, e, 7, 6, max_stdev=ctx.prior()[0])
+    assert np.isfinite(m.logdensity(theta_true))
+    T, R, it = 8, 128, 240
+    ctx.pt_create(T, R, adapt_iters=10 ** 6, seed=44)
+    ctx.pt_start(None)
+    _, lp0 = ctx.pt_get_chains()
+    t0 = time.perf_counter()
+    ctx.pt_iterate(it)
+    dt = time.perf_counter() - t0
+    print("config 3 shape: %d iterations x %d chains, n=10000, in %.2f s = %.0f it/s" % (it, T * R, dt, it / dt))
+    th, lp = ctx.pt_get_chains()
+    flat = th.reshape(-1, 16)
+    from helpers import loglik_truth
+    assert_parity(lp.reshape(-1), m.logdensity_batch(flat, nthreads=os.cpu_count() or 8), 1e-10, "config 3 chain states",
+                  arbiter=lambda i: loglik_truth(t, y, e, flat[i], 7, 6)[0])
+    acc, swp = ctx.pt_stats()
+    assert acc.mean() > 0.02 and swp[:, 1:].mean() > 0.01
+    assert np.median(lp[:, 0]) > np.median(lp0[:, 0])                   # the cold chains climbed
+
+
+def _sharded_worker(q, blocks, T, R, it, seed):
+    import carma_pack_amd as cpa
+    from carma_pack_amd import _lib, parallel as par
+    from carma_pack_amd.synth import config4_series
+    t, y, e, _ = config4_series(10000, seed=4)
+    temps = par.ladder_temperatures(T)
+    comm = _lib.Comm(_lib.Comm.unique_id(), 1, 0, device=0)
+    ctxs, slot0 = [], 0
+    for Tl in blocks:
+        c = cpa.Context(t, y, e, 7, 6)
+        c.pt_create(Tl, R, 10 ** 6, seed=seed, temperatures=temps[slot0:slot0 + Tl])
+        c.pt_shard(T, slot0, 0)
+        c.pt_start(None)
+        ctxs.append(c)
+        slot0 += Tl
+    import time as _t
+    t0 = _t.perf_counter()
+    _lib.pt_iterate_sharded(ctxs, it, comm)
+    dt = _t.perf_counter() - t0
+    q.put([(c.pt_get_chains(), c.pt_boundary_stats()) for c in ctxs] + [dt])
+    comm.close()
+
+
+def test_config3_ladder_sharded_over_rccl():
+    """The same ladder split into blocks (4 + 4 temperatures, then one per block as on 8 GPUs), the boundary chains
+    travelling through carma_pt_iterate_sharded's RCCL send/recv (to the process's own rank: the box has one GPU):
+    stored log-posterior == oracle for every chain of every block, boundary swaps accepted on every boundary."""
+    import torch.multiprocessing as mp
+    from carma_pack_amd.synth import config4_series
+    from helpers import loglik_truth
+    t, y, e, _ = config4_series(10000, seed=4)
+    m = orc.OracleModel(t, y, e, 7, 6, max_stdev=10.0 * np.sqrt(np.var(y, ddof=1)))
+    for blocks, R, it in (([4, 4], 128, 40), ([1] * 8, 32, 24)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        p = ctx.Process(target=_sharded_worker, args=(q, blocks, 8, R, it, 91))
+        p.start()
+        out = q.get(timeout=900)
+        p.join(120)
+        assert p.exitcode == 0
+        dt = out.pop()
+        print("config 3 sharded %s: %d iterations, R=%d: %.0f it/s" % (blocks, it, R, it / dt))
+        th = np.concatenate([o[0][0] for o in out], axis=1).reshape(-1, 16)
+        lp = np.concatenate([o[0][1] for o in out], axis=1).reshape(-1)
+        assert_parity(lp, m.logdensity_batch(th, nthreads=os.cpu_count() or 8), 1e-10, "sharded %s" % blocks,
+                      arbiter=lambda i: loglik_truth(t, y, e, th[i], 7, 6)[0])
+        prop = [o[1][0] for o in out]
+        acc = [o[1][1] for o in out]
+        assert all(p_ > 0 for p_ in prop) and all(a > 0 for a in acc), (prop, acc)
+
+
+def test_config4_mixed_order_batch(cpa, golden_dir):
+    """All 28 (p, q) with p <= 7, q < p on OGLE-LMC-LPV-00007 (n = 437), 100 prior-like parameter vectors each with the
+    prior bounds ignored (the MLE path, SetMLE(true)): 2800 evaluations, one launch per order, against the oracle."""
+    og = np.loadtxt(os.path.join(golden_dir, "ogle_lmc_lpv_00007.dat"))
+    t, y, e = og[:, 0], og[:, 1], og[:, 2]
+    rng = np.random.default_rng(5)
+    from helpers import loglik_truth
+    narb = 0
+    for p in range(1, 8):
+        for q in range(p):
+            th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(100)])
+            ctx = cpa.Context(t, y, e, p, q)
+            got = ctx.logdensity(th, ignore_prior=True)
+            m = orc.OracleModel(t, y, e, p, q, max_stdev=ctx.prior()[0])
+            want = m.logdensity_batch(th, ignore_prior=True, nthreads=os.cpu_count() or 8)
+            if p == 1:
+                np.testing.assert_allclose(got, want, rtol=1e-10)
+                continue
+            fin = np.isfinite(want)
+            narb += int(np.sum(np.abs(got[fin] - want[fin]) > 1e-10 * np.abs(want[fin])))
+            assert_parity(got, want, 1e-10, "OGLE p=%d q=%d" % (p, q),
+                          arbiter=lambda i: loglik_truth(t, y, e, th[i], p, q)[0])
+    print("config 4: 2800 evaluations, %d arbitrated" % narb)
+
+
+def test_config4_choose_order_vs_scipy(cpa, golden_dir):
+    """choose_order(pmax=7, ntrials=100) (carma_pack.py:131-192): 28 orders x 100 random starts, lock-step batched
+    L-BFGS on the GPU objective.  Against it: scipy's L-BFGS-B from the SAME starts on the same objective (the
+    reference's optimiser, carma_pack.py:250) -- the batched optimiser must find an optimum at least as good (to 0.5 in
+    -log L, out of ~ -1000) for every order, hence the same AICc ranking up to that slack; and the MLE objective itself
+    is the oracle's: -LogDensity(x, ignore_prior) at every optimum."""
+    og = np.loadtxt(os.path.join(golden_dir, "ogle_lmc_lpv_00007.dat"))
+    t, y, e = og[:, 0], og[:, 1], og[:, 2]
+    model = cpa.CarmaModel(t, y, e)
+    t0 = time.perf_counter()
+    best, pqlist, aicc = model.choose_order(7, ntrials=100, seed=1)
+    dt = time.perf_counter() - t0
+    print("choose_order(pmax=7, ntrials=100): %.1f s, chosen (p, q) = (%d, %d)" % (dt, model.p, model.q))
+    assert len(pqlist) == 28 and pqlist[0] == (1, 0) and pqlist[-1] == (7, 6) and np.all(np.isfinite(aicc))
+    assert (model.p, model.q) == pqlist[int(np.argmin(aicc))]
+    n = t.size
+    # per order: the optimum behind the AICc entry against scipy L-BFGS-B from the same starts (a subset of orders and
+    # 12 of the 100 starts each keeps the scipy side within a minute)
+    for (p, q) in ((1, 0), (2, 1), (3, 0), (4, 2), (5, 3), (6, 1), (7, 6)):
+        k = 2 + p + q
+        fun_b = 0.5 * (aicc[pqlist.index((p, q))] - 2.0 * k - 2.0 * k * (k + 1.0) / (n - k - 1.0))
+        ref = model.get_mle(p, q, ntrials=12, seed=1, method="scipy")
+        assert fun_b <= ref.fun + 0.5, (p, q, fun_b, ref.fun)
+        m = orc.OracleModel(t, y, e, p, q)
+        mle = model.get_mle(p, q, ntrials=12, seed=1)
+        want = -m.logdensity(mle.x, ignore_prior=True) if p > 1 else -m.logdensity(mle.x)
+        assert abs(mle.fun - want) <= 1e-9 * abs(want), (p, q)

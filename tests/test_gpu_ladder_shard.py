@@ -92,7 +92,7 @@ def test_ladder_sharded_over_two_ranks():
     lp = np.concatenate([lp0, lp1], axis=1).ravel()
     assert np.all(np.isfinite(lp))
     from helpers import assert_parity
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     m = orc.OracleModel(t, y, e, P, Q, max_stdev=ms)
     assert_parity(lp, m.logdensity_batch(th), 1e-10, "sharded chain states",
                   arbiter=lambda i: loglik_truth(t, y, e, th[i], P, Q)[0])
@@ -162,7 +162,7 @@ def test_native_rccl_exchange_walks_the_same_trajectory():
     th = np.concatenate([o[0] for o in one], axis=1).reshape(-1, 3 + P + Q)
     lp = np.concatenate([o[1] for o in one], axis=1).ravel()
     from helpers import assert_parity
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     assert_parity(lp, m.logdensity_batch(th), 1e-10, "one temperature per block",
                   arbiter=lambda i: loglik_truth(t, y, e, th[i], P, Q)[0])
     prop = [o[2][0] for o in one]

@@ -139,7 +139,7 @@ def test_random_batch_vs_oracle_config2(cpa, readme):
     th = theta_batch(rng, 1024, 5, 3, t, y, theta_center=g["theta"][0])
     ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_var_stdev(y))
     m = orc.OracleModel(t, y, yerr, 5, 3)
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     arb = lambda i: loglik_truth(t, y, yerr, th[i], 5, 3)[0]   # noqa: E731
     got = ctx.logdensity(th)
     want = m.logdensity_batch(th, nthreads=8)
@@ -229,7 +229,7 @@ def test_launch_shapes_agree(cpa, p, q):
     ctx = cpa.Context(t, y, yerr, p, q)
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     want = m.logdensity_batch(th, nthreads=8)
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     arb = lambda i: loglik_truth(t, y, yerr, th[i % 48], p, q)[0]   # noqa: E731
     G = 2 if p <= 2 else (4 if p <= 4 else 8)
     pc_small, pc_big = 3100, min(4000, 512 * (64 // G))            # beyond the pipeline, within 512 waves
@@ -266,7 +266,7 @@ def test_series_lengths_around_chunk_boundaries(cpa, p, q):
         want = m.logdensity_batch(th, ignore_prior=True)
         roots = [np.asarray(orc.ar_roots(v, p)) for v in th]
         dup = np.array([np.min(np.abs(r[:, None] - r[None, :]) + np.eye(p)) == 0.0 for r in roots])
-        from mp_truth import loglik_truth
+        from helpers import loglik_truth
         arb = lambda i: loglik_truth(t, y, yerr, th[i % 12], p, q)[0]   # noqa: E731
         for B in (12, 1100, 3200):       # four-wave pipeline, one and two workgroups per CU / G-lane producer-consumer
             big = np.tile(th, (B // 12 + 1, 1))[:B]
@@ -292,7 +292,7 @@ def test_long_series_vs_oracle(cpa, p, q, n):
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(40)])
     ctx = cpa.Context(t, y, yerr, p, q)
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     arb = lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0]   # noqa: E731
     got = ctx.logdensity(th, ignore_prior=True)
     want = m.logdensity_batch(th, ignore_prior=True, nthreads=8)
@@ -441,7 +441,7 @@ def test_corotating_frame_windows_and_rebases(cpa, p, q):
         assert np.max(np.abs(got[fin] - other[fin]) / np.abs(other[fin])) < 1e-11
     # (2) against the oracle, at the bar of every other parity test: 1e-10, or -- where the reference's own arithmetic
     # loses digits on clustered roots -- no further from the 50-digit value than the oracle
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     assert_parity(got, want, RTOL, "co-rotating p=%d q=%d" % (p, q),
                   arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
     # independence of the neighbours: alone, and in any position of a shuffled batch
@@ -471,7 +471,7 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
     real[:, 4] = np.log(r1 + r2)
     ctx = cpa.Context(t, y, yerr, p, q)
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     B = 20000                                                   # throughput kernel
     res = {}
     for name, pool in (("complex", cplx), ("real", real), ("mixed", np.concatenate([cplx, real])[rng.permutation(64)])):
@@ -497,7 +497,7 @@ def test_prior_like_sweep_never_worse_than_reference(cpa, p):
     against the oracle, and wherever the two differ by more the GPU must be within 1e-10 of the 50-digit value of the
     reference's formulas or no further from it than the oracle (factor 1.0).  (tests/tools/parity_sweep.py is the
     1000-per-order version, profiles/r02/parity_sweep_*.txt its output.)"""
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     narb = 0
     for q in range(p):
         t, y, yerr = irregular_series(150, seed=100 * p + q)

@@ -64,7 +64,7 @@ def test_carma53_tempered_sampler(cpa, golden_dir):
     th, l2 = ctx.pt_get_chains()
     # hot chains roam into ill-conditioned corners of the prior: arbitrate those against 50 digits
     from helpers import assert_parity
-    from mp_truth import loglik_truth
+    from helpers import loglik_truth
     flat_th = th.reshape(-1, 11)
     assert_parity(l2.reshape(-1), m.logdensity_batch(flat_th), 1e-10, "chain states",
                   arbiter=lambda i: loglik_truth(t, y, yerr, flat_th[i], 5, 3)[0])

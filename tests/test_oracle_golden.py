@@ -249,3 +249,25 @@ def test_literal_sampler_restatement_car1(golden_dir):
     idx = np.arange(0, 6000, 500)
     np.testing.assert_allclose(out["logpost"][idx], m.logdensity_batch(S[idx]), rtol=1e-12)
     assert 0.15 < out["accept_rate"][0] < 0.40
+
+
+def test_quad_precision_arbiter_is_the_50_digit_value():
+    """oracle/carma_truth_q.c (the reference's formulas in __float128: the arbiter of the parity tests) against the
+    mpmath restatement at 50 digits (tests/mp_truth.py), on well- and ILL-conditioned models -- including the ones on
+    which the double-precision oracle is 1e-5 ... 1e-3 off."""
+    from helpers import irregular_series, prior_like_theta
+    from mp_truth import loglik_truth as mp_truth
+    worst_oracle = 0.0
+    for (p, q, picks) in ((2, 1, (0, 1)), (4, 2, (331, 28)), (6, 2, (297, 479)), (6, 1, (849,)), (7, 6, (468, 3)), (5, 3, (767,))):
+        t, y, yerr = irregular_series(150, seed=100 * p + q)
+        rng = np.random.default_rng(7000 + 10 * p + q)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(max(picks) + 1)])
+        m = orc.OracleModel(t, y, yerr, p, q, max_stdev=10.0 * np.sqrt(np.var(y, ddof=1)))
+        for i in picks:
+            a, a_ll = orc.truth_logdensity(t, y, yerr, th[i], p, q)
+            b, b_ll = mp_truth(t, y, yerr, th[i], p, q)
+            assert abs(a - b) <= 4e-16 * abs(b) and abs(a_ll - b_ll) <= 4e-16 * abs(b_ll), (p, q, i, a, b)
+            o = m.logdensity(th[i], ignore_prior=True)
+            if np.isfinite(o):
+                worst_oracle = max(worst_oracle, abs(o - b) / abs(b))
+    assert worst_oracle > 1e-6          # these cases ARE the ones the double-precision restatement cannot resolve

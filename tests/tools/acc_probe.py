@@ -10,7 +10,7 @@ if len(sys.argv) > 1:
     L0.lib = L0._load()
 import oracle as orc
 from helpers import irregular_series, prior_like_theta
-from mp_truth import loglik_truth
+from helpers import loglik_truth
 p, q = 7, 4
 rng = np.random.default_rng(900 + p)
 for n in (2, 3, 7, 8, 9, 15, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49):

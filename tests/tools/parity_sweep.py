@@ -12,7 +12,7 @@ if os.environ.get("SWEEP_LIB"):
     _L.lib = _L._load()
 import oracle as orc
 from helpers import irregular_series, prior_like_theta
-from mp_truth import loglik_truth
+from helpers import loglik_truth
 
 ntheta = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 tot = bad = arbitrated = worse3 = worse1 = better3 = within = 0
