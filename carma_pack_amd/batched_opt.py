@@ -26,11 +26,13 @@ def _project(x, lo, hi):
     return np.minimum(np.maximum(x, lo), hi)
 
 
-def minimize_batched(fun_batch, x0, bounds, maxiter=300, m=8, ftol=2.220446049250313e-09, gtol=1e-5, fd_step=1e-6):
+def minimize_batched(fun_batch, x0, bounds, maxiter=2000, m=8, ftol=2.220446049250313e-09, gtol=1e-5, fd_step=1e-6):
     """Minimise f independently from every row of x0.
 
     fun_batch : callable mapping an array [N, d] to [N] function values (non-finite = infeasible)
     x0        : [B, d] starting points;  bounds : list of (lo, hi) with None for unbounded
+    maxiter   : iterations per start (L-BFGS-B's own default is 15000; on the OGLE CARMA(7,6) surface most starts need
+                300-800, measured against scipy from identical starts)
     Returns a list of B BatchResult."""
     x = np.array(x0, dtype=float)
     B, d = x.shape
@@ -64,6 +66,9 @@ def minimize_batched(fun_batch, x0, bounds, maxiter=300, m=8, ftol=2.22044604925
     nhist = np.zeros(B, dtype=int)
     active = np.ones(B, dtype=bool)
     nit = np.zeros(B, dtype=int)
+    nsmall = np.zeros(B, dtype=int)
+    restarted = np.zeros(B, dtype=bool)
+    patience = 3
     msg = ["maximum number of iterations reached"] * B
     for _ in range(maxiter):
         idx = np.flatnonzero(active)
@@ -150,7 +155,18 @@ def minimize_batched(fun_batch, x0, bounds, maxiter=300, m=8, ftol=2.22044604925
         rel = (fa[mv] - fnew) / np.maximum(np.maximum(np.abs(fa[mv]), np.abs(fnew)), 1.0)
         x[im], f[im], g[im] = xn[mv], fnew, gnew
         nit[im] += 1
-        conv = rel <= ftol
+        # L-BFGS-B stops at the first iteration whose relative decrease is <= ftol.  Its line search (strong Wolfe, steps
+        # may grow) makes such an iteration a reliable sign of convergence; with plain backtracking a single short step in
+        # a curved valley is not -- measured on the OGLE CARMA(7,6) surface: stopping there left up to 4 units of -log L
+        # on the table against scipy from the same start.  So: `patience` such iterations in a row, and on the first
+        # occasion the quasi-Newton memory is dropped (a steepest-descent restart) before they start to count.
+        small = rel <= ftol
+        nsmall[im] = np.where(small, nsmall[im] + 1, 0)
+        first = im[small & ~restarted[im]]
+        restarted[first] = True
+        nhist[first] = 0
+        nsmall[first] = 0
+        conv = nsmall[im] >= patience
         for i in im[conv]:
             msg[i] = "converged: relative reduction of f <= ftol"
         active[im[conv]] = False

@@ -484,7 +484,7 @@ class CarmaModel(object):
             bnds += [(lo, hi)] * p + [(None, None)] * q
         return bnds
 
-    def get_mle(self, p, q, ntrials=100, njobs=1, seed=None, method="batched"):
+    def get_mle(self, p, q, ntrials=100, njobs=1, seed=None, method="batched", return_all=False):
         """Best of `ntrials` bounded quasi-Newton fits started from short tempered MCMC runs
         (reference :92-129,195-260).  The reference launches ntrials separate 26-iteration samplers
         and calls the C++ log-density once per function evaluation; here ONE sampler call with
@@ -492,7 +492,8 @@ class CarmaModel(object):
         starts are optimised in lock-step (carma_pack_amd.batched_opt): one launch evaluates the
         finite-difference stencils of every start.  method="scipy" runs scipy's L-BFGS-B per start
         with a batched gradient.  `njobs` is accepted for compatibility.  Returns an object with
-        .x, .fun (= -loglik), .message like scipy's OptimizeResult."""
+        .x, .fun (= -loglik), .message like scipy's OptimizeResult (return_all=True: the list of all ntrials results,
+        in the order of the starts)."""
         if p == 1:
             proc = carmcmcLib.run_mcmc_car1(1, 25, self._time, self._y, self._ysig, 1, nreplicas=ntrials, seed=seed)
         else:
@@ -512,6 +513,8 @@ class CarmaModel(object):
         if method == "batched":
             from .batched_opt import minimize_batched
             results = minimize_batched(lambda pts: -np.asarray(proc.getLogDensityBatch(pts)), starts, bnds)
+            if return_all:
+                return results
             results = [r for r in results if np.isfinite(r.fun) and r.fun < 1e299] or results
             return min(results, key=lambda r: r.fun)
 
@@ -525,12 +528,8 @@ class CarmaModel(object):
             g[~np.isfinite(g)] = 0.0
             return (f[0] if np.isfinite(f[0]) else 1e300), g
 
-        best = None
-        for x0 in starts:
-            res = minimize(fun_and_grad, x0, jac=True, method="L-BFGS-B", bounds=bnds)
-            if best is None or res.fun < best.fun:
-                best = res
-        return best
+        results = [minimize(fun_and_grad, x0, jac=True, method="L-BFGS-B", bounds=bnds) for x0 in starts]
+        return results if return_all else min(results, key=lambda r: r.fun)
 
     def choose_order(self, pmax, qmax=None, pqlist=None, njobs=1, ntrials=100, seed=None, method="batched"):
         """Minimise AICc over a (p,q) grid (reference :131-192); sets self.p, self.q."""

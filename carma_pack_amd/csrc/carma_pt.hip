@@ -511,6 +511,14 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     // COOPERATIVE launch: the swap step is a rendezvous of the ladder's workgroups through global memory, so the whole
     // grid has to be resident at once.  The runtime checks that (hipErrorCooperativeLaunchTooLarge otherwise, and the
     // host falls back to the ladder kernel) and schedules the grid as a gang, instead of this code assuming it.
+    if (S.wpl == 1) {
+        // the whole ladder (block) in one workgroup: the rendezvous has a single participant, no co-residency needed --
+        // an ordinary launch (a cooperative one costs ~2 ms on this stack, which matters when the ladder is sharded
+        // across GPUs and every iteration is a launch of its own)
+        hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)L.R), dim3(256), lds, st, L, S, series, pr, temps, theta, logpost, chol,
+                           naccept, nswap, samples, sample_lp);
+        return hipGetLastError();
+    }
     PtLaunch La = L;
     PtRowSync Sa = S;
     Prior pra = pr;
