@@ -200,3 +200,45 @@ def test_gpu_sampler_matches_literal_cpu_sampler(cpa):
     assert np.all(np.abs(ratio - 1.0) < 0.15), ratio
     acc, swp = ctx.pt_stats()
     assert 0.15 < acc[:, 0].mean() < 0.40
+
+
+@pytest.mark.parametrize("p,q", [(5, 3), (4, 0), (1, 0)])
+def test_starting_values_follow_the_reference_distribution(cpa, golden_dir, p, q):
+    """A12: 10^4 starting values through carma_pt_start (CARMA::StartingValue / CARp::StartingAR / StartingMA /
+    CAR1::StartingValue, src/carpack.cpp:38-81, 268-311, 416-477, 515-519: draw until the log-posterior is finite).
+    Structure: Lorentzian centroids in descending order, widths and centroids inside [f_min, f_max], the error scale
+    clamped to [0.51, 1.99]; distribution: every component against an independent numpy restatement of the same
+    draws (carma_pack_amd.synth.prior_like_theta, accepted on the oracle's finite log-posterior) by two-sample
+    Kolmogorov-Smirnov tests."""
+    from scipy.stats import ks_2samp
+    from helpers import prior_like_theta
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ms = _pop_stdev(y)
+    ctx = cpa.Context(t, y, yerr, p, q, max_stdev=ms)
+    T, R = 10, 1000
+    ctx.pt_create(T, R, adapt_iters=0, seed=123)
+    ctx.pt_start(None)
+    th, lp = ctx.pt_get_chains()
+    th = th.reshape(-1, ctx.d)
+    assert th.shape[0] == 10000 and np.all(np.isfinite(lp))
+    _, fmax, fmin = ctx.prior()
+    assert np.all((th[:, 1] >= 0.51) & (th[:, 1] <= 1.99)) and np.all(th[:, 0] > 0)
+    if p > 1:
+        roots = np.array([orc.ar_roots(v, p) for v in th[:500]])
+        cent, width = np.abs(roots.imag) / (2 * np.pi), -roots.real / (2 * np.pi)
+        assert np.all(width > fmin) and np.all(width < fmax) and np.all(cent < fmax)
+        pair_cent = cent[:, 0:p - (p % 2):2]
+        assert np.all(np.diff(pair_cent, axis=1) <= 1e-12)                  # descending (carpack.cpp:286)
+        assert np.all(pair_cent > fmin * (1 - 1e-12))
+    # the same distribution drawn with numpy, accepted by the oracle
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ms)
+    rng = np.random.default_rng(99)
+    ref = []
+    while sum(len(r) for r in ref) < 10000:
+        cand = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(4000)])
+        ref.append(cand[np.isfinite(m.logdensity_batch(cand, nthreads=os.cpu_count() or 8))])
+    ref = np.concatenate(ref)[:10000]
+    pv = [ks_2samp(th[:, j], ref[:, j]).pvalue for j in range(ctx.d)]
+    print("p=%d q=%d KS p-values:" % (p, q), np.round(pv, 3))
+    assert min(pv) > 1e-4, pv
