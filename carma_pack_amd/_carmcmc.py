@@ -185,23 +185,24 @@ class _KalmanBase(object):
         return pairD(float(m[0]), float(v[0]))
 
     def Simulate(self, time):
-        """Draw the process at `time` conditional on the series (KalmanFilter::Simulate,
-        kfilter.hpp:135-184): times are visited in ascending order, every drawn value is inserted
-        into the series with zero measurement error before the next time is predicted."""
+        """Draw the (noise-free) process at `time` conditional on the measured series (KalmanFilter::Simulate,
+        kfilter.hpp:135-184).  The reference visits the times in ascending order and re-filters the growing series once
+        per time (M full filters, each drawn value inserted with zero measurement error).  The same joint conditional
+        distribution is drawn here with TWO launches, by Matheron's rule for Gaussian processes:
+            f*|y  =  f~*  +  E[f* | y - y~],      f~ = an unconditional path on (data times U requested times),
+                                                   y~ = f~(data times) + measurement noise
+        -- one batched unconditional simulation (carma_simulate_*) and one batched Predict of the residual series."""
         times = np.sort(_arr(time))
-        t0, y0, e0 = self._t, self._y, self._e
-        out = np.empty(times.size)
-        try:
-            for i, tp in enumerate(times):
-                m, v = self.PredictBatch([tp])
-                out[i] = np.random.normal(m[0], np.sqrt(v[0]))
-                k = int(np.searchsorted(self._t, tp, side="left"))
-                self._t = np.insert(self._t, k, tp)
-                self._y = np.insert(self._y, k, out[i])
-                self._e = np.insert(self._e, k, 0.0)
-        finally:
-            self._t, self._y, self._e = t0, y0, e0
-        return vecD(out.tolist())
+        n = self._t.size
+        tt = np.concatenate([self._t, times])
+        order = np.argsort(tt, kind="stable")
+        inv = np.empty(order.size, dtype=int)
+        inv[order] = np.arange(order.size)
+        path = self._simulate(tt[order], int(np.random.randint(0, 2 ** 62)))
+        f_data, f_new = path[inv[:n]], path[inv[n:]]
+        y_tilde = f_data + self._e * np.random.standard_normal(n)
+        m, _ = self._predict(self._t, self._y - y_tilde, self._e, times)
+        return vecD((f_new + m).tolist())
 
 
 class KalmanFilter1(_KalmanBase):
@@ -218,7 +219,13 @@ class KalmanFilter1(_KalmanBase):
 
     def PredictBatch(self, times):
         """Extension: all times in one launch (carma_predict_car1)."""
-        return _lib.predict_car1(self._t, self._y, self._e, self._sigsqr, self._omega, _arr(times))
+        return self._predict(self._t, self._y, self._e, _arr(times))
+
+    def _predict(self, t, y, e, times):
+        return _lib.predict_car1(t, y, e, self._sigsqr, self._omega, times)
+
+    def _simulate(self, times, seed):
+        return _lib.simulate_car1(times, self._sigsqr, self._omega, 1, seed)[0]
 
 
 class KalmanFilterp(_KalmanBase):
@@ -238,4 +245,10 @@ class KalmanFilterp(_KalmanBase):
 
     def PredictBatch(self, times):
         """Extension: all times in one launch (carma_predict_carma)."""
-        return _lib.predict_carma(self._t, self._y, self._e, self._sigsqr, self._omega, self._ma, _arr(times))
+        return self._predict(self._t, self._y, self._e, _arr(times))
+
+    def _predict(self, t, y, e, times):
+        return _lib.predict_carma(t, y, e, self._sigsqr, self._omega, self._ma, times)
+
+    def _simulate(self, times, seed):
+        return _lib.simulate_carma(times, self._sigsqr, self._omega, self._ma, 1, seed)[0]

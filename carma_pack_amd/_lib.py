@@ -96,6 +96,8 @@ def _load():
     L.carma_predict_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, C.c_int,
                                       _dp, _dp, C.c_int]
     L.carma_predict_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp, C.c_int]
+    L.carma_simulate_carma.argtypes = [_dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, C.c_int, C.c_uint64, _dp, C.c_int]
+    L.carma_simulate_car1.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, _dp, C.c_int]
     L.carma_pt_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64,
                                _dp, _dp]
     L.carma_pt_create.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64]
@@ -128,7 +130,7 @@ EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
     "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_kfilter_carma",
-    "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
+    "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_simulate_carma", "carma_simulate_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_boundary_stats",
@@ -408,3 +410,27 @@ def predict_car1(time, y, yerr, sigsqr, omega, tpred, device=None):
                                  ptr(pm), ptr(pv), default_device() if device is None else device),
           "carma_predict_car1")
     return pm, pv
+
+
+def simulate_carma(time, sigsqr, omega, ma, npaths=1, seed=0, device=None):
+    """carma_process for `npaths` paths in one launch -> [npaths][n] at the sorted times (carma_simulate_carma)."""
+    time = as_f64(np.sort(np.asarray(time, dtype=float)))
+    omega = np.asarray(omega, dtype=complex)
+    om = as_f64(np.c_[omega.real, omega.imag])
+    ma = as_f64(ma)
+    out = np.empty((int(npaths), time.size))
+    rc = lib.carma_simulate_carma(ptr(time), time.size, omega.size, float(sigsqr), ptr(om), ptr(ma), ma.size, int(npaths),
+                                  C.c_uint64(int(seed) & (2 ** 64 - 1)), ptr(out), default_device() if device is None else device)
+    if rc == 1:
+        raise CarmaError("carma_process: repeated AR root (singular eigenvector matrix)")
+    check(rc, "carma_simulate_carma")
+    return out
+
+
+def simulate_car1(time, sigsqr, omega, npaths=1, seed=0, device=None):
+    time = as_f64(np.sort(np.asarray(time, dtype=float)))
+    out = np.empty((int(npaths), time.size))
+    check(lib.carma_simulate_car1(ptr(time), time.size, float(sigsqr), float(omega), int(npaths),
+                                  C.c_uint64(int(seed) & (2 ** 64 - 1)), ptr(out), default_device() if device is None else device),
+          "carma_simulate_car1")
+    return out

@@ -14,7 +14,7 @@ from scipy.optimize import minimize
 from . import _carmcmc as carmcmcLib
 
 __all__ = ["CarmaModel", "CarmaSample", "Car1Sample", "MCMCSample", "get_ar_roots", "power_spectrum",
-           "carma_variance", "car1_process", "carma_process"]
+           "carma_variance", "car1_process", "carma_process", "carma_process_batch", "car1_process_batch"]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -120,6 +120,23 @@ def carma_process(time, sigsqr, ar_roots, ma_coefs=(1.0,), rng=None):
         y[k] = rng.normal(mean, np.sqrt(var))
         innov = y[k] - mean
     return y
+
+
+def carma_process_batch(time, sigsqr, ar_roots, ma_coefs=(1.0,), npaths=1, seed=0, device=None):
+    """`npaths` independent draws of carma_process in ONE launch on the GPU (carma_simulate_carma: the same
+    value-by-value construction, reference :1148-1259, normal variates from the counter-based generator keyed by
+    (seed, path, step)).  Returns [npaths][n] at the sorted times."""
+    from . import _lib
+    r = np.atleast_1d(np.asarray(ar_roots, dtype=complex))
+    if r.size == 1:
+        return car1_process_batch(time, sigsqr, -1.0 / r.real.item(), npaths, seed, device)
+    return _lib.simulate_carma(time, sigsqr, r, np.asarray(ma_coefs, dtype=float), npaths, seed, device)
+
+
+def car1_process_batch(time, sigsqr, tau, npaths=1, seed=0, device=None):
+    """`npaths` independent Ornstein-Uhlenbeck paths (car1_process, reference :1126-1146) in one launch."""
+    from . import _lib
+    return _lib.simulate_car1(time, sigsqr, 1.0 / tau, npaths, seed, device)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -466,4 +466,72 @@ int carma_predict_car1(const double* time, const double* y, const double* yerr, 
     return predict_common(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, tpred, M, pmean, pvar, device);
 }
 
+// carma_process / car1_process for npaths paths in one launch
+static int simulate_common(const double* time, int n, int p, double sigsqr, const double* omega_re_im, const double* ma,
+                           int nma, double car1_omega, int npaths, uint64_t seed, double* out, int device)
+{
+    if (!time || !out || n < 1 || npaths < 0) {
+        set_error("carma_simulate: bad argument");
+        return CARMA_EINVAL;
+    }
+    if (npaths == 0) return CARMA_OK;
+    int rc = select_device(device);
+    if (rc != CARMA_OK) return rc;
+    std::vector<double> t(time, time + n);
+    std::sort(t.begin(), t.end());                            // time.sort() (carma_pack.py:1176)
+    std::vector<double> par(2 * CARMA_PMAX + CARMA_PMAX, 0.0);
+    if (p > 1) {
+        if (normalize_roots(p, omega_re_im, par.data()) != CARMA_OK) {
+            set_error("carma_simulate_carma: the AR roots must be real or come in complex-conjugate pairs");
+            return CARMA_EINVAL;
+        }
+        for (int i = 0; i < p && i < nma; i++) par[2 * CARMA_PMAX + i] = ma[i];
+    }
+    double *d_t = nullptr, *d_par = nullptr, *d_out = nullptr;
+    int* d_sing = nullptr;
+    const size_t nout = (size_t)npaths * n;
+    hipError_t e = hipMalloc(&d_t, sizeof(double) * n);
+    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(double) * nout);
+    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_t, t.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_sing, 0, sizeof(int));
+    const unsigned s0 = (unsigned)(seed & 0xffffffffu), s1 = (unsigned)(seed >> 32);
+    if (e == hipSuccess) {
+        if (p == 1)
+            e = launch_simulate_car1(sigsqr, car1_omega, d_t, n, npaths, s0, s1, 0u, d_out, nullptr);
+        else
+            e = launch_simulate_carma(p, d_par, d_par + 2 * CARMA_PMAX, sigsqr, d_t, n, npaths, s0, s1, 0u, d_out, d_sing, nullptr);
+    }
+    int sing = 0;
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&sing, d_sing, sizeof(int), hipMemcpyDeviceToHost);
+    if (d_t) (void)hipFree(d_t);
+    if (d_par) (void)hipFree(d_par);
+    if (d_out) (void)hipFree(d_out);
+    if (d_sing) (void)hipFree(d_sing);
+    if (e != hipSuccess) return hip_fail(e, "carma_simulate");
+    return sing ? 1 : CARMA_OK;
+}
+
+int carma_simulate_carma(const double* time, int n, int p, double sigsqr, const double* omega_re_im, const double* ma, int nma,
+                         int npaths, uint64_t seed, double* out, int device)
+{
+    if (p < 2 || p > CARMA_PMAX || !omega_re_im || !ma || nma < 1 || !(sigsqr > 0.0)) {
+        set_error("carma_simulate_carma: need 2 <= p <= %d, omega, ma and sigsqr > 0", CARMA_PMAX);
+        return CARMA_EINVAL;
+    }
+    return simulate_common(time, n, p, sigsqr, omega_re_im, ma, nma, 0.0, npaths, seed, out, device);
+}
+
+int carma_simulate_car1(const double* time, int n, double sigsqr, double omega, int npaths, uint64_t seed, double* out, int device)
+{
+    if (!(sigsqr > 0.0) || !(omega > 0.0)) {
+        set_error("carma_simulate_car1: need sigsqr > 0 and omega > 0");
+        return CARMA_EINVAL;
+    }
+    return simulate_common(time, n, 1, sigsqr, nullptr, nullptr, 0, omega, npaths, seed, out, device);
+}
+
 }  // extern "C"

@@ -21,6 +21,7 @@
 #include "carma_core.h"
 #include "carma_ring.h"
 #include "carma_predict.h"
+#include "carma_simulate.h"
 #include "carma_pipe3l.h"
 #include "carma_launch.h"
 
@@ -202,6 +203,37 @@ __global__ __launch_bounds__(64) void k_predict_car1(double sigsqr, double omega
     if (e < M) predict_car1(sigsqr, omega, series, n, tpred[e], pmean + e, pvar + e);
 }
 
+// carma_process for `npaths` independent paths at once: one lane group per path.
+template <int P, int G>
+__global__ __launch_bounds__(64) void k_simulate_carma(const double* __restrict__ om_re_im, const double* __restrict__ ma,
+                                                       double sigsqr, const double* __restrict__ times, int n, int npaths,
+                                                       unsigned seed0, unsigned seed1, unsigned path0, double* __restrict__ out,
+                                                       int* __restrict__ singular)
+{
+    __shared__ double4 xch[64];
+    __shared__ double2 xch2[64];
+    const int tid = threadIdx.x;
+    Grp<G> g{xch, tid & 63, xch2};
+    long e = ((long)blockIdx.x * 64 + tid) / G;
+    const bool live = e < npaths;
+    if (!live) e = npaths - 1;
+    Model<P> m;
+    model_from_roots<P, G>(g, om_re_im, ma, sigsqr, m);
+    RngKey key{seed0, seed1, path0 + (unsigned)e};
+    bool sing;
+    // (shadow groups past the end redo the last path and write the same values)
+    simulate_run<P, G>(g, m, times, n, key, out + e * (long)n, &sing);
+    if (live && g.lane() == 0 && sing) *singular = 1;
+}
+
+__global__ __launch_bounds__(64) void k_simulate_car1(double sigsqr, double omega, const double* __restrict__ times, int n,
+                                                      int npaths, unsigned seed0, unsigned seed1, unsigned path0,
+                                                      double* __restrict__ out)
+{
+    const long e = (long)blockIdx.x * 64 + threadIdx.x;
+    if (e < npaths) simulate_car1(sigsqr, omega, times, n, RngKey{seed0, seed1, path0 + (unsigned)e}, out + e * (long)n);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Largest launch (in workgroups of four evaluations) that takes the wave pipeline of carma_pipe3l.h: three workgroups
 // per CU (measured, tools/tput_probe.py).  CARMA_TUNE_P3L_ROWS overrides it for such measurements; read once.
@@ -370,6 +402,42 @@ hipError_t launch_predict_carma(int p, const double* om, const double* ma, doubl
         case 7: return launch_predict_p<7>(om, ma, sigsqr, series, n, tpred, M, pmean, pvar, singular, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <int P>
+static hipError_t launch_simulate_p(const double* om, const double* ma, double sigsqr, const double* times, int n, int npaths,
+                                    unsigned seed0, unsigned seed1, unsigned path0, double* out, int* singular, hipStream_t st)
+{
+    constexpr int G = GroupOf<P>::value;
+    const unsigned blocks = (unsigned)(((long)npaths * G + 63) / 64);
+    hipLaunchKernelGGL((k_simulate_carma<P, G>), dim3(blocks), dim3(64), 0, st, om, ma, sigsqr, times, n, npaths, seed0, seed1,
+                       path0, out, singular);
+    return hipGetLastError();
+}
+
+hipError_t launch_simulate_carma(int p, const double* om, const double* ma, double sigsqr, const double* times, int n,
+                                 int npaths, unsigned seed0, unsigned seed1, unsigned path0, double* out, int* singular,
+                                 hipStream_t st)
+{
+    (void)hipGetLastError();
+    switch (p) {
+        case 2: return launch_simulate_p<2>(om, ma, sigsqr, times, n, npaths, seed0, seed1, path0, out, singular, st);
+        case 3: return launch_simulate_p<3>(om, ma, sigsqr, times, n, npaths, seed0, seed1, path0, out, singular, st);
+        case 4: return launch_simulate_p<4>(om, ma, sigsqr, times, n, npaths, seed0, seed1, path0, out, singular, st);
+        case 5: return launch_simulate_p<5>(om, ma, sigsqr, times, n, npaths, seed0, seed1, path0, out, singular, st);
+        case 6: return launch_simulate_p<6>(om, ma, sigsqr, times, n, npaths, seed0, seed1, path0, out, singular, st);
+        case 7: return launch_simulate_p<7>(om, ma, sigsqr, times, n, npaths, seed0, seed1, path0, out, singular, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_simulate_car1(double sigsqr, double omega, const double* times, int n, int npaths, unsigned seed0,
+                                unsigned seed1, unsigned path0, double* out, hipStream_t st)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_simulate_car1, dim3((unsigned)(((long)npaths + 63) / 64)), dim3(64), 0, st, sigsqr, omega, times, n,
+                       npaths, seed0, seed1, path0, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_predict_car1(double sigsqr, double omega, const double4* series, int n, const double* tpred, int M,

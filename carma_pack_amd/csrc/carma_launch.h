@@ -24,6 +24,13 @@ hipError_t launch_predict_carma(int p, const double* om_re_im, const double* ma,
 hipError_t launch_predict_car1(double sigsqr, double omega, const double4* series, int n, const double* tpred, int M,
                                double* pmean, double* pvar, hipStream_t st);
 
+// npaths independent paths of the process at n sorted times (carma_simulate.h); out = [npaths][n]
+hipError_t launch_simulate_carma(int p, const double* om_re_im, const double* ma, double sigsqr, const double* times, int n,
+                                 int npaths, unsigned seed0, unsigned seed1, unsigned path0, double* out, int* singular,
+                                 hipStream_t st);
+hipError_t launch_simulate_car1(double sigsqr, double omega, const double* times, int n, int npaths, unsigned seed0,
+                                unsigned seed1, unsigned path0, double* out, hipStream_t st);
+
 // one chunk of the persistent PT sampler kernel (carma_pt.hip)
 hipError_t launch_pt(int p, const PtLaunch& L, const double4* series, const Prior& pr, const double* temps,
                      double* theta, double* logpost, double* chol, unsigned* naccept, unsigned* nswap, double* samples,

@@ -49,12 +49,22 @@ struct RngKey {
 };
 
 // purposes
-constexpr uint32_t RNG_PROPOSAL = 0, RNG_ACCEPT = 1, RNG_SWAP = 2;
+constexpr uint32_t RNG_PROPOSAL = 0, RNG_ACCEPT = 1, RNG_SWAP = 2, RNG_PATH = 3;
 
 CARMA_DEV double rng_uniform(const RngKey& key, uint64_t iter, uint32_t purpose, uint32_t idx)
 {
     Philox4 x = philox4x32_10((uint32_t)iter, (uint32_t)(iter >> 32), key.chain, (purpose << 24) | idx, key.k0, key.k1);
     return u01(x.v[0], x.v[1]);
+}
+
+// N(0,1) by Box-Muller (simulation of process paths, carma_simulate.h): one draw per (key, iter, idx)
+CARMA_DEV double rng_normal(const RngKey& key, uint64_t iter, uint32_t idx)
+{
+    Philox4 a = philox4x32_10((uint32_t)iter, (uint32_t)(iter >> 32), key.chain, (RNG_PATH << 24) | idx, key.k0, key.k1);
+    const double u1 = u01(a.v[0], a.v[1]), u2 = u01(a.v[2], a.v[3]);
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+    return sqrt(-2.0 * log(u1)) * cs;
 }
 
 // Student-t, nu = 8:  Z / sqrt(chi2_8 / 8), Z by Box-Muller, chi2_8 = -2 ln(U1 U2 U3 U4)

@@ -113,6 +113,18 @@ int carma_predict_car1(const double* time, const double* y, const double* yerr, 
                        double omega, const double* tpred, int M, double* pmean, double* pvar, int device);
 
 /*
+ * carma_process / car1_process (src/carmcmc/carma_pack.py:1148-1259, 1126-1146) for npaths independent paths in ONE
+ * launch: exact draws of the process at the n (sorted here) times, value by value from the one-step predictive
+ * distribution of the Kalman recursion without measurement error.  Normal variates from the counter-based generator
+ * keyed by (seed, path, step): reproducible, and a path does not depend on the batch it is drawn in.
+ * out = [npaths][n] (host).  CAR(1): omega = 1 / tau.  Returns 1 on a repeated AR root.
+ */
+int carma_simulate_carma(const double* time, int n, int p, double sigsqr, const double* omega_re_im,
+                         const double* ma, int nma, int npaths, uint64_t seed, double* out, int device);
+int carma_simulate_car1(const double* time, int n, double sigsqr, double omega, int npaths, uint64_t seed,
+                        double* out, int device);
+
+/*
  * Parallel-tempered Robust-Adaptive-Metropolis sampler == RunCarmaSampler / RunCar1Sampler
  * (src/carmcmc.cpp:30-177; bindings run_mcmc_car1 / run_mcmc_carma, boost_python_wrapper.cpp:76-77)
  * with every chain advanced on the GPU by one persistent kernel (carma_pt.hip).

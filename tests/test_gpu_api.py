@@ -222,3 +222,53 @@ def test_car1_sample_predict_simulate_assess_fit(cm):
     pm, pv = sample.predict(np.sort(ts)[:1], bestfit="map")                           # first time visited: plain conditional
     z = (draws[:, 0].mean() - pm[0]) / np.sqrt(pv[0] / 300)
     assert abs(z) < 4.5 and 0.7 < draws[:, 0].var() / pv[0] < 1.4
+
+
+def _philox_normals(seed, path, n):
+    """rng_normal(key{seed, path}, i, 0) of carma_rng.h for i < n, restated with numpy (Box-Muller on Philox4x32-10)."""
+    from carma_pack_amd import parallel as par
+    out = np.empty(n)
+    for i in range(n):
+        x = par.philox4x32_10(i & 0xFFFFFFFF, (i >> 32) & 0xFFFFFFFF, path, (3 << 24) | 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        u1 = ((((x[0] << 32) | x[1]) >> 11) + 0.5) / 9007199254740992.0
+        u2 = ((((x[2] << 32) | x[3]) >> 11) + 0.5) / 9007199254740992.0
+        out[i] = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return out
+
+
+def test_device_carma_process_is_the_reference_construction(cm, golden_dir):
+    """carma_process_batch (carma_simulate_carma): many paths in one launch.  Exactness: the reference draws
+    y_i ~ N(kalman_mean_i, kalman_var_i) from the Kalman recursion without measurement error (carma_pack.py:1226-1257),
+    so the ORACLE's filter run over a simulated path with yerr = 0 must give back, as standardised innovations, exactly
+    the normal variates the path was built from -- the counter-based Philox draws, restated here with numpy.  Then
+    moments over 4096 paths against carma_variance."""
+    import os
+    import oracle as orc
+    g = np.load(os.path.join(golden_dir, "cpp_carma_test300.npz"))
+    roots, ma, sigsqr = g["omega"], g["ma"], float(g["sigsqr"])
+    t = g["t"][:200]
+    seed = 0x1234567
+    paths = cm.carma_process_batch(t, sigsqr, roots, ma, npaths=5, seed=seed)
+    assert paths.shape == (5, 200) and np.all(np.isfinite(paths))
+    again = cm.carma_process_batch(t, sigsqr, roots, ma, npaths=3, seed=seed)
+    assert np.array_equal(again, paths[:3])                           # a path does not depend on the batch it is drawn in
+    for k in (0, 4):
+        mean, var = orc.kfilter_carma(t, paths[k], np.zeros(t.size), sigsqr, roots, ma)
+        z = (paths[k] - mean) / np.sqrt(var)
+        np.testing.assert_allclose(z, _philox_normals(seed, k, t.size), rtol=0, atol=2e-7)
+    big = cm.carma_process_batch(t, sigsqr, roots, ma, npaths=4096, seed=77)
+    v0 = cm.carma_variance(sigsqr, roots, ma)
+    assert abs(big.var(axis=0).mean() / v0 - 1.0) < 0.03
+    for lag_idx in (1, 7, 40):
+        dt = t[100 + lag_idx] - t[100]
+        acv = np.mean(big[:, 100] * big[:, 100 + lag_idx])
+        assert abs(acv - cm.carma_variance(sigsqr, roots, ma, lag=dt)) < 0.06 * v0
+    # CAR(1): exact OU recursion
+    p1 = cm.car1_process_batch(t, 0.5, 20.0, npaths=2048, seed=5)
+    assert p1.shape == (2048, 200) and abs(p1.var(axis=0).mean() / (0.5 * 20.0 / 2.0) - 1.0) < 0.05
+    z1 = _philox_normals(5, 3, 4)
+    rho = np.exp(-np.diff(t[:4]) / 20.0)
+    want = [np.sqrt(5.0) * z1[0]]
+    for i in range(1, 4):
+        want.append(rho[i - 1] * want[-1] + np.sqrt(5.0 * (1.0 - rho[i - 1] ** 2)) * z1[i])
+    np.testing.assert_allclose(p1[3, :4], want, rtol=1e-12)
