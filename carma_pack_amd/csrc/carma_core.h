@@ -172,13 +172,15 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
     // --- roots.  Slot s < P is AR root s (carpack.cpp:137-172), slot P + k is MA root k (carpack.cpp:522-552); lane l
     // evaluates slot l, and slot l + G in a second pass when the group is too small for all of them
     const bool ma0 = (r >= P) && (r - P < q);
-    const Cx root0 = ma0 ? poly_root(theta + 3 + P, q, r - P) : own_ar_root<P>(theta, rr);
+    // (selections between Cx values go through csel: a ?: on the structs makes the compiler select between their
+    // ADDRESSES and keeps the whole Model in scratch memory -- 5.8 MB of scratch writes per 1024-evaluation launch)
+    const Cx root0 = poly_root(ma0 ? theta + 3 + P : theta + 3, ma0 ? q : P, ma0 ? r - P : rr);
 #pragma unroll
     for (int j = 0; j < P; j++) {
         m.wall[j].re = g.bcast_u(root0.re, j);
         m.wall[j].im = g.bcast_u(root0.im, j);
     }
-    m.w = (r < P) ? root0 : m.wall[P - 1];
+    m.w = csel(r < P, root0, m.wall[P - 1]);
     constexpr int NMA = P > 1 ? P - 1 : 1;       // q <= P - 1
     constexpr int MA0 = G - P;                   // MA roots held by the first pass
     Cx root1 = {-1.0, 0.0};
@@ -189,7 +191,8 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
     // --- b_r = beta(omega_r) = prod_k (mu_k - omega_r) / mu_k,  beta(-omega_r) = prod_k (mu_k + omega_r) / mu_k;
     //     prod_k mu_k is real (conjugate pairs and real roots)
     Cx pb = {1.0, 0.0}, pm = {1.0, 0.0}, pmu = {1.0, 0.0};
-    static_for<0, NMA>([&](auto kc) {
+    const Cx wr = m.w;       // (a copy: the lambda must not capture the Model, or the whole struct is kept in scratch memory)
+    static_for<0, NMA>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         Cx mu;
         if constexpr (k < MA0) {
@@ -198,8 +201,8 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
             mu = {g.bcast_u(root1.re, k - MA0), g.bcast_u(root1.im, k - MA0)};
         }
         if (k < q) {
-            pb = cmul(pb, csub(mu, m.w));
-            pm = cmul(pm, cadd(mu, m.w));
+            pb = cmul(pb, csub(mu, wr));
+            pm = cmul(pm, cadd(mu, wr));
             pmu = cmul(pmu, mu);
         }
     });

@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, sys
 tag, kern = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles", "r01")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles", "r02")
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "kernel_stats_%s.csv" % tag))
