@@ -163,7 +163,13 @@ CARMA_DEV void model_kappa(const GrpT& g, Model<P>& m, const Cx bm)
 }
 
 // theta -> Model  (ARRoots, ExtractMA, ExtractSigsqr, CheckPriorBounds)
-template <int P, int G, class GrpT>
+// PART selects what is evaluated -- the wave pipeline splits the set-up between its two recursion waves:
+//   MODEL_ALL     everything
+//   MODEL_CONSTS  roots, b, kappa, sigma^2, s0 (what the covariance wave needs); valid = true, sing as computed
+//   MODEL_FLAGS   roots, mu, scale, the prior bounds and the repeated-root flag (what the mean wave needs); b, kappa,
+//                 sigma^2 and s0 are NOT set
+constexpr int MODEL_ALL = 0, MODEL_CONSTS = 1, MODEL_FLAGS = 2;
+template <int P, int G, int PART = MODEL_ALL, class GrpT>
 CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const Prior& pr, int ignore_prior,
                                 Model<P>& m)
 {
@@ -181,6 +187,9 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
         m.wall[j].im = g.bcast_u(root0.im, j);
     }
     m.w = csel(r < P, root0, m.wall[P - 1]);
+    m.scale = theta[1];
+    m.mu = theta[2];
+    if constexpr (PART != MODEL_FLAGS) {
     constexpr int NMA = P > 1 ? P - 1 : 1;       // q <= P - 1
     constexpr int MA0 = G - P;                   // MA roots held by the first pass
     Cx root1 = {-1.0, 0.0};
@@ -213,11 +222,17 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
     const double var1 = g.sum(r < P ? (m.b.re * m.kap.re - m.b.im * m.kap.im) : 0.0);
     m.sigsqr = theta[0] * theta[0] / var1;
     m.s0 = theta[0] * theta[0];                  // = sigma^2 Variance(1): var_0 = sigma_y^2 + yerr_0^2 (kfilter.cpp:180-182)
-    m.scale = theta[1];
-    m.mu = theta[2];
+    } else {
+        // repeated-root flag without the products: two roots with the same bits
+        bool same = false;
+#pragma unroll
+        for (int j = 0; j < P; j++)
+            if (j != rr && m.w.re == m.wall[j].re && m.w.im == m.wall[j].im) same = true;
+        m.sing = g.sum((r < P && same) ? 1.0 : 0.0) != 0.0;
+    }
     // --- prior bounds (carpack.cpp:314-374, unique_roots :709-732)
     m.valid = true;
-    if (!ignore_prior) {
+    if (PART != MODEL_CONSTS && !ignore_prior) {
         double cent = fabs(m.w.im) / 2.0 / (TWO_PI / 2.0);
         double width = -m.w.re / 2.0 / (TWO_PI / 2.0);
         bool viol = !(cent < pr.max_freq) || !(width < pr.max_freq) || !(width > pr.min_freq);

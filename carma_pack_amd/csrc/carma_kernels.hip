@@ -110,28 +110,32 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
         return;
     }
     Model<P> m;
-    model_from_theta<P, 16>(g, theta + e * d, q, pr, ignore_prior, m);
-    CARMA_MARK(1);
-    FilterConsts<P> fc;
-    filter_reset<P, 16>(g, m, fc);
-    RowConsts<P> rc;
-    row_consts<P>(g, m, fc, rc);
-    CARMA_MARK(2);
     if (wave == 0) {
+        model_from_theta<P, 16, MODEL_CONSTS>(g, theta + e * d, q, pr, ignore_prior, m);
+        CARMA_MARK(1);
+        FilterConsts<P> fc;
+        filter_reset<P, 16>(g, m, fc);
+        RowConsts<P> rc;
+        row_consts<P>(g, m, fc, rc);
+        CARMA_MARK(2);
         pipe3l_cov<P>(g, m, rc, series, n, ring);
         CARMA_MARK(3);
         CARMA_MARK_DUMP("covariance", 0);
         return;
     }
+    // the set-up is split: the covariance wave forms the constants of the recursion, this wave checks the prior bounds
+    model_from_theta<P, 16, MODEL_FLAGS>(g, theta + e * d, q, pr, ignore_prior, m);
+    CARMA_MARK(1);
     // the log prior is evaluated HERE, while the mean wave would otherwise wait for the pipeline to fill, not after the
     // recursion (a serial chain of ~1000 cycles on the critical path of the launch)
     double lpri = log_prior(m.scale, pr.measerr_dof);
     asm volatile("" : "+v"(lpri));
-    double ll = pipe3l_mean<P>(g, m, rc, series, n, ring);
+    CARMA_MARK(2);
+    double ll = pipe3l_mean<P>(g, m.mu, series, n, ring);
     CARMA_MARK(3);
     ll += lpri;
     const double ninf = -1.0 / 0.0;
-    if (fc.sing || !m.valid) ll = ninf;
+    if (m.sing || !m.valid) ll = ninf;
     if (live && g.lane() == 0) out[e] = ll;
     CARMA_MARK(4);
     CARMA_MARK_DUMP("mean", 0);

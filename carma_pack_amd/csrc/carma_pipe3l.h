@@ -43,7 +43,6 @@ namespace carma {
 template <int P>
 struct RowConsts {
     double h_own, c_own, s0;
-    double hall[P];
 };
 template <int P>
 __device__ __forceinline__ void row_consts(const Grp<16>& g, const Model<P>& m, const FilterConsts<P>& fc, RowConsts<P>& rc)
@@ -56,8 +55,6 @@ __device__ __forceinline__ void row_consts(const Grp<16>& g, const Model<P>& m, 
     rc.h_own = !act ? 0.0 : (cpx ? (odd ? 2.0 * fc.b_own.im : 2.0 * fc.b_own.re) : fc.b_own.re);
     rc.c_own = cpx ? (odd ? c_im_partner : fc.c_own.re) : fc.c_own.re;
     rc.s0 = fc.s0;
-#pragma unroll
-    for (int j = 0; j < P; j++) rc.hall[j] = g.bcast_u(rc.h_own, j);
 }
 
 template <int P>
@@ -295,10 +292,12 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     __syncthreads();                                          // barrier nc
 }
 
-// wave B
+// wave B.  Of the model it needs mu only (and the flags its caller checks): the observation row h_r -- used at the
+// re-base data -- is read from what the covariance wave published for the producers, so this wave does not repeat that
+// part of the set-up (model_from_theta<MODEL_FLAGS>).
 template <int P>
-__device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc,
-                                              const double4* __restrict__ series, int n, const Cx* __restrict__ ring)
+__device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const double4* __restrict__ series, int n,
+                                              const Cx* __restrict__ ring)
 {
     using Geo = Pipe3LGeom<P>;
     using RA = RowAsm<P>;
@@ -306,7 +305,7 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
     const int lane = g.lane64;
     const int nc = (n + C - 1) / C;
     const double one = 1.0;
-    double z = 0.0;
+    double z = 0.0, h_own = 0.0;                              // h_own: read from LDS once the covariance wave has published it
     LogLikAcc acc;
     acc.init();
     const double2* ring_b = nullptr;
@@ -327,11 +326,11 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
             const double rc_ = mine ? hc.x : 1.0, rs_ = mine ? hc.y : 0.0;
             const double zp = g.partner(z);
             z = fma(rc_, z, -(rs_ * zp));
-            ht = mine ? rc.h_own : hc.x;
+            ht = mine ? h_own : hc.x;
         }
         // innov_j = (y - mu) - h~.z~   (kfilter.cpp:184, 207, 213); log-likelihood terms (carpack.hpp:167-171)
         double innov;
-        RA::innov_t2(innov, yj, m.mu, z, ht, one);
+        RA::innov_t2(innov, yj, mu, z, ht, one);
         acc.add_var(lk.y);
         const double si = recip(lk.y) * innov;
         acc.chi2 += innov * si;
@@ -339,6 +338,7 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, const Model<P>& 
     };
     const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
     __syncthreads();                                          // (h_r, c_r) published
+    h_own = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF)[Geo::entry(lane)].x;
     __syncthreads();                                          // barrier 0
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c + 1: wave A has finished chunk c

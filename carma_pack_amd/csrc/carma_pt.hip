@@ -321,19 +321,20 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             });
         } else {
             Model<P> m;
-            model_from_theta<P, G>(g, thn_lds, L.q, pr, 0, m);
-            FilterConsts<P> fc;
-            filter_reset<P, G>(g, m, fc);
-            RowConsts<P> rc;
-            row_consts<P>(g, m, fc, rc);
             if (wave == 0) {
+                model_from_theta<P, G, MODEL_CONSTS>(g, thn_lds, L.q, pr, 0, m);
+                FilterConsts<P> fc;
+                filter_reset<P, G>(g, m, fc);
+                RowConsts<P> rc;
+                row_consts<P>(g, m, fc, rc);
                 pipe3l_cov<P>(g, m, rc, series, L.n, ring);
             } else {
+                model_from_theta<P, G, MODEL_FLAGS>(g, thn_lds, L.q, pr, 0, m);
                 double lpri = log_prior(m.scale, pr.measerr_dof);       // before the recursion: off the critical path
                 asm volatile("" : "+v"(lpri));
-                double ll = pipe3l_mean<P>(g, m, rc, series, L.n, ring);
+                double ll = pipe3l_mean<P>(g, m.mu, series, L.n, ring);
                 ll += lpri;
-                if (fc.sing || !m.valid) ll = -1.0 / 0.0;
+                if (m.sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;
             }
         }
