@@ -47,6 +47,21 @@ int main()
         double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
         printf("empty kernel, grid %4d x 256 threads, 42 KiB LDS: %.2f us per back-to-back launch\n", grid, us);
     }
+    {   // the same 2000 launches as a captured graph of 100 kernel nodes, replayed 20 times
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+        for (int i = 0; i < 100; i++) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 42800, st, d);
+        hipStreamEndCapture(st, &graph);
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphLaunch(exec, st);
+        hipStreamSynchronize(st);
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 20; i++) hipGraphLaunch(exec, st);
+        hipStreamSynchronize(st);
+        double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+        printf("empty kernel, grid  256, as a hipGraph of 100 nodes: %.2f us per kernel\n", us);
+    }
     hipLaunchKernelGGL(k_clock, dim3(1024), dim3(64), 0, st, dc, d, 200000);
     hipStreamSynchronize(st);
     long long h[2];
