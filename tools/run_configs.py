@@ -44,9 +44,12 @@ out["config3_pt_mcmc"] = {
     "truth_first5": truth[:5].tolist(),
 }
 
-# ---- config 4: CARMA(7,6), n=10000, 8 temperatures, >=128 replicas (one GPU holds the whole ladder here;
-#      carma_pack_amd.parallel.LadderShard splits it one block per rank under torch.distributed)
-t4, y4, e4 = irregular_series(10000, seed=4)
+# ---- config 4: CARMA(7,6), n=10000 (0.1 + |Cauchy| steps, own CARMA draw), 8 temperatures x 128 replicas: the whole
+#      ladder on one GPU, then the same ladder as two blocks of 4 / eight blocks of 1 through carma_pt_iterate_sharded
+#      (RCCL send/recv to this process's own rank: one GPU here; the blocks run one after the other on it)
+from carma_pack_amd import _lib  # noqa: E402
+from carma_pack_amd.synth import config4_series  # noqa: E402
+t4, y4, e4, th4 = config4_series(10000, seed=4)
 ctx4 = cpa.Context(t4, y4, e4, 7, 6)
 rng = np.random.default_rng(4)
 th = np.array([prior_like_theta(rng, 7, 6, t4, y4) for _ in range(1024)])
@@ -54,16 +57,43 @@ ctx4.logdensity(th[:8])
 t0 = time.perf_counter()
 ld = ctx4.logdensity(th, ignore_prior=True)
 dt_eval = time.perf_counter() - t0
-sh = par.LadderShard(ctx4, 8, 128, adapt_iters=10 ** 6, seed=5, dist=None)
-sh.start()
-sh.iterate(2)
+ctx4.pt_create(8, 128, adapt_iters=10 ** 6, seed=5)
+ctx4.pt_start(None)
+ctx4.pt_iterate(5)
 t0 = time.perf_counter()
-sh.iterate(20)
+ctx4.pt_iterate(100)
 dt_pt = time.perf_counter() - t0
 out["config4_carma76_n10000"] = {
     "batch_1024_evals_seconds": dt_eval, "evals_per_s": 1024 / dt_eval, "finite": int(np.isfinite(ld).sum()),
-    "pt_8temps_128replicas_iters_per_s": 20 / dt_pt, "pt_chain_evals_per_s": 20 * 8 * 128 / dt_pt,
+    "logdensity_at_truth": float(ctx4.logdensity(th4)),
+    "pt_8temps_128replicas_iters_per_s": 100 / dt_pt, "pt_chain_evals_per_s": 100 * 8 * 128 / dt_pt,
 }
+comm = _lib.Comm(_lib.Comm.unique_id(), 1, 0, device=0)
+temps = par.ladder_temperatures(8)
+for blocks in ([4, 4], [1] * 8):
+    ctxs, slot0 = [], 0
+    for Tl in blocks:
+        c = cpa.Context(t4, y4, e4, 7, 6)
+        c.pt_create(Tl, 128, 10 ** 6, seed=5, temperatures=temps[slot0:slot0 + Tl])
+        c.pt_shard(8, slot0, 0)
+        c.pt_start(None)
+        ctxs.append(c)
+        slot0 += Tl
+    _lib.pt_iterate_sharded(ctxs, 4, comm)
+    t0 = time.perf_counter()
+    _lib.pt_iterate_sharded(ctxs, 40, comm)
+    dts = time.perf_counter() - t0
+    # the blocks' kernels alone, one after the other (what the sharded run costs without any exchange)
+    t0 = time.perf_counter()
+    for _ in range(40):
+        for c in ctxs:
+            c.pt_iterate(1)
+    dta = time.perf_counter() - t0
+    out["config4_carma76_n10000"]["sharded_%s" % "x".join(map(str, blocks))] = {
+        "iters_per_s": 40 / dts, "ms_per_iteration": 1e3 * dts / 40,
+        "ms_per_iteration_blocks_alone_with_a_host_sync_each": 1e3 * dta / 40,
+        "boundary_swaps": [c.pt_boundary_stats() for c in ctxs]}
+comm.close()
 
 # ---- config 5: OGLE-LMC-LPV-00007, all (p,q), 100 prior-like thetas each, ignore_prior ---------------
 og = np.loadtxt(os.path.join(G, "ogle_lmc_lpv_00007.dat"))
