@@ -10,7 +10,7 @@
  * Conventions
  *   - return value 0 = success, negative = error (CARMA_E*); carma_last_error() has the text.
  *   - numerical failure is reported IN BAND, exactly as the reference does: a log-density of
- *     -INFINITY for a prior-bound violation or a singular Vandermonde solve
+ *     -INFINITY for a prior-bound violation or a repeated AR root (the reference's singular Vandermonde solve)
  *     (src/include/carpack.hpp:134-138,154-164), NaN where the reference's arithmetic gives NaN.
  *   - theta layout (src/carpack.cpp:205-207,432): theta[0]=sigma_y, theta[1]=measurement-error
  *     scale, theta[2]=mu, theta[3..3+p) log quadratic-factor coefficients of the AR polynomial,
@@ -85,9 +85,10 @@ double carma_logprior(const carma_ctx* h, const double* theta);
  * KalmanFilterp(time,y,yerr,sigsqr,omega,ma).Filter() + GetMean()/GetVar()
  * (src/include/kfilter.hpp:303-334,126-132; wrapper :91-101).  y is already centred, yerr is
  * used as given; omega_re_im = [p][2]; ma has p entries (zero padded by the caller or here if
- * nma < p, kfilter.hpp:318-320).  The series is sorted/deduplicated first; *n_out receives the
- * resulting length and mean/var must have room for n values.
- * Returns 1 (and fills nothing useful) if the Vandermonde solve is singular -- the reference
+ * nma < p, kfilter.hpp:318-320).  The AR roots may come in any order but must be closed under conjugation (real
+ * roots, conjugate pairs): anything else is not a real-valued process and is CARMA_EINVAL.  The series is
+ * sorted/deduplicated first; *n_out receives the resulting length and mean/var must have room for n values.
+ * Returns 1 (and fills nothing useful) for a repeated AR root (singular eigenvector matrix) -- the reference
  * throws std::runtime_error there.
  */
 int carma_kfilter_carma(const double* time, const double* y, const double* yerr, int n, int p,

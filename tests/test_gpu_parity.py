@@ -70,6 +70,16 @@ def test_ogle_grid_all_orders(cpa, golden_dir):
             ll = ctx.logdensity(th, ignore_prior=True) - np.array([ctx.logprior(x) for x in th])
             worst = max(worst, assert_parity(ll, g[k + "loglik"], RTOL, "ogle p=%d q=%d" % (p, q)))
             ctx.close()
+    # the 28th order of BASELINE configs[4]: (1, 0), against the closed-form dense GP (make_golden_ogle_car1.py)
+    g1 = np.load(os.path.join(golden_dir, "ogle_car1.npz"))
+    ctx = cpa.Context(t, y, yerr, 1, 0)
+    ll = ctx.logdensity(g1["theta"]) - np.array([ctx.logprior(x) for x in g1["theta"]])
+    assert np.all(np.isfinite(ll))
+    worst = max(worst, assert_parity(ll, g1["loglik"], RTOL, "ogle p=1 q=0"))
+    for i in (0, 3):
+        th = g1["theta"][i]
+        mean, var = cpa.kfilter_car1(t, y - th[2], np.sqrt(th[1]) * yerr, 2.0 * th[0] ** 2 * np.exp(th[3]), np.exp(th[3]))
+        np.testing.assert_allclose(var, g1["var"][i], rtol=1e-9)
     print("worst rel err on OGLE grid: %.2e" % worst)
 
 

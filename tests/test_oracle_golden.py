@@ -271,3 +271,19 @@ def test_quad_precision_arbiter_is_the_50_digit_value():
             if np.isfinite(o):
                 worst_oracle = max(worst_oracle, abs(o - b) / abs(b))
     assert worst_oracle > 1e-6          # these cases ARE the ones the double-precision restatement cannot resolve
+
+
+def test_ogle_grid_car1_member(golden_dir):
+    """(p, q) = (1, 0) on OGLE-LMC-LPV-00007 (the 28th order of BASELINE configs[4]): the oracle's CAR(1) filter and
+    log-density against the closed-form dense Gaussian process (make_golden_ogle_car1.py)."""
+    og = np.loadtxt(os.path.join(golden_dir, "ogle_lmc_lpv_00007.dat"))
+    t, y, e = og[:, 0], og[:, 1], og[:, 2]
+    g = _load(golden_dir, "ogle_car1.npz")
+    m = orc.OracleModel(t, y, e, 1)
+    for i, th in enumerate(g["theta"]):
+        mean, var = orc.kfilter_car1(t, y - th[2], np.sqrt(th[1]) * e, 2.0 * th[0] ** 2 * np.exp(th[3]), np.exp(th[3]))
+        np.testing.assert_allclose(var, g["var"][i], rtol=1e-9)
+        np.testing.assert_allclose(mean, g["mean"][i], rtol=0, atol=1e-9 * np.abs(y - th[2]).max())
+        ll = m.logdensity(th) - m.log_prior(th)
+        assert np.isfinite(ll) and abs(ll - g["loglik"][i]) <= 1e-10 * abs(ll)
+        assert abs(ll - g["dense_loglik"][i]) <= 1e-9 * abs(ll)
