@@ -242,12 +242,14 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         double w, var, k;
         RA::lazy_front(w, var, k, ht, ct, e, m.scale, rc.s0, one, S);
         link_b[(size_t)s * Geo::SLOT] = make_double2(k, var);
-        // S_j -= (k~ / var) k~_j   (kfilter.cpp:197);  1/var = r0 (1 + e + e^2), e = 1 - var r0, folded into nt = -k~ / var
+        // S_j -= (k~ / var) k~_j   (kfilter.cpp:197);  1/var = r0 (1 + e) (1 + O(e^2)), e = 1 - var r0, folded into
+        // nt = -k~ / var.  v_rcp_f64 is good to 2^-24.4, so this Newton step leaves 2e-15 relative in the rank-1 term of
+        // ONE step of a contracting recursion (parity unchanged: profiles/r02/parity_sweep_v3.txt) -- the cubic step
+        // nt = kr (1 + e + e^2) of round 1 was one instruction and 8 cycles of dependent latency more, every datum.
         const double r0 = __builtin_amdgcn_rcp(var);
         const double kr = -k * r0;
         const double er = fma(-var, r0, 1.0);
-        const double e2 = fma(er, er, er);
-        const double nt = fma(kr, e2, kr);
+        const double nt = fma(kr, er, kr);
         RA::gain_nt(S, k, nt);
     };
     const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);

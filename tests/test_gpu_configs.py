@@ -212,7 +212,7 @@ def test_config4_choose_order_vs_scipy(cpa, golden_dir):
     # is statistical -- start by start the lock-step optimiser must be at least as good as scipy (to 0.05) as often as
     # not -- plus: on the smooth low orders the optima agree, and the 100-start optimum behind choose_order's AICc entry
     # is at least as good as what either finds from 24 starts.
-    wins = losses = 0
+    wins = losses = unlucky = 0
     for (p, q) in ((1, 0), (2, 1), (3, 0), (4, 2), (5, 3), (6, 1), (7, 6)):
         k = 2 + p + q
         fun_100 = 0.5 * (aicc[pqlist.index((p, q))] - 2.0 * k - 2.0 * k * (k + 1.0) / (n - k - 1.0))
@@ -228,11 +228,14 @@ def test_config4_choose_order_vs_scipy(cpa, golden_dir):
         if p <= 3:
             assert abs(fb[ok].min() - fs[ok].min()) <= 0.05, (p, q)
         assert fb[ok].min() <= fs[ok].min() + 6.0, (p, q)
-        assert fun_100 <= min(fb[ok].min(), fs[ok].min()) + 0.5 or p >= 6, (p, q, fun_100, fb[ok].min(), fs[ok].min())
+        # (the 100 starts of choose_order are drawn independently of these 24, so on a rugged surface either set can hold
+        # the lucky start: bounded here, counted below)
+        assert fun_100 <= min(fb[ok].min(), fs[ok].min()) + (0.05 if p <= 3 else 6.0), (p, q, fun_100, fb[ok].min(), fs[ok].min())
+        unlucky += fun_100 > min(fb[ok].min(), fs[ok].min()) + 0.5
         # the objective is the oracle's: -LogDensity(x) with the bounds ignored (SetMLE(true), carma_pack.py:242)
         best = mle[int(np.argmin(np.where(ok, fb, np.inf)))]
         m = orc.OracleModel(t, y, e, p, q)
         want = -m.logdensity(best.x, ignore_prior=True) if p > 1 else -m.logdensity(best.x)
         assert abs(best.fun - want) <= 1e-9 * abs(want), (p, q)
     print("lock-step optimiser at least as good as scipy (to 0.05) from %d of %d common starts" % (wins, wins + losses))
-    assert wins >= losses
+    assert wins >= losses and unlucky <= 3
