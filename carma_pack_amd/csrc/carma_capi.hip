@@ -149,13 +149,18 @@ int Ctx::ensure_staging(int B)
     if (B <= cap) return CARMA_OK;
     if (d_theta) (void)hipFree(d_theta);
     if (d_out) (void)hipFree(d_out);
-    d_theta = d_out = nullptr;
+    if (h_stage) (void)hipHostFree(h_stage);
+    d_theta = d_out = h_stage = nullptr;
     cap = 0;
     int newcap = std::max(B, 1024);
     hipError_t e = hipMalloc(&d_theta, sizeof(double) * (size_t)newcap * d);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(theta)");
     e = hipMalloc(&d_out, sizeof(double) * (size_t)newcap);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(out)");
+    // pinned, so that both copies are real asynchronous DMA transfers ordered on the stream (a copy from pageable memory
+    // is staged by the runtime and synchronises)
+    e = hipHostMalloc(reinterpret_cast<void**>(&h_stage), sizeof(double) * (size_t)newcap * (d + 1), hipHostMallocDefault);
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(staging)");
     cap = newcap;
     return CARMA_OK;
 }
@@ -230,6 +235,7 @@ void carma_ctx_destroy(carma_ctx* h)
     if (c->d_series) (void)hipFree(c->d_series);
     if (c->d_theta) (void)hipFree(c->d_theta);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -301,13 +307,18 @@ int carma_logdensity_batch(carma_ctx* h, const double* theta, int B, int ignore_
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     int rc = c->ensure_staging(B);
     if (rc != CARMA_OK) return rc;
-    e = hipMemcpyAsync(c->d_theta, theta, sizeof(double) * (size_t)B * c->d, hipMemcpyHostToDevice, c->stream);
+    // host -> pinned -> device, launch, device -> pinned: three stream-ordered operations and ONE synchronisation
+    double* h_th = c->h_stage;
+    double* h_out = c->h_stage + (size_t)c->cap * c->d;
+    std::memcpy(h_th, theta, sizeof(double) * (size_t)B * c->d);
+    e = hipMemcpyAsync(c->d_theta, h_th, sizeof(double) * (size_t)B * c->d, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) return hip_fail(e, "H2D theta");
     rc = carma_logdensity_batch_dev(h, c->d_theta, B, ignore_prior, c->d_out, c->stream);
     if (rc != CARMA_OK) return rc;
-    e = hipMemcpyAsync(out, c->d_out, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, c->stream);
+    e = hipMemcpyAsync(h_out, c->d_out, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return hip_fail(e, "D2H logdensity");
+    std::memcpy(out, h_out, sizeof(double) * (size_t)B);
     return CARMA_OK;
 }
 

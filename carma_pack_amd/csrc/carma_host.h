@@ -45,6 +45,7 @@ struct Ctx {
     double* d_series = nullptr;       // [n] records {dt, y, yerr^2, t}, resident in HBM
     double* d_theta = nullptr;        // staging for the host-pointer entry points
     double* d_out = nullptr;
+    double* h_stage = nullptr;        // pinned host staging: [cap * d] parameter vectors followed by [cap] results
     int cap = 0;
     hipStream_t stream = nullptr;
     PtState* pt = nullptr;

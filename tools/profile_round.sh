@@ -13,9 +13,9 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --no-cpu > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o $TAG -- python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu --no-mcmc --no-throughput --no-ladder > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o $TAG -- python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu --no-mcmc --no-pipelined --no-throughput --no-ladder > $OUT/pmc_$c.log 2>&1
   echo "pmc $c rc=$?"
 done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -o $TAG -- python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu --no-mcmc --no-throughput --no-ladder > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -o $TAG -- python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu --no-mcmc --no-pipelined --no-throughput --no-ladder > $OUT/pmc_SQ.log 2>&1
 echo "pmc SQ rc=$?"
 find $OUT -name "*.csv" | head -20
