@@ -172,6 +172,12 @@ class _KalmanBase(object):
         self._t, self._y, self._e = _arr(time), _arr(y), _arr(yerr)
         self._mean = np.zeros(self._t.size)
         self._var = np.zeros(self._t.size)
+        self._kf = None          # carma_kf handle: series + model resident in HBM from the first Filter / Predict on
+
+    def _handle(self):
+        if self._kf is None:
+            self._kf = self._make_handle(self._t, self._y, self._e)
+        return self._kf
 
     def GetMean(self):
         return vecD(self._mean.tolist())
@@ -215,11 +221,16 @@ class KalmanFilter1(_KalmanBase):
     def Filter(self):
         if self._sigsqr is None or self._omega is None:
             raise RuntimeError("KalmanFilter1: sigsqr and omega are not set")
-        self._mean, self._var = _lib.kfilter_car1(self._t, self._y, self._e, self._sigsqr, self._omega)
+        self._mean, self._var = self._handle().filter()
+
+    def _make_handle(self, t, y, e):
+        if self._sigsqr is None or self._omega is None:
+            raise RuntimeError("KalmanFilter1: sigsqr and omega are not set")
+        return _lib.KalmanHandle(t, y, e, self._sigsqr, self._omega)
 
     def PredictBatch(self, times):
-        """Extension: all times in one launch (carma_predict_car1)."""
-        return self._predict(self._t, self._y, self._e, _arr(times))
+        """Extension: all times in one launch (carma_kf_predict)."""
+        return self._handle().predict(_arr(times))
 
     def _predict(self, t, y, e, times):
         return _lib.predict_car1(t, y, e, self._sigsqr, self._omega, times)
@@ -241,11 +252,16 @@ class KalmanFilterp(_KalmanBase):
     def Filter(self):
         if self._sigsqr is None or self._omega is None or self._ma is None:
             raise RuntimeError("KalmanFilterp: sigsqr, omega and ma_coefs are not set")
-        self._mean, self._var = _lib.kfilter_carma(self._t, self._y, self._e, self._sigsqr, self._omega, self._ma)
+        self._mean, self._var = self._handle().filter()
+
+    def _make_handle(self, t, y, e):
+        if self._sigsqr is None or self._omega is None or self._ma is None:
+            raise RuntimeError("KalmanFilterp: sigsqr, omega and ma_coefs are not set")
+        return _lib.KalmanHandle(t, y, e, self._sigsqr, self._omega, self._ma)
 
     def PredictBatch(self, times):
-        """Extension: all times in one launch (carma_predict_carma)."""
-        return self._predict(self._t, self._y, self._e, _arr(times))
+        """Extension: all times in one launch (carma_kf_predict)."""
+        return self._handle().predict(_arr(times))
 
     def _predict(self, t, y, e, times):
         return _lib.predict_carma(t, y, e, self._sigsqr, self._omega, self._ma, times)

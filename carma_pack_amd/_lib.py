@@ -96,6 +96,15 @@ def _load():
     L.carma_predict_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, C.c_int,
                                       _dp, _dp, C.c_int]
     L.carma_predict_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp, C.c_int]
+    L.carma_kf_create_carma.restype = C.c_void_p
+    L.carma_kf_create_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, C.c_int]
+    L.carma_kf_create_car1.restype = C.c_void_p
+    L.carma_kf_create_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int]
+    L.carma_kf_destroy.argtypes = [C.c_void_p]
+    L.carma_kf_destroy.restype = None
+    L.carma_kf_n.argtypes = [C.c_void_p]
+    L.carma_kf_filter.argtypes = [C.c_void_p, _dp, _dp]
+    L.carma_kf_predict.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp]
     L.carma_simulate_carma.argtypes = [_dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, C.c_int, C.c_uint64, _dp, C.c_int]
     L.carma_simulate_car1.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, _dp, C.c_int]
     L.carma_pt_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64,
@@ -130,7 +139,8 @@ EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
     "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_kfilter_carma",
-    "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_simulate_carma", "carma_simulate_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
+    "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_kf_create_carma", "carma_kf_create_car1",
+    "carma_kf_destroy", "carma_kf_n", "carma_kf_filter", "carma_kf_predict", "carma_simulate_carma", "carma_simulate_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_boundary_stats",
@@ -357,6 +367,54 @@ def pt_iterate_sharded(contexts, niter, comm=None):
     arr = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
     check(lib.carma_pt_iterate_sharded(arr, len(contexts), int(niter), comm._h if comm is not None else None),
           "carma_pt_iterate_sharded")
+
+
+class KalmanHandle:
+    """carma_kf: a KalmanFilter1 / KalmanFilterp object whose series and model stay resident in HBM; Filter and any
+    number of (batched) Predict calls only launch and copy results back."""
+
+    def __init__(self, time, y, yerr, sigsqr, omega, ma=None, device=None):
+        time, y, yerr = as_f64(time), as_f64(y), as_f64(yerr)
+        dev = default_device() if device is None else int(device)
+        if ma is None:                                   # CAR(1): omega is the real rate 1 / tau
+            self._h = lib.carma_kf_create_car1(ptr(time), ptr(y), ptr(yerr), time.size, float(sigsqr), float(omega), dev)
+        else:
+            omega = np.asarray(omega, dtype=complex)
+            om, ma = as_f64(np.c_[omega.real, omega.imag]), as_f64(ma)
+            self._h = lib.carma_kf_create_carma(ptr(time), ptr(y), ptr(yerr), time.size, omega.size, float(sigsqr), ptr(om),
+                                                ptr(ma), ma.size, dev)
+        if not self._h:
+            msg = "carma_kf_create failed: " + last_error()
+            raise CarmaDeviceError(msg) if "no HIP device" in msg else ValueError(msg)
+        self.n = lib.carma_kf_n(self._h)
+
+    def filter(self):
+        mean, var = np.empty(self.n), np.empty(self.n)
+        rc = lib.carma_kf_filter(self._h, ptr(mean), ptr(var))
+        if rc == 1:
+            raise CarmaError("KalmanFilterp: singular eigenvector matrix (solve failed)")
+        check(rc, "carma_kf_filter")
+        return mean, var
+
+    def predict(self, tpred):
+        tp = as_f64(np.atleast_1d(tpred))
+        pm, pv = np.empty(tp.size), np.empty(tp.size)
+        rc = lib.carma_kf_predict(self._h, ptr(tp), tp.size, ptr(pm), ptr(pv))
+        if rc == 1:
+            raise CarmaError("KalmanFilterp: singular eigenvector matrix (solve failed)")
+        check(rc, "carma_kf_predict")
+        return pm, pv
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.carma_kf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def kfilter_carma(time, y, yerr, sigsqr, omega, ma, device=None):

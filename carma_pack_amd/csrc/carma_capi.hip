@@ -338,143 +338,233 @@ double carma_logprior(const carma_ctx* h, const double* theta)
     return -0.5 * c->pr.measerr_dof / s - (1.0 + c->pr.measerr_dof / 2.0) * std::log(s);
 }
 
-static int kfilter_common(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
-                          const double* omega_re_im, const double* ma, int nma, double car1_omega, double* mean,
-                          double* var, int* n_out, int device)
-{
-    if (!time || !y || !yerr || !mean || !var || n < 1) {
-        set_error("carma_kfilter: bad argument");
-        return CARMA_EINVAL;
+}  // extern "C"
+
+namespace carma {
+
+// KalmanFilter1 / KalmanFilterp object (kfilter.hpp:211-334): the sorted / deduplicated series and the model, resident
+// in HBM for the life of the handle (the free functions below build one per call).
+struct Kf {
+    int device = 0, p = 0, n = 0;
+    double sigsqr = 0.0, car1_omega = 0.0;
+    double *d_series = nullptr, *d_par = nullptr, *d_io = nullptr;
+    int* d_sing = nullptr;
+    size_t io_cap = 0;
+    hipStream_t stream = nullptr;
+    int ensure_io(size_t nd)
+    {
+        if (nd <= io_cap) return CARMA_OK;
+        if (d_io) (void)hipFree(d_io);
+        d_io = nullptr;
+        io_cap = 0;
+        hipError_t e = hipMalloc(&d_io, sizeof(double) * nd);
+        if (e != hipSuccess) return hip_fail(e, "carma_kf: hipMalloc");
+        io_cap = nd;
+        return CARMA_OK;
     }
-    int rc = select_device(device);
-    if (rc != CARMA_OK) return rc;
+};
+
+static void kf_free(Kf* k)
+{
+    if (!k) return;
+    (void)hipSetDevice(k->device);
+    if (k->d_series) (void)hipFree(k->d_series);
+    if (k->d_par) (void)hipFree(k->d_par);
+    if (k->d_io) (void)hipFree(k->d_io);
+    if (k->d_sing) (void)hipFree(k->d_sing);
+    if (k->stream) (void)hipStreamDestroy(k->stream);
+    delete k;
+}
+
+static Kf* kf_make(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
+                   const double* omega_re_im, const double* ma, int nma, double car1_omega, int device, const char* who,
+                   int* rc_out = nullptr)
+{
+    int rc_local = CARMA_EINVAL;
+    int& rc = rc_out ? *rc_out : rc_local;
+    rc = CARMA_EINVAL;
+    if (!time || !y || !yerr || n < 1) {
+        set_error("%s: bad argument", who);
+        return nullptr;
+    }
+    if (p != 1 && (p < 2 || p > CARMA_PMAX || !omega_re_im || !ma || nma < 1)) {
+        set_error("%s: need 2 <= p <= %d, omega and ma", who, CARMA_PMAX);
+        return nullptr;
+    }
+    rc = select_device(device);
+    if (rc != CARMA_OK) return nullptr;
+    rc = CARMA_EINVAL;
     std::vector<double> t(time, time + n), yy(y, y + n), ee(yerr, yerr + n);
     if (n >= 2) sort_dedup(t, yy, ee);
-    const int m = (int)t.size();
-    if (n_out) *n_out = m;
     std::vector<double> s = pack_series(t, yy, ee);
     std::vector<double> par(2 * CARMA_PMAX + CARMA_PMAX, 0.0);
     if (p > 1) {
         if (normalize_roots(p, omega_re_im, par.data()) != CARMA_OK) {
-            set_error("carma_kfilter_carma: the AR roots must be real or come in complex-conjugate pairs");
-            return CARMA_EINVAL;
+            set_error("%s: the AR roots must be real or come in complex-conjugate pairs", who);
+            return nullptr;
         }
         for (int i = 0; i < p && i < nma; i++) par[2 * CARMA_PMAX + i] = ma[i];   // zero padded (kfilter.hpp:318-320)
     }
-    double *d_s = nullptr, *d_par = nullptr, *d_mv = nullptr;
-    int* d_sing = nullptr;
-    hipError_t e = hipMalloc(&d_s, sizeof(double) * s.size());
-    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
-    if (e == hipSuccess) e = hipMalloc(&d_mv, sizeof(double) * 2 * m);
-    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int));
-    if (e == hipSuccess) e = hipMemcpy(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_sing, 0, sizeof(int));
+    Kf* k = new Kf();
+    k->device = device;
+    k->p = p;
+    k->n = (int)t.size();
+    k->sigsqr = sigsqr;
+    k->car1_omega = car1_omega;
+    hipError_t e = hipMalloc(&k->d_series, sizeof(double) * s.size());
+    if (e == hipSuccess) e = hipMalloc(&k->d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = hipMalloc(&k->d_sing, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(k->d_series, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(k->d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        rc = hip_fail(e, who);
+        kf_free(k);
+        return nullptr;
+    }
+    rc = CARMA_OK;
+    return k;
+}
+
+// Filter() + GetMean() / GetVar() (kfilter.hpp:126-132)
+static int kf_filter(Kf* k, double* mean, double* var)
+{
+    if (!mean || !var) return CARMA_EINVAL;
+    hipError_t e = hipSetDevice(k->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    const int m = k->n;
+    int rc = k->ensure_io(2 * (size_t)m);
+    if (rc != CARMA_OK) return rc;
+    e = hipMemsetAsync(k->d_sing, 0, sizeof(int), k->stream);
     if (e == hipSuccess) {
-        if (p == 1)
-            e = launch_kfilter_car1(sigsqr, car1_omega, reinterpret_cast<const double4*>(d_s), m, d_mv, d_mv + m, nullptr);
+        if (k->p == 1)
+            e = launch_kfilter_car1(k->sigsqr, k->car1_omega, reinterpret_cast<const double4*>(k->d_series), m, k->d_io, k->d_io + m,
+                                    k->stream);
         else
-            e = launch_kfilter_carma(p, d_par, d_par + 2 * CARMA_PMAX, sigsqr, reinterpret_cast<const double4*>(d_s), m,
-                                     d_mv, d_mv + m, d_sing, nullptr);
+            e = launch_kfilter_carma(k->p, k->d_par, k->d_par + 2 * CARMA_PMAX, k->sigsqr,
+                                     reinterpret_cast<const double4*>(k->d_series), m, k->d_io, k->d_io + m, k->d_sing, k->stream);
     }
     int sing = 0;
-    if (e == hipSuccess) e = hipMemcpy(mean, d_mv, sizeof(double) * m, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(var, d_mv + m, sizeof(double) * m, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(&sing, d_sing, sizeof(int), hipMemcpyDeviceToHost);
-    if (d_s) (void)hipFree(d_s);
-    if (d_par) (void)hipFree(d_par);
-    if (d_mv) (void)hipFree(d_mv);
-    if (d_sing) (void)hipFree(d_sing);
+    if (e == hipSuccess) e = hipMemcpyAsync(mean, k->d_io, sizeof(double) * m, hipMemcpyDeviceToHost, k->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(var, k->d_io + m, sizeof(double) * m, hipMemcpyDeviceToHost, k->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&sing, k->d_sing, sizeof(int), hipMemcpyDeviceToHost, k->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
     if (e != hipSuccess) return hip_fail(e, "carma_kfilter");
     return sing ? 1 : CARMA_OK;
+}
+
+// Predict for M times in one launch (kfilter.cpp:218-337, 72-135)
+static int kf_predict(Kf* k, const double* tpred, int M, double* pmean, double* pvar)
+{
+    if (!tpred || !pmean || !pvar || M < 0) {
+        set_error("carma_predict: bad argument");
+        return CARMA_EINVAL;
+    }
+    if (M == 0) return CARMA_OK;
+    hipError_t e = hipSetDevice(k->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int rc = k->ensure_io(3 * (size_t)M);
+    if (rc != CARMA_OK) return rc;
+    double* d_io = k->d_io;
+    e = hipMemcpyAsync(d_io, tpred, sizeof(double) * M, hipMemcpyHostToDevice, k->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(k->d_sing, 0, sizeof(int), k->stream);
+    if (e == hipSuccess) {
+        if (k->p == 1)
+            e = launch_predict_car1(k->sigsqr, k->car1_omega, reinterpret_cast<const double4*>(k->d_series), k->n, d_io, M, d_io + M,
+                                    d_io + 2 * (size_t)M, k->stream);
+        else
+            e = launch_predict_carma(k->p, k->d_par, k->d_par + 2 * CARMA_PMAX, k->sigsqr,
+                                     reinterpret_cast<const double4*>(k->d_series), k->n, d_io, M, d_io + M, d_io + 2 * (size_t)M,
+                                     k->d_sing, k->stream);
+    }
+    int sing = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(pmean, d_io + M, sizeof(double) * M, hipMemcpyDeviceToHost, k->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pvar, d_io + 2 * (size_t)M, sizeof(double) * M, hipMemcpyDeviceToHost, k->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&sing, k->d_sing, sizeof(int), hipMemcpyDeviceToHost, k->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+    if (e != hipSuccess) return hip_fail(e, "carma_predict");
+    return sing ? 1 : CARMA_OK;
+}
+
+}  // namespace carma
+
+extern "C" {
+
+carma_kf* carma_kf_create_carma(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
+                                const double* omega_re_im, const double* ma, int nma, int device)
+{
+    if (p < 2) {
+        set_error("carma_kf_create_carma: need 2 <= p <= %d", CARMA_PMAX);
+        return nullptr;
+    }
+    return reinterpret_cast<carma_kf*>(kf_make(time, y, yerr, n, p, sigsqr, omega_re_im, ma, nma, 0.0, device, "carma_kf_create_carma"));
+}
+
+carma_kf* carma_kf_create_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr, double omega, int device)
+{
+    return reinterpret_cast<carma_kf*>(kf_make(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, device, "carma_kf_create_car1"));
+}
+
+void carma_kf_destroy(carma_kf* h) { kf_free(reinterpret_cast<Kf*>(h)); }
+int carma_kf_n(const carma_kf* h) { return h ? reinterpret_cast<const Kf*>(h)->n : CARMA_EINVAL; }
+int carma_kf_filter(carma_kf* h, double* mean, double* var) { return h ? kf_filter(reinterpret_cast<Kf*>(h), mean, var) : CARMA_EINVAL; }
+int carma_kf_predict(carma_kf* h, const double* tpred, int M, double* pmean, double* pvar)
+{
+    return h ? kf_predict(reinterpret_cast<Kf*>(h), tpred, M, pmean, pvar) : CARMA_EINVAL;
 }
 
 int carma_kfilter_carma(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
                         const double* omega_re_im, const double* ma, int nma, double* mean, double* var, int* n_out,
                         int device)
 {
-    if (p < 2 || p > CARMA_PMAX || !omega_re_im || !ma || nma < 1) {
-        set_error("carma_kfilter_carma: need 2 <= p <= %d, omega and ma", CARMA_PMAX);
-        return CARMA_EINVAL;
+    int rc0 = CARMA_EINVAL;
+    Kf* k = (p >= 2) ? kf_make(time, y, yerr, n, p, sigsqr, omega_re_im, ma, nma, 0.0, device, "carma_kfilter_carma", &rc0) : nullptr;
+    if (!k) {
+        if (p < 2) set_error("carma_kfilter_carma: need 2 <= p <= %d, omega and ma", CARMA_PMAX);
+        return rc0;
     }
-    return kfilter_common(time, y, yerr, n, p, sigsqr, omega_re_im, ma, nma, 0.0, mean, var, n_out, device);
+    if (n_out) *n_out = k->n;
+    const int rc = kf_filter(k, mean, var);
+    kf_free(k);
+    return rc;
 }
 
 int carma_kfilter_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr, double omega,
                        double* mean, double* var, int* n_out, int device)
 {
-    return kfilter_common(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, mean, var, n_out, device);
-}
-
-// KalmanFilter*::Predict for M times in one launch.
-static int predict_common(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
-                          const double* omega_re_im, const double* ma, int nma, double car1_omega, const double* tpred,
-                          int M, double* pmean, double* pvar, int device)
-{
-    if (!time || !y || !yerr || !tpred || !pmean || !pvar || n < 1 || M < 0) {
-        set_error("carma_predict: bad argument");
-        return CARMA_EINVAL;
-    }
-    if (M == 0) return CARMA_OK;
-    int rc = select_device(device);
-    if (rc != CARMA_OK) return rc;
-    std::vector<double> t(time, time + n), yy(y, y + n), ee(yerr, yerr + n);
-    if (n >= 2) sort_dedup(t, yy, ee);
-    const int m = (int)t.size();
-    std::vector<double> s = pack_series(t, yy, ee);
-    std::vector<double> par(2 * CARMA_PMAX + CARMA_PMAX, 0.0);
-    if (p > 1) {
-        if (normalize_roots(p, omega_re_im, par.data()) != CARMA_OK) {
-            set_error("carma_predict_carma: the AR roots must be real or come in complex-conjugate pairs");
-            return CARMA_EINVAL;
-        }
-        for (int i = 0; i < p && i < nma; i++) par[2 * CARMA_PMAX + i] = ma[i];
-    }
-    double *d_s = nullptr, *d_par = nullptr, *d_io = nullptr;
-    int* d_sing = nullptr;
-    hipError_t e = hipMalloc(&d_s, sizeof(double) * s.size());
-    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
-    if (e == hipSuccess) e = hipMalloc(&d_io, sizeof(double) * 3 * (size_t)M);
-    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int));
-    if (e == hipSuccess) e = hipMemcpy(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_io, tpred, sizeof(double) * M, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_sing, 0, sizeof(int));
-    if (e == hipSuccess) {
-        if (p == 1)
-            e = launch_predict_car1(sigsqr, car1_omega, reinterpret_cast<const double4*>(d_s), m, d_io, M, d_io + M,
-                                    d_io + 2 * (size_t)M, nullptr);
-        else
-            e = launch_predict_carma(p, d_par, d_par + 2 * CARMA_PMAX, sigsqr, reinterpret_cast<const double4*>(d_s), m,
-                                     d_io, M, d_io + M, d_io + 2 * (size_t)M, d_sing, nullptr);
-    }
-    int sing = 0;
-    if (e == hipSuccess) e = hipMemcpy(pmean, d_io + M, sizeof(double) * M, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(pvar, d_io + 2 * (size_t)M, sizeof(double) * M, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(&sing, d_sing, sizeof(int), hipMemcpyDeviceToHost);
-    if (d_s) (void)hipFree(d_s);
-    if (d_par) (void)hipFree(d_par);
-    if (d_io) (void)hipFree(d_io);
-    if (d_sing) (void)hipFree(d_sing);
-    if (e != hipSuccess) return hip_fail(e, "carma_predict");
-    return sing ? 1 : CARMA_OK;
+    int rc0 = CARMA_EINVAL;
+    Kf* k = kf_make(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, device, "carma_kfilter_car1", &rc0);
+    if (!k) return rc0;
+    if (n_out) *n_out = k->n;
+    const int rc = kf_filter(k, mean, var);
+    kf_free(k);
+    return rc;
 }
 
 int carma_predict_carma(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
                         const double* omega_re_im, const double* ma, int nma, const double* tpred, int M, double* pmean,
                         double* pvar, int device)
 {
-    if (p < 2 || p > CARMA_PMAX || !omega_re_im || !ma || nma < 1) {
-        set_error("carma_predict_carma: need 2 <= p <= %d, omega and ma", CARMA_PMAX);
-        return CARMA_EINVAL;
+    int rc0 = CARMA_EINVAL;
+    Kf* k = (p >= 2) ? kf_make(time, y, yerr, n, p, sigsqr, omega_re_im, ma, nma, 0.0, device, "carma_predict_carma", &rc0) : nullptr;
+    if (!k) {
+        if (p < 2) set_error("carma_predict_carma: need 2 <= p <= %d, omega and ma", CARMA_PMAX);
+        return rc0;
     }
-    return predict_common(time, y, yerr, n, p, sigsqr, omega_re_im, ma, nma, 0.0, tpred, M, pmean, pvar, device);
+    const int rc = kf_predict(k, tpred, M, pmean, pvar);
+    kf_free(k);
+    return rc;
 }
 
 int carma_predict_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr, double omega,
                        const double* tpred, int M, double* pmean, double* pvar, int device)
 {
-    return predict_common(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, tpred, M, pmean, pvar, device);
+    int rc0 = CARMA_EINVAL;
+    Kf* k = kf_make(time, y, yerr, n, 1, sigsqr, nullptr, nullptr, 0, omega, device, "carma_predict_car1", &rc0);
+    if (!k) return rc0;
+    const int rc = kf_predict(k, tpred, M, pmean, pvar);
+    kf_free(k);
+    return rc;
 }
 
 // carma_process / car1_process for npaths paths in one launch

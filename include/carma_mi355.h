@@ -40,6 +40,7 @@ extern "C" {
 
 typedef struct carma_ctx carma_ctx;
 typedef struct carma_comm carma_comm;
+typedef struct carma_kf carma_kf;
 
 /* Library / device queries. */
 const char* carma_version(void);
@@ -112,6 +113,21 @@ int carma_predict_carma(const double* time, const double* y, const double* yerr,
                         const double* tpred, int M, double* pmean, double* pvar, int device);
 int carma_predict_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr,
                        double omega, const double* tpred, int M, double* pmean, double* pvar, int device);
+
+/*
+ * The same as OBJECTS, as the reference has them (KalmanFilter1 / KalmanFilterp, kfilter.hpp:211-334; wrapper :83-101):
+ * carma_kf_create_* copies, sorts and deduplicates the series and uploads it with the model ONCE; Filter and any number
+ * of Predict calls then only launch and copy results (the free functions above build such an object per call).
+ * carma_kf_n = length after sort/dedup (size of mean/var).  Return codes as above.
+ */
+carma_kf* carma_kf_create_carma(const double* time, const double* y, const double* yerr, int n, int p, double sigsqr,
+                                const double* omega_re_im, const double* ma, int nma, int device);
+carma_kf* carma_kf_create_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr,
+                               double omega, int device);
+void carma_kf_destroy(carma_kf* kf);
+int carma_kf_n(const carma_kf* kf);
+int carma_kf_filter(carma_kf* kf, double* mean, double* var);
+int carma_kf_predict(carma_kf* kf, const double* tpred, int M, double* pmean, double* pvar);
 
 /*
  * carma_process / car1_process (src/carmcmc/carma_pack.py:1148-1259, 1126-1146) for npaths independent paths in ONE

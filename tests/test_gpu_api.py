@@ -272,3 +272,42 @@ def test_device_carma_process_is_the_reference_construction(cm, golden_dir):
     for i in range(1, 4):
         want.append(rho[i - 1] * want[-1] + np.sqrt(5.0 * (1.0 - rho[i - 1] ** 2)) * z1[i])
     np.testing.assert_allclose(p1[3, :4], want, rtol=1e-12)
+
+
+def test_kalman_filter_objects_keep_their_series_on_the_device(cm, golden_dir):
+    """KalmanFilterp / KalmanFilter1 as objects (carma_kf_*): one upload, then Filter() and many Predict() calls -- the
+    reference's calling pattern (carma_pack.py:793-803: one Predict per plot point) -- give what the one-shot entry points
+    give, and what the oracle gives."""
+    import os
+    import oracle as orc
+    import carma_pack_amd as cpa
+    g = np.load(os.path.join(golden_dir, "cpp_carma_test300.npz"))
+    t, y, e = g["t"][:150], g["y"][:150], g["yerr"][:150]
+    roots, ma, sigsqr = g["omega"], g["ma"], float(g["sigsqr"])
+    om = cm.vecC()
+    for r in roots[::-1]:                                                  # any order of the roots is accepted
+        om.append(complex(r))
+    kf = cm.KalmanFilterp(cm.vecD(t.tolist()), cm.vecD(y.tolist()), cm.vecD(e.tolist()), sigsqr, om, cm.vecD(ma.tolist()))
+    kf.Filter()
+    mean, var = np.array(kf.GetMean()), np.array(kf.GetVar())
+    m1, v1 = cpa.kfilter_carma(t, y, e, sigsqr, roots, ma)
+    np.testing.assert_allclose(var, v1, rtol=1e-11)                       # (pairs in another order: other summation order)
+    np.testing.assert_allclose(mean, m1, rtol=0, atol=1e-10)
+    om_, ov_ = orc.kfilter_carma(t, y, e, sigsqr, roots, ma)
+    np.testing.assert_allclose(var, ov_, rtol=1e-10)
+    tp = np.r_[t[0] - 2.0, 0.5 * (t[20] + t[21]), t[-1] + 3.0]
+    for x in tp:                                                            # the reference's one-Predict-per-time pattern
+        pr = kf.Predict(float(x))
+        wm, wv = orc.predict_carma(t, y, e, sigsqr, roots, ma, [x])
+        assert abs(pr.first - wm[0]) <= 1e-9 * max(1.0, abs(wm[0])) and abs(pr.second - wv[0]) <= 1e-9 * wv[0]
+    pm, pv = kf.PredictBatch(tp)
+    assert pm[1] == kf.Predict(float(tp[1])).first
+    # a set of roots that is not closed under conjugation is not a real-valued process
+    bad = cm.vecC([complex(-0.1, 0.3), complex(-0.2, 0.0)])
+    with pytest.raises(ValueError):
+        cm.KalmanFilterp(cm.vecD(t.tolist()), cm.vecD(y.tolist()), cm.vecD(e.tolist()), 1.0, bad, cm.vecD([1.0])).Filter()
+    k1 = cm.KalmanFilter1(cm.vecD(t.tolist()), cm.vecD(y.tolist()), cm.vecD(e.tolist()), 0.3, 0.05)
+    k1.Filter()
+    o1m, o1v = orc.kfilter_car1(t, y, e, 0.3, 0.05)
+    np.testing.assert_allclose(np.array(k1.GetVar()), o1v, rtol=1e-11)
+    assert abs(k1.Predict(float(tp[2])).first - orc.predict_car1(t, y, e, 0.3, 0.05, [tp[2]])[0][0]) < 1e-10
