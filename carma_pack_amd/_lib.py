@@ -128,6 +128,7 @@ def _load():
     L.carma_comm_rank.argtypes = [C.c_void_p]
     L.carma_comm_size.argtypes = [C.c_void_p]
     L.carma_pt_iterate_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_void_p]
+    L.carma_pt_sample_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, _dp, _dp]
     L.carma_pt_boundary_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     return L
 
@@ -143,7 +144,7 @@ EXPORTS = [
     "carma_kf_destroy", "carma_kf_n", "carma_kf_filter", "carma_kf_predict", "carma_simulate_carma", "carma_simulate_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
-    "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_boundary_stats",
+    "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_sample_sharded", "carma_pt_boundary_stats",
 ]
 
 
@@ -273,6 +274,7 @@ class Context:
 
     def pt_shard(self, ntemps_global, slot0, replica0):
         check(lib.carma_pt_shard(self._h, int(ntemps_global), int(slot0), int(replica0)), "carma_pt_shard")
+        self._pt_slot0 = int(slot0)
 
     def pt_bind_state(self, d_theta_ptr, d_logpost_ptr):
         check(lib.carma_pt_bind_state(self._h, C.c_void_p(d_theta_ptr), C.c_void_p(d_logpost_ptr)),
@@ -492,3 +494,18 @@ def simulate_car1(time, sigsqr, omega, npaths=1, seed=0, device=None):
                                   C.c_uint64(int(seed) & (2 ** 64 - 1)), ptr(out), default_device() if device is None else device),
           "carma_simulate_car1")
     return out
+
+
+def pt_sample_sharded(contexts, nsamples, thin=1, comm=None):
+    """carma_pt_sample_sharded: returns (samples[R][nsamples][d], logposts[R][nsamples]) on the process that owns
+    temperature 0, (None, None) elsewhere."""
+    arr = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+    c0 = contexts[0]
+    owner = getattr(c0, "_pt_slot0", 0) == 0
+    R = c0._pt_shape[0]
+    samples = np.empty((R, int(nsamples), c0.d)) if owner else None
+    logposts = np.empty((R, int(nsamples))) if owner else None
+    check(lib.carma_pt_sample_sharded(arr, len(contexts), int(nsamples), int(thin), comm._h if comm is not None else None,
+                                      ptr(samples) if owner else None, ptr(logposts) if owner else None),
+          "carma_pt_sample_sharded")
+    return samples, logposts

@@ -128,6 +128,20 @@ __global__ void k_shard_swap(double* __restrict__ theta, double* __restrict__ lp
     }
 }
 
+// Sampler::SaveValues (src/samplers.cpp:118-124) for the sharded ladder: the coldest chain of every replica, AFTER the
+// iteration's boundary swaps -> samples[r][sidx][d], logposts[r][sidx]
+__global__ void k_shard_save(const double* __restrict__ theta, const double* __restrict__ lp, int R, int T, int d, long sidx,
+                             long cap, double* __restrict__ samples, double* __restrict__ slp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * (d + 1)) return;
+    const int r = i / (d + 1), j = i - r * (d + 1);
+    if (j < d)
+        samples[((size_t)r * cap + sidx) * d + j] = theta[((size_t)r * T) * d + j];
+    else
+        slp[(size_t)r * cap + sidx] = lp[(size_t)r * T];
+}
+
 }  // namespace carma
 
 using namespace carma;
@@ -191,7 +205,12 @@ void carma_comm_destroy(carma_comm* h)
 int carma_comm_rank(const carma_comm* h) { return h ? reinterpret_cast<const Comm*>(h)->rank : CARMA_EINVAL; }
 int carma_comm_size(const carma_comm* h) { return h ? reinterpret_cast<const Comm*>(h)->nranks : CARMA_EINVAL; }
 
-int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, carma_comm* comm)
+}  // extern "C"
+
+// niter iterations of the sharded ladder; save_thin > 0: after every save_thin-th iteration (and its boundary swaps)
+// the coldest chain of every replica is appended to d_samples / d_slp -- only on the process that owns temperature 0.
+static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, carma_comm* comm, int save_thin, long sample_cap,
+                           double* d_samples, double* d_slp)
 {
     if (!shards || nlocal < 1 || niter < 0) {
         set_error("carma_pt_iterate_sharded: bad argument");
@@ -260,7 +279,18 @@ int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, c
             int rc = pt_enqueue(cs[i], 1, 1, 0, nullptr, st);
             if (rc != CARMA_OK) return rc;
         }
-        if (nblocks == 1) continue;
+        const bool save_now = save_thin > 0 && d_samples && s0->slot0 == 0 && ((it + 1) % save_thin) == 0;
+        auto save = [&]() {
+            if (!save_now) return;
+            const long sidx = (it + 1) / save_thin - 1;
+            if (sidx < sample_cap)
+                hipLaunchKernelGGL(k_shard_save, dim3((unsigned)((R * (d + 1) + tpb - 1) / tpb)), dim3(tpb), 0, st, s0->d_theta, s0->d_lp,
+                                   R, s0->T, d, sidx, sample_cap, d_samples, d_slp);
+        };
+        if (nblocks == 1) {
+            save();
+            continue;
+        }
         const int parity = (int)(iter & 1ull);
         // boundary k sits between block k and block k + 1; active when k has the iteration's parity.  A block has at
         // most one active boundary per iteration, so one send and one receive buffer per block are enough.
@@ -277,7 +307,10 @@ int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, c
             if (gb + 1 < nblocks && (gb & 1) == parity) sides.push_back({i, cs[i]->pt->T - 1, 1, (gb + 1) / nlocal, gb});
             if (gb > 0 && ((gb - 1) & 1) == parity) sides.push_back({i, 0, 0, (gb - 1) / nlocal, gb - 1});
         }
-        if (sides.empty()) continue;
+        if (sides.empty()) {
+            save();
+            continue;
+        }
         for (const Side& sd : sides) {
             PtState* s = cs[sd.local]->pt;
             hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((nbuf + tpb - 1) / tpb)), dim3(tpb), 0, st, s->d_theta, s->d_lp, R,
@@ -316,6 +349,7 @@ int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, c
                                (unsigned)(s->seed >> 32), iter, s->T_global, s->replica0, hot_slot, s->d_bnd_swaps);
             s->bnd_proposed += (unsigned long long)R;
         }
+        save();
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_shard_swap");
     }
@@ -331,6 +365,49 @@ int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, c
         }
     }
     return CARMA_OK;
+}
+
+extern "C" {
+
+int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, carma_comm* comm)
+{
+    return iterate_sharded(shards, nlocal, niter, comm, 0, 0, nullptr, nullptr);
+}
+
+int carma_pt_sample_sharded(carma_ctx* const* shards, int nlocal, int nsamples, int thin, carma_comm* comm, double* samples,
+                            double* logposts)
+{
+    if (!shards || nlocal < 1 || nsamples < 1 || thin < 1 || !shards[0] || !reinterpret_cast<Ctx*>(shards[0])->pt) {
+        set_error("carma_pt_sample_sharded: bad argument");
+        return CARMA_EINVAL;
+    }
+    Ctx* c0 = reinterpret_cast<Ctx*>(shards[0]);
+    const bool owner = c0->pt->slot0 == 0;            // this process holds temperature 0: it collects the samples
+    if (owner && (!samples || !logposts)) {
+        set_error("carma_pt_sample_sharded: the process that owns temperature 0 must pass sample buffers");
+        return CARMA_EINVAL;
+    }
+    double *d_s = nullptr, *d_l = nullptr;
+    const size_t R = (size_t)c0->pt->R, d = (size_t)c0->d;
+    if (owner) {
+        hipError_t e = hipSetDevice(c0->device);
+        if (e == hipSuccess) e = hipMalloc(&d_s, sizeof(double) * R * nsamples * d);
+        if (e == hipSuccess) e = hipMalloc(&d_l, sizeof(double) * R * nsamples);
+        if (e != hipSuccess) {
+            if (d_s) (void)hipFree(d_s);
+            return hip_fail(e, "carma_pt_sample_sharded: sample buffers");
+        }
+    }
+    int rc = iterate_sharded(shards, nlocal, (long)nsamples * thin, comm, thin, nsamples, d_s, d_l);
+    if (owner) {
+        hipError_t e = hipSuccess;
+        if (rc == CARMA_OK) e = hipMemcpy(samples, d_s, sizeof(double) * R * nsamples * d, hipMemcpyDeviceToHost);
+        if (rc == CARMA_OK && e == hipSuccess) e = hipMemcpy(logposts, d_l, sizeof(double) * R * nsamples, hipMemcpyDeviceToHost);
+        (void)hipFree(d_s);
+        (void)hipFree(d_l);
+        if (e != hipSuccess) rc = hip_fail(e, "carma_pt_sample_sharded: D2H");
+    }
+    return rc;
 }
 
 int carma_pt_boundary_stats(carma_ctx* h, unsigned long long* proposed, unsigned long long* accepted)

@@ -204,6 +204,11 @@ void carma_comm_destroy(carma_comm* comm);
 int carma_comm_rank(const carma_comm* comm);
 int carma_comm_size(const carma_comm* comm);
 int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, carma_comm* comm);
+/* nsamples x thin more iterations; after every thin-th (and its boundary swaps) the coldest chain of every replica is
+ * saved (Sampler::SaveValues, src/samplers.cpp:118-124).  Collective like carma_pt_iterate_sharded; the process that
+ * owns temperature 0 receives samples = [R][nsamples][d], logposts = [R][nsamples] (host), the others pass NULL. */
+int carma_pt_sample_sharded(carma_ctx* const* shards, int nlocal, int nsamples, int thin, carma_comm* comm,
+                            double* samples, double* logposts);
 /* boundary swaps this block took part in: proposed = R per active boundary and iteration; accepted */
 int carma_pt_boundary_stats(carma_ctx* h, unsigned long long* proposed, unsigned long long* accepted);
 

@@ -49,3 +49,17 @@ def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=1
     assert rel.max() <= rtol, "%s: max rel err %.3e at %d (got %r want %r)" % (
         what, rel.max(), idx[rel.argmax()], got[fin][rel.argmax()], want[fin][rel.argmax()])
     return float(rel.max())
+
+
+def queue_get(q, procs, timeout=600.0):
+    """q.get() that notices a dead worker at once instead of after the whole time-out."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2.0)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if not p.is_alive() and p.exitcode not in (0, None)]
+            assert not dead, "worker process exited with code %r" % dead
+            assert time.time() - t0 < timeout, "worker timed out"

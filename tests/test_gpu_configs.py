@@ -151,7 +151,8 @@ def test_config3_ladder_sharded_over_rccl():
         q = ctx.Queue()
         p = ctx.Process(target=_sharded_worker, args=(q, blocks, 8, R, it, 91))
         p.start()
-        out = q.get(timeout=900)
+        from helpers import queue_get
+        out = queue_get(q, [p], 900)
         p.join(120)
         assert p.exitcode == 0
         dt = out.pop()

@@ -71,7 +71,8 @@ def _run(resident):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, resident)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    from helpers import queue_get
+    res = sorted((queue_get(q, procs, 300) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -102,7 +103,7 @@ def test_ladder_sharded_over_two_ranks():
         assert a[1] == b[1] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
 
 
-def _native_worker(q, nblocks_T, rccl):
+def _native_worker(q, nblocks_T, rccl, nsample=0):
     """One process owning the whole ladder as consecutive blocks; boundaries go through carma_pt_iterate_sharded."""
     import carma_pack_amd as cpa
     from carma_pack_amd import _lib, parallel as par
@@ -119,22 +120,24 @@ def _native_worker(q, nblocks_T, rccl):
         slot0 += Tl
     _lib.pt_iterate_sharded(ctxs, NITER // 2, comm)
     _lib.pt_iterate_sharded(ctxs, NITER - NITER // 2, comm)        # resumable: two calls == one
+    samples = _lib.pt_sample_sharded(ctxs, nsample, 3, comm) if nsample else None
     out = []
     for c in ctxs:
         th, lp = c.pt_get_chains()
         out.append((th, lp, c.pt_boundary_stats(), c.pt_iterations_done()))
-    q.put(out)
+    q.put(out + ([samples] if nsample else []))
     if comm is not None:
         comm.close()
 
 
-def _run_native(nblocks_T, rccl=True):
+def _run_native(nblocks_T, rccl=True, nsample=0):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_native_worker, args=(q, nblocks_T, rccl))
+    p = ctx.Process(target=_native_worker, args=(q, nblocks_T, rccl, nsample))
     p.start()
-    out = q.get(timeout=300)
+    from helpers import queue_get
+    out = queue_get(q, [p], 300)
     p.join(120)
     assert p.exitcode == 0
     return out
@@ -171,3 +174,25 @@ def test_native_rccl_exchange_walks_the_same_trajectory():
     assert all(0 < a < p_ for a, p_ in zip(acc, prop))
     # boundary k is counted once by either side: blocks 0 and 4 see one boundary, the inner blocks two
     assert acc[0] + acc[2] + acc[4] == acc[1] + acc[3]
+
+
+def test_sharded_ladder_saves_the_coldest_chain():
+    """carma_pt_sample_sharded: the sharded ladder as a complete sampler -- after every thin-th iteration AND its
+    boundary swaps the coldest chain of every replica is saved (Sampler::SaveValues, samplers.cpp:118-124): the last
+    sample is the final chain state, every stored log-posterior is the oracle's LogDensity of its sample, and with one
+    temperature per block (where the coldest chain IS a boundary chain) the samples are not all the same point."""
+    import oracle as orc
+    from helpers import assert_parity, loglik_truth
+    t, y, e = _series()
+    m = orc.OracleModel(t, y, e, P, Q, max_stdev=10.0 * y.std())
+    for blocks in ([3, 2], [1, 1, 1, 1, 1]):
+        out = _run_native(blocks, nsample=7)
+        samples, slp = out.pop()
+        assert samples.shape == (R, 7, 3 + P + Q) and slp.shape == (R, 7)
+        (th0, lp0, _, it0) = out[0]
+        assert it0 == NITER + 21
+        assert np.array_equal(samples[:, -1, :], th0[:, 0, :]) and np.array_equal(slp[:, -1], lp0[:, 0])
+        flat = samples.reshape(-1, 3 + P + Q)
+        assert_parity(slp.reshape(-1), m.logdensity_batch(flat), 1e-10, "sharded samples %s" % blocks,
+                      arbiter=lambda i: loglik_truth(t, y, e, flat[i], P, Q)[0])
+        assert np.unique(flat[:, 0]).size > R                     # the chains moved between saves
