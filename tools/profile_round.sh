@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --no-cpu > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --no-cpu --no-pipelined > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o $TAG -- python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu --no-mcmc --no-pipelined --no-throughput --no-ladder > $OUT/pmc_$c.log 2>&1
