@@ -96,6 +96,7 @@ def _load():
     L.carma_predict_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, C.c_int,
                                       _dp, _dp, C.c_int]
     L.carma_predict_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp, C.c_int]
+    L.carma_normalize_roots.argtypes = [C.c_int, _dp, _dp]
     L.carma_kf_create_carma.restype = C.c_void_p
     L.carma_kf_create_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, C.c_int]
     L.carma_kf_create_car1.restype = C.c_void_p
@@ -140,7 +141,7 @@ EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
     "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_kfilter_carma",
-    "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_kf_create_carma", "carma_kf_create_car1",
+    "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_normalize_roots", "carma_kf_create_carma", "carma_kf_create_car1",
     "carma_kf_destroy", "carma_kf_n", "carma_kf_filter", "carma_kf_predict", "carma_simulate_carma", "carma_simulate_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
@@ -509,3 +510,15 @@ def pt_sample_sharded(contexts, nsamples, thin=1, comm=None):
                                       ptr(samples) if owner else None, ptr(logposts) if owner else None),
           "carma_pt_sample_sharded")
     return samples, logposts
+
+
+def normalize_roots(omega):
+    """AR roots in any order -> conjugate pairs adjacent (negative imaginary part first), real roots last
+    (carma_normalize_roots; host arithmetic, no device needed).  ValueError when the set is not closed under conjugation."""
+    omega = np.asarray(omega, dtype=complex)
+    om = as_f64(np.c_[omega.real, omega.imag])
+    out = np.empty_like(om)
+    rc = lib.carma_normalize_roots(omega.size, ptr(om), ptr(out))
+    if rc != CARMA_OK:
+        raise ValueError("the AR roots must be real or come in complex-conjugate pairs")
+    return out[:, 0] + 1j * out[:, 1]

@@ -329,6 +329,12 @@ int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len)
     return logdens_kernel_name(c->p, B, c->n, buf, len) > 0 ? CARMA_OK : CARMA_EINVAL;
 }
 
+int carma_normalize_roots(int p, const double* omega_re_im, double* out)
+{
+    if (p < 1 || p > CARMA_PMAX || !omega_re_im || !out) return CARMA_EINVAL;
+    return normalize_roots(p, omega_re_im, out);
+}
+
 double carma_logprior(const carma_ctx* h, const double* theta)
 {
     if (!h || !theta) return std::numeric_limits<double>::quiet_NaN();

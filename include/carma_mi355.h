@@ -114,6 +114,12 @@ int carma_predict_carma(const double* time, const double* y, const double* yerr,
 int carma_predict_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr,
                        double omega, const double* tpred, int M, double* pmean, double* pvar, int device);
 
+/* The order in which the KalmanFilterp-type entry points want the AR roots -- conjugate pairs adjacent (negative
+ * imaginary part first), then the real roots: what CARp::ARRoots emits (src/carpack.cpp:137-172) -- from roots in any
+ * order.  They do this themselves; exported for callers that keep per-root quantities aligned.  Host arithmetic.
+ * CARMA_EINVAL when the set is not closed under conjugation (to 1e-12).  out = p (re, im) pairs. */
+int carma_normalize_roots(int p, const double* omega_re_im, double* out);
+
 /*
  * The same as OBJECTS, as the reference has them (KalmanFilter1 / KalmanFilterp, kfilter.hpp:211-334; wrapper :83-101):
  * carma_kf_create_* copies, sorts and deduplicates the series and uploads it with the model ONCE; Filter and any number

@@ -180,3 +180,26 @@ def test_car1_sample_psd_and_kalman_filter(golden_dir):
     if cpa._lib.lib.carma_device_count() == 0:
         with pytest.raises(cpa._lib.CarmaDeviceError):
             s.predict(t[-1] + 5.0)
+
+
+def test_root_order_normalisation():
+    """carma_normalize_roots (host arithmetic of the KalmanFilterp-type entry points): any order in, ARRoots order out."""
+    from carma_pack_amd import _lib
+    rng = np.random.default_rng(3)
+    roots = np.array([-0.3 + 0.7j, -0.05 + 0j, -0.3 - 0.7j, -1.2 - 0.1j, -2.0 + 0j, -1.2 + 0.1j, -0.9 + 0j])
+    for _ in range(5):
+        out = _lib.normalize_roots(roots[rng.permutation(7)])
+        assert sorted(out, key=lambda z: (z.real, z.imag)) == sorted(roots, key=lambda z: (z.real, z.imag))
+        assert np.all(out[0:4:2].imag < 0) and np.array_equal(out[1:4:2], np.conj(out[0:4:2])) and np.all(out[4:].imag == 0)
+    # get_ar_roots puts a real root wherever its centroid is zero (carma_pack.py:1038-1059)
+    mixed = cm.get_ar_roots(np.array([0.01, 0.02, 0.005]), np.array([0.2, 0.0, 0.03]))
+    out = _lib.normalize_roots(mixed)
+    assert out.size == 5 and out[4].imag == 0 and out[0].imag < 0 < out[1].imag
+    # a conjugate that is off by one ulp is still its conjugate; a lone complex root is not a real-valued process
+    r = -0.123456789 + 0.987654321j
+    out = _lib.normalize_roots([r, complex(np.nextafter(r.real, 0.0), -r.imag)])
+    assert out[1] == np.conj(out[0])
+    with pytest.raises(ValueError):
+        _lib.normalize_roots([-0.1 + 0.3j, -0.2 + 0j])
+    with pytest.raises(ValueError):
+        _lib.normalize_roots([-0.1 + 0.3j, -0.1 - 0.31j])
