@@ -198,10 +198,17 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
         // wins while a CU holds at most one ladder (12.3k vs 8.0k it/s at 16 x 256) and loses once the ladders queue up
         // for the SIMDs (3.1k vs 4.0k it/s at 16 x 1024, tools/mcmc_bigR_probe.py; the plain chain waves share the
         // exp/sincos inside root pairs, RhoPair).  CARMA_PT_PLAIN=0/1 overrides.
-        int dev = 0, ncu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        static const int ncu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n;
+        }();
         bool plain = L.R > (long)ncu;
-        if (const char* fp = getenv("CARMA_PT_PLAIN")) plain = fp[0] == '1';
+        static const int force_plain = [] {                 // CARMA_PT_PLAIN=0/1, read once
+            const char* fp = getenv("CARMA_PT_PLAIN");
+            return fp ? (fp[0] == '1' ? 1 : 0) : -1;
+        }();
+        if (force_plain >= 0) plain = force_plain == 1;
         if (pc && L.n >= 32 && !plain) {
             if (nthr <= 256)
                 return launch_pt_k<P, G, 256, true>(L, nthr, lds, series, pr, temps, theta, logpost, chol, naccept, nswap,

@@ -68,7 +68,13 @@ static double sample_var(const std::vector<double>& y)   // arma::var
 
 static int chunk_iters(const Ctx* c)
 {
-    // keep one launch around a quarter of a second: ~0.8 us per datum per iteration for p >= 5
+    // Iterations per launch.  Ladder kernel: around a quarter of a second (~0.8 us per datum per iteration for p >= 5).
+    // Row kernel: ~0.14 us per datum per iteration, and its COOPERATIVE launch costs ~2 ms on this stack -- 4.5 % of a
+    // 44 ms chunk (measured) -- so its chunks are sized for half a second.
+    if (c->pt && c->pt->use_row) {
+        const double est_us = std::max(1.0, 0.14 * c->n);
+        return (int)std::max(1.0, std::min(16384.0, 500000.0 / est_us));
+    }
     const double est_us = std::max(1.0, 0.8 * c->n * (c->p >= 5 ? 1.0 : 0.5));
     return (int)std::max(1.0, std::min(4096.0, 250000.0 / est_us));
 }
