@@ -92,10 +92,20 @@ __global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* 
 template <int P>
 __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restrict__ theta, int B, int d, int q,
                                                            const double4* __restrict__ series, int n, Prior pr,
-                                                           int ignore_prior, double* __restrict__ out)
+                                                           int ignore_prior, double* __restrict__ out, int ncu)
 {
     extern __shared__ double4 smem4[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane64 = tid & 63;
+    const int tid = threadIdx.x, lane64 = tid & 63;
+    // Which wave plays which part.  Workgroups i, i + ncu, i + 2 ncu share a CU, and the waves of successive workgroups
+    // of a CU land on SIMDs (s, s+2, s+1, s+3), (s+2, s+1, s+3, s), (s+1, s+3, s, s+2) (tools/ubench/wave_placement.hip).
+    // With the same assignment everywhere the second workgroup's covariance wave -- the critical one -- would share
+    // its SIMD with the first one's mean wave; rotated, each covariance and each mean wave gets a producer for company.
+    //                 part of wave:  0  1  2  3      (0 covariance, 1 mean, 2 / 3 producers)
+    //   first  workgroup of a CU     0  1  2  3
+    //   second                       2  0  1  3
+    //   third                        2  1  3  0
+    const int round = (blockIdx.x >= (unsigned)ncu) + (blockIdx.x >= 2u * (unsigned)ncu);
+    const int wave = ((round == 0 ? 0xE4 : round == 1 ? 0xD2 : 0x36) >> (2 * (tid >> 6))) & 3;
     Grp<16> g{nullptr, lane64, nullptr};
     Cx* ring = reinterpret_cast<Cx*>(smem4);
     long e = ((long)blockIdx.x * 64 + lane64) / 16;
@@ -241,6 +251,17 @@ __global__ __launch_bounds__(64) void k_simulate_car1(double sigsqr, double omeg
 // ---------------------------------------------------------------------------------------------
 // Largest launch (in workgroups of four evaluations) that takes the wave pipeline of carma_pipe3l.h: three workgroups
 // per CU (measured, tools/tput_probe.py).  CARMA_TUNE_P3L_ROWS overrides it for such measurements; read once.
+static int device_cus()
+{
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    return v;
+}
+
 static long p3l_max_rows()
 {
     static const long v = [] {
@@ -289,7 +310,7 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             // covariance wave + mean wave + two producer waves per four evaluations, co-rotating frame
             // (carma_pipe3l.h); 42 KiB of LDS: up to three workgroups per CU
             hipLaunchKernelGGL((k_logdens_carma_p3l<P>), dim3((unsigned)rows), dim3(256), Pipe3LGeom<P>::BYTES, st, theta, B, d, q,
-                               series, n, pr, ignore_prior, out);
+                               series, n, pr, ignore_prior, out, device_cus());
             return hipGetLastError();
         case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);
         case LdShape::PC2: return launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);

@@ -105,11 +105,17 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
 {
     using Geo = Pipe3LGeom<P>;
     constexpr int C = Geo::C;
-    constexpr int PPL = 16 / P;
+    // a lane works on a conjugate PAIR of roots (2 pr, 2 pr + 1): both share |E|, cos and sin, so one exp/sincos
+    // evaluation serves two ring entries; an odd order's last lane holds the single real root
+    constexpr int NPAIR = (P + 1) / 2, PPL = 16 / NPAIR;
     const int lane = g.lane64, l = lane & 15;
-    const int sub = l / P, jr = l - sub * P;
-    const bool worker = sub < PPL;
+    const int sub = l / NPAIR, jr = 2 * (l - sub * NPAIR);
+    const bool worker = sub < PPL, two = jr + 1 < P;
     const Cx w = own_ar_root<P>(theta, jr);
+    // a quadratic factor with positive discriminant puts two different REAL roots into the pair: the second one then
+    // gets its own exponential (no sine / cosine either way)
+    const Cx w1 = two ? own_ar_root<P>(theta, jr + 1) : w;
+    const bool realpair = two && w.im == 0.0;
     const int nc = (n + C - 1) / C;
     if (pw == 0 && l >= P) {                                  // entries of the idle lanes: exact zeros
 #pragma unroll 4
@@ -118,7 +124,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     // grid of this evaluation's re-base schedule: cells of width 2^-ex <= min over its roots of (LIM_RE / |Re omega|,
     // LIM_IM / |Im omega|).  Dyadic widths nest, so the re-base data of the evaluation with the finest grid contain
     // those of the other three evaluations of the workgroup and the waves branch on that one mask.
-    double wl = fmax(fabs(w.re) * (1.0 / Geo::LIM_RE), fabs(w.im) * (1.0 / Geo::LIM_IM));
+    double wl = fmax(fmax(fabs(w.re), fabs(w1.re)) * (1.0 / Geo::LIM_RE), fabs(w.im) * (1.0 / Geo::LIM_IM));
     wl = (wl < 1e12) ? wl : ((wl == wl && wl < 1.0 / 0.0) ? 1e12 : 0.0);
     wl = Grp<16>::max(wl);
     int wex;
@@ -131,7 +137,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     double t_last = carry;                                   // time of the datum before this chunk
     double2 hc_own = make_double2(0.0, 0.0), hc_par = make_double2(0.0, 0.0);
     constexpr int NIT = (C + 2 * PPL - 1) / (2 * PPL);        // exp/sincos evaluations per lane and chunk
-    double ec0[NIT], es0[NIT];                                // chunk 0: evaluated while the other waves set the model up
+    double ec0[NIT], es0[NIT], e10[NIT];                              // chunk 0: evaluated while the other waves set the model up
     for (int c = 0; c < nc; c++) {
         const int j0 = c * C;
         // --- schedule of this chunk: lane s (of every row) looks at datum j0 + s
@@ -152,39 +158,51 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
         if (pw == 0 && lane == 0) reinterpret_cast<unsigned long long*>(ring + Geo::FLAG_OFF)[c % 3] = fmask;
         Cx* buf = ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT + Geo::row_base(lane) + jr;
         auto slot_of = [&](int it) { return it * 2 * PPL + pw * PPL + sub; };
-        auto rotation = [&](int it, double& ec, double& es) {            // accumulated (E cos, E sin) of the lane's slot
+        auto rotation = [&](int it, double& ec, double& es, double& e1) {   // accumulated (E cos, E sin) of the lane's slot
             const int slot = slot_of(it);
             const double dta = __shfl(dta_l, (lane & ~15) + (slot < C ? slot : C - 1), 64);
             ec = 1.0;
             es = 0.0;
             if (worker && slot < C && j0 + slot < n) cexp_step(w.re, w.im, dta, &ec, &es);
+            e1 = ec;                                          // the partner: same modulus ...
+            if (realpair && worker && slot < C && j0 + slot < n) {
+                double z;
+                cexp_step(w1.re, 0.0, dta, &e1, &z);          // ... unless it is another real root
+            }
         };
-        auto entry = [&](int it, double ec, double es) {
+        auto entry = [&](int it, double ec, double es, double e1) {
             const int slot = slot_of(it);
             const bool flag = __shfl((int)fl, (lane & ~15) + (slot < C ? slot : C - 1), 64) != 0;
             if (worker && slot < C && j0 + slot < n) {
                 // h~_r = (A^T h)_r = E (cos h_r + sin h_partner) ;  c~_r = (A^-1 c)_r = (cos c_r + sin c_partner) / E
+                // (the partner root is the conjugate: same cos, sin of the opposite sign)
                 const double inv = recip(fma(ec, ec, es * es));
                 const double ht = fma(ec, hc_own.x, es * hc_par.x);
                 const double ct = fma(ec, hc_own.y, es * hc_par.y) * inv;
                 buf[(size_t)slot * Geo::SLOT] = flag ? Cx{ec, es} : Cx{ht, ct};
+                if (two) {
+                    const double inv1 = realpair ? recip(e1 * e1) : inv;
+                    const double hp = fma(e1, hc_par.x, -es * hc_own.x);
+                    const double cp = fma(e1, hc_par.y, -es * hc_own.y) * inv1;
+                    buf[(size_t)slot * Geo::SLOT + 1] = flag ? Cx{e1, -es} : Cx{hp, cp};
+                }
             }
         };
         if (c == 0) {
 #pragma unroll
-            for (int it = 0; it < NIT; it++) rotation(it, ec0[it], es0[it]);
+            for (int it = 0; it < NIT; it++) rotation(it, ec0[it], es0[it], e10[it]);
             __syncthreads();                                  // the covariance wave has published (h_r, c_r)
             const double2* cst = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF) + Geo::row_base(lane);
             hc_own = cst[jr];
-            hc_par = cst[jr ^ 1];
+            hc_par = cst[jr + 1];
 #pragma unroll
-            for (int it = 0; it < NIT; it++) entry(it, ec0[it], es0[it]);
+            for (int it = 0; it < NIT; it++) entry(it, ec0[it], es0[it], e10[it]);
         } else {
 #pragma unroll 1
             for (int it = 0; it < NIT; it++) {
-                double ec, es;
-                rotation(it, ec, es);
-                entry(it, ec, es);
+                double ec, es, e1;
+                rotation(it, ec, es, e1);
+                entry(it, ec, es, e1);
             }
         }
         __syncthreads();                                      // barrier c: chunk c is in the ring

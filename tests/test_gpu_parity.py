@@ -500,6 +500,41 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
         assert v == res["mixed"][key] or (np.isnan(v) and np.isnan(res["mixed"][key]))
 
 
+@pytest.mark.parametrize("p,q", [(2, 0), (4, 1), (5, 3), (6, 0), (7, 2)])
+def test_wave_pipeline_real_pairs(cpa, p, q):
+    """The wave pipeline's producer lanes evaluate ONE exp/sincos per root pair; a quadratic factor with two real roots
+    is the pair whose members do not share a modulus and gets a second exponential.  Real-pair thetas alone, next to
+    complex-pair ones in the same workgroup (the re-base grid of a workgroup is the finest of its four evaluations),
+    and alone in a launch: same value every time, parity with the oracle."""
+    from helpers import loglik_truth
+    t, y, yerr = irregular_series(150, seed=170 + p)
+    rng = np.random.default_rng(1700 + 10 * p + q)
+    cplx = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(32)])
+    real = cplx.copy()
+    for f in range(p // 2 if p < 6 else 1):                      # p < 6: every factor real; beyond, one (conditioning)
+        r1 = 10.0 ** rng.uniform(-2.0, -0.5, 32) * 3.0 ** f
+        r2 = r1 * rng.uniform(3.0, 20.0, 32)
+        real[:, 3 + 2 * f] = np.log(r1 * r2)
+        real[:, 4 + 2 * f] = np.log(r1 + r2)
+    ctx = cpa.Context(t, y, yerr, p, q)
+    assert ctx.kernel_name(64).startswith("k_logdens_carma_p3l")
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    mixed = np.concatenate([cplx, real])[rng.permutation(64)]
+    got_r, got_m = ctx.logdensity(real, ignore_prior=True), ctx.logdensity(mixed, ignore_prior=True)
+    assert_parity(got_r, m.logdensity_batch(real, ignore_prior=True), RTOL, "real pairs p=%d q=%d" % (p, q),
+                  arbiter=lambda i: loglik_truth(t, y, yerr, real[i], p, q)[0])
+    assert_parity(got_m, m.logdensity_batch(mixed, ignore_prior=True), RTOL, "mixed p=%d q=%d" % (p, q),
+                  arbiter=lambda i: loglik_truth(t, y, yerr, mixed[i], p, q)[0])
+    assert np.isfinite(got_r).sum() >= 24
+    alone = dict(zip(map(bytes, real), got_r))
+    for th, v in zip(mixed, got_m):
+        w = alone.get(bytes(th))
+        if w is not None:                                        # another grid of re-base points: rounding-level differences
+            assert v == w or abs(v - w) <= 1e-11 * abs(w) or (np.isnan(v) and np.isnan(w)), (v, w)
+    for i in (0, 9):
+        assert np.array_equal(ctx.logdensity(real[i:i + 1], ignore_prior=True), got_r[i:i + 1], equal_nan=True)
+
+
 @pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
 def test_prior_like_sweep_never_worse_than_reference(cpa, p):
     """Every order (p, q < p) x 200 random PRIOR-LIKE parameter vectors -- the nastiest inputs the sampler can meet:
