@@ -117,7 +117,11 @@ static inline SinCos sincos_slow(double x)
 // rho = exp((a + i b) dt) -> (re, im).  The four polynomial chains (even/odd halves of the exp
 // polynomial, sin, cos) are advanced in lock-step so that a single in-order wave always has
 // independent FMAs to issue between the members of each dependent chain.
-CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im)
+// EXACT: the rounding of the products a dt and b dt (relative 2^-53: 3e-14 rad at a phase of 256 rad, 1e-11 at 1e5 rad) is
+// recovered with an FMA and added back after the argument reduction, so the accuracy no longer degrades with |b dt|.
+// dt_lo: the part of the time difference its double does not hold (two-difference of the two times), EXACT only.
+template <bool EXACT = false>
+CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im, double dt_lo = 0.0)
 {
     const double x = a * dt;
     const double ph = b * dt;
@@ -125,6 +129,12 @@ CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im)
         // rare: library reduction for huge phases (NaN also lands here)
         const double e = exp_neg(x);
         SinCos sc = sincos_slow(ph);
+        if constexpr (EXACT) {
+            const double pl = fma3(b, dt_lo, fma3(b, dt, -ph));
+            const double c0 = sc.c, s0 = sc.s;
+            sc.c = fma3(-s0, pl, c0);
+            sc.s = fma3(c0, pl, s0);
+        }
         *re = e * sc.c;
         *im = e * sc.s;
         return;
@@ -138,6 +148,10 @@ CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im)
     t = fma3(-n2, 6.07710050630396597660e-11, t);
     t = fma3(-n2, 2.02226624871116645580e-21, t);
     t = fma3(-n2, 8.47842766036889956997e-32, t);
+    if constexpr (EXACT) {
+        r += fma3(a, dt_lo, fma3(a, dt, -x));
+        t += fma3(b, dt_lo, fma3(b, dt, -ph));
+    }
     const double r2 = r * r;
     const double z = t * t;
     // --- exp(r) = E(r^2) + r O(r^2) (Taylor to r^13), sin(t) = t + t^3 S(z), cos(t) = 1 + z C(z)

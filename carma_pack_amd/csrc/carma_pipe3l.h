@@ -75,8 +75,10 @@ struct Pipe3LGeom {
     static constexpr double LIM_RE = 200.0;                     // |Re omega| dt_acc: scale factors within e^+-200; S carries their
                                                                 // squares (5e173 at most: room for any variance below 1e130;
                                                                 // 100 instead of 200 costs 3 % per step in extra re-bases)
-    static constexpr double LIM_IM = 256.0;                     // |Im omega| dt_acc: the phase product rounds to 3e-14 rad at most,
-                                                                // what the stepwise products accumulate over such a window anyway
+    static constexpr double LIM_IM = 262144.0;                  // |Im omega| dt_acc: the producers recover the rounding of the phase
+                                                                // product (cexp_step<true>), so the window is set by the decay of
+                                                                // the scale factors alone unless Q = |Im|/|Re| exceeds 1300; the
+                                                                // limit keeps the phase inside the fast argument reduction (2^20)
     static_assert(P < ROWW, "one row of entries per evaluation");
     // entry of a lane inside a [SLOT] array
     static __device__ __forceinline__ int entry(int lane)
@@ -152,7 +154,10 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
         M = fmax(M, dpp_mov_old<0x114>(ninf, M));             // row_shr:4
         M = fmax(M, dpp_mov_old<0x118>(ninf, M));             // row_shr:8
         const double Mx = dpp_mov_old<0x111>(ninf, M);        // exclusive
-        const double dta_l = tj - fmax(carry, Mx);            // time since the base this datum is expressed in
+        const double tb = fmax(carry, Mx);
+        const double dta_l = tj - tb;                         // time since the base this datum is expressed in ...
+        const double dvv = dta_l - tj;                        // ... and what the double leaves of the exact difference
+        const double dtl_l = (tj - (dta_l - dvv)) - (tb + dvv);
         carry = fmax(carry, __shfl(M, (lane & ~15) + 15, 64));
         const unsigned long long fmask = __ballot(fl && j0 + l < n);      // bit 16 row + s: datum j0 + s of that row's evaluation
         if (pw == 0 && lane == 0) reinterpret_cast<unsigned long long*>(ring + Geo::FLAG_OFF)[c % 3] = fmask;
@@ -161,13 +166,14 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
         auto rotation = [&](int it, double& ec, double& es, double& e1) {   // accumulated (E cos, E sin) of the lane's slot
             const int slot = slot_of(it);
             const double dta = __shfl(dta_l, (lane & ~15) + (slot < C ? slot : C - 1), 64);
+            const double dtl = __shfl(dtl_l, (lane & ~15) + (slot < C ? slot : C - 1), 64);
             ec = 1.0;
             es = 0.0;
-            if (worker && slot < C && j0 + slot < n) cexp_step(w.re, w.im, dta, &ec, &es);
+            if (worker && slot < C && j0 + slot < n) cexp_step<true>(w.re, w.im, dta, &ec, &es, dtl);
             e1 = ec;                                          // the partner: same modulus ...
             if (realpair && worker && slot < C && j0 + slot < n) {
                 double z;
-                cexp_step(w1.re, 0.0, dta, &e1, &z);          // ... unless it is another real root
+                cexp_step<true>(w1.re, 0.0, dta, &e1, &z, dtl);         // ... unless it is another real root
             }
         };
         auto entry = [&](int it, double ec, double es, double e1) {

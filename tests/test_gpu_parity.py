@@ -393,7 +393,12 @@ def test_edge_cases_nan_inf_tiny_series(cpa, readme):
         # where the oracle is finite the GPU agrees; where it is not, the GPU is not finite either
         fin = np.isfinite(want)
         assert np.all(~np.isfinite(got[~fin]))
-        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9)
+        # case 4 is ill-conditioned by construction (a phase of 1e13 rad per time unit: the oracle's own stepwise
+        # products are good to 1e-3 rad): there the quad-precision evaluation arbitrates, factor 1.0
+        idx = np.flatnonzero(fin)
+        from helpers import loglik_truth
+        assert_parity(got[fin], want[fin], 1e-9, "edge cases",
+                      arbiter=lambda i: loglik_truth(t, y, yerr, cases[idx[i]], 5, 3)[0])
     # two-point series and a series that dedups down to two points
     c2 = cpa.Context(t[:2], y[:2], yerr[:2], 2, 1, max_stdev=10.0)
     m2 = orc.OracleModel(t[:2], y[:2], yerr[:2], 2, 1, max_stdev=10.0)
