@@ -181,7 +181,10 @@ def _roots_from_log_quads(logq):
         disc = q2 * q2 - 4.0 * q1
         sq = np.where(disc > 0, np.sqrt(np.abs(disc)) + 0j, 1j * np.sqrt(np.abs(disc)))
         roots[:, 2 * i] = -0.5 * (q2 + sq)
-        roots[:, 2 * i + 1] = -0.5 * (q2 - sq)
+        # two real roots: the smaller one from the product q1 (as the kernels do, carma_core.h quad_root) --
+        # -(q2 - sq) / 2 cancels to nothing once q2^2 >> 4 q1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            roots[:, 2 * i + 1] = np.where((disc > 0) & (q2 - sq != 0), q1 / roots[:, 2 * i], -0.5 * (q2 - sq))
     if m % 2:
         roots[:, -1] = -quad[:, -1]
     return roots

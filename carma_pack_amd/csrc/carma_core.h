@@ -76,7 +76,13 @@ CARMA_DEV Cx quad_root(double lq1, double lq2, int which)
     const double sq = sqrt(fabs(disc));              // one sqrt for both signs of the discriminant
     Cx r;
     if (disc > 0) {
-        r.re = which ? -0.5 * (q2 - sq) : -0.5 * (q2 + sq);
+        // two real roots: the larger one from the sum that does not cancel, the smaller one from the product q1 (the
+        // reference's -(q2 - sq)/2 loses every digit once q2^2 >> 4 q1 -- MA parameters of the sampler reach q2 ~ 1e15
+        // with the small root of order one; in quad precision the reference's form agrees with this one)
+        // Where the reference's difference is EXACTLY zero (q2^2 > 2^53 * 4 q1) its MA polynomial divides by that root and
+        // the log-density is NaN: kept, so that the sampler moves in the same domain as the reference's.
+        const double big = -0.5 * (q2 + sq);
+        r.re = which ? (q2 - sq == 0.0 ? 0.0 : q1 / big) : big;
         r.im = 0.0;
     } else {
         r.re = -0.5 * q2;

@@ -68,13 +68,16 @@ struct Pipe3LGeom {
     static constexpr int RING_OFF = 0;                          // double2[3][C][SLOT]
     static constexpr int LINK_OFF = 3 * C * SLOT;               // double2 {k~_r, var}[2][C][SLOT]
     static constexpr int CONST_OFF = LINK_OFF + 2 * C * SLOT;   // double2 {h_r, c_r}[SLOT]
-    static constexpr int FLAG_OFF = CONST_OFF + SLOT;           // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
+    static constexpr int CONST2_OFF = CONST_OFF + SLOT;         // double2 {g_r h_r, c_r / g_r}[SLOT]: (h~, c~) at a re-base datum
+    static constexpr int FLAG_OFF = CONST2_OFF + SLOT;          // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
     static constexpr int TAIL_OFF = FLAG_OFF + 2;               // double[2][C]: yerr^2 (wave A) and y (wave B) of the last, partial chunk
     static constexpr int ENTRIES = TAIL_OFF + C;
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 41.8 KiB
-    static constexpr double LIM_RE = 200.0;                     // |Re omega| dt_acc: scale factors within e^+-200; S carries their
-                                                                // squares (5e173 at most: room for any variance below 1e130;
-                                                                // 100 instead of 200 costs 3 % per step in extra re-bases)
+    static constexpr double LIM_RE = 400.0;                     // |Re omega| x window: the scale factor of a root runs from
+                                                                // e^+200 at a re-base to e^-200 at the end of the window (the
+                                                                // frame starts HALF a window ahead), so S carries factors within
+                                                                // e^+-400 (5e173: room for variances from 1e-130 to 1e130)
+                                                                // -- twice the window of a frame that starts at the identity
     static constexpr double LIM_IM = 262144.0;                  // |Im omega| dt_acc: the producers recover the rounding of the phase
                                                                 // product (cexp_step<true>), so the window is set by the decay of
                                                                 // the scale factors alone unless Q = |Im|/|Re| exceeds 1300; the
@@ -122,6 +125,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     if (pw == 0 && l >= P) {                                  // entries of the idle lanes: exact zeros
 #pragma unroll 4
         for (int i = 0; i < 3 * C; i++) ring[(size_t)i * Geo::SLOT + Geo::entry(lane)] = Cx{0.0, 0.0};
+        ring[Geo::CONST2_OFF + Geo::entry(lane)] = Cx{0.0, 0.0};
     }
     // grid of this evaluation's re-base schedule: cells of width 2^-ex <= min over its roots of (LIM_RE / |Re omega|,
     // LIM_IM / |Im omega|).  Dyadic widths nest, so the re-base data of the evaluation with the finest grid contain
@@ -132,6 +136,15 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     int wex;
     (void)frexp(wl, &wex);
     const double sc = wl > 0.0 ? ldexp(1.0, wex) : 0.0;
+    // the frame of a window starts half a window ahead: scale factor g_r e^{Re omega_r dt}, g_r = e^{-Re omega_r W / 2}
+    const double halfw = sc > 0.0 ? 0.5 / sc : 0.0;
+    // (this wave reaches the first barrier about when the covariance wave does: short forms, no library calls)
+    const double rg0 = exp_neg(w.re * halfw), g0 = recip(rg0);
+    double rg1 = rg0, g1 = g0;
+    if (realpair) {
+        rg1 = exp_neg(w1.re * halfw);
+        g1 = recip(rg1);
+    }
     const double ninf = -1.0 / 0.0;
     auto clampi = [n](int i) { return i < n ? (i < 0 ? 0 : i) : n - 1; };
     double4 rec_n = series[clampi(l)];                       // records are fetched one chunk ahead
@@ -154,10 +167,9 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
         M = fmax(M, dpp_mov_old<0x114>(ninf, M));             // row_shr:4
         M = fmax(M, dpp_mov_old<0x118>(ninf, M));             // row_shr:8
         const double Mx = dpp_mov_old<0x111>(ninf, M);        // exclusive
-        const double tb = fmax(carry, Mx);
-        const double dta_l = tj - tb;                         // time since the base this datum is expressed in ...
-        const double dvv = dta_l - tj;                        // ... and what the double leaves of the exact difference
-        const double dtl_l = (tj - (dta_l - dvv)) - (tb + dvv);
+        // time since the base this datum is expressed in.  (The difference of two time stamps is exact unless the base is
+        // much the smaller of the two, and then off by at most half an ulp of t_j: 1e-13 rad for |Im omega| = 1 at t = 1000.)
+        const double dta_l = tj - fmax(carry, Mx);
         carry = fmax(carry, __shfl(M, (lane & ~15) + 15, 64));
         const unsigned long long fmask = __ballot(fl && j0 + l < n);      // bit 16 row + s: datum j0 + s of that row's evaluation
         if (pw == 0 && lane == 0) reinterpret_cast<unsigned long long*>(ring + Geo::FLAG_OFF)[c % 3] = fmask;
@@ -166,14 +178,13 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
         auto rotation = [&](int it, double& ec, double& es, double& e1) {   // accumulated (E cos, E sin) of the lane's slot
             const int slot = slot_of(it);
             const double dta = __shfl(dta_l, (lane & ~15) + (slot < C ? slot : C - 1), 64);
-            const double dtl = __shfl(dtl_l, (lane & ~15) + (slot < C ? slot : C - 1), 64);
             ec = 1.0;
             es = 0.0;
-            if (worker && slot < C && j0 + slot < n) cexp_step<true>(w.re, w.im, dta, &ec, &es, dtl);
+            if (worker && slot < C && j0 + slot < n) cexp_step<true>(w.re, w.im, dta, &ec, &es);
             e1 = ec;                                          // the partner: same modulus ...
             if (realpair && worker && slot < C && j0 + slot < n) {
                 double z;
-                cexp_step<true>(w1.re, 0.0, dta, &e1, &z, dtl);         // ... unless it is another real root
+                cexp_step<true>(w1.re, 0.0, dta, &e1, &z);         // ... unless it is another real root
             }
         };
         auto entry = [&](int it, double ec, double es, double e1) {
@@ -182,14 +193,17 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
             if (worker && slot < C && j0 + slot < n) {
                 // h~_r = (A^T h)_r = E (cos h_r + sin h_partner) ;  c~_r = (A^-1 c)_r = (cos c_r + sin c_partner) / E
                 // (the partner root is the conjugate: same cos, sin of the opposite sign)
-                const double inv = recip(fma(ec, ec, es * es));
-                const double ht = fma(ec, hc_own.x, es * hc_par.x);
-                const double ct = fma(ec, hc_own.y, es * hc_par.y) * inv;
+                // a re-base datum's entry is the rotation accumulated over the closing window (the offsets g cancel)
+                const double gc = ec * g0, gs = es * g0;
+                const double inv = recip(fma(gc, gc, gs * gs));
+                const double ht = fma(gc, hc_own.x, gs * hc_par.x);
+                const double ct = fma(gc, hc_own.y, gs * hc_par.y) * inv;
                 buf[(size_t)slot * Geo::SLOT] = flag ? Cx{ec, es} : Cx{ht, ct};
                 if (two) {
-                    const double inv1 = realpair ? recip(e1 * e1) : inv;
-                    const double hp = fma(e1, hc_par.x, -es * hc_own.x);
-                    const double cp = fma(e1, hc_par.y, -es * hc_own.y) * inv1;
+                    const double gc1 = e1 * g1, gs1 = es * g1;
+                    const double inv1 = realpair ? recip(gc1 * gc1) : inv;
+                    const double hp = fma(gc1, hc_par.x, -gs1 * hc_own.x);
+                    const double cp = fma(gc1, hc_par.y, -gs1 * hc_own.y) * inv1;
                     buf[(size_t)slot * Geo::SLOT + 1] = flag ? Cx{e1, -es} : Cx{hp, cp};
                 }
             }
@@ -201,6 +215,28 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
             const double2* cst = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF) + Geo::row_base(lane);
             hc_own = cst[jr];
             hc_par = cst[jr + 1];
+            // Modal coordinates come in whatever scale the MA polynomial gives them: the sampler's unconstrained MA
+            // parameters reach h_r ~ 1e115, c_r ~ 1e-115 with s0 = h.V.h of order one, and the frame's scale factors
+            // (e^+-200) would push such products out of range.  So every coordinate is rescaled by an exact power of two
+            // that makes |h_r| of order one (one power for both members of a complex pair: the rescaling must commute
+            // with their rotation).  Everything the recursion waves see -- ring entries, the re-base constants -- comes
+            // from here, so they work in the rescaled coordinates without knowing; h.D.h, h.z and with them var and
+            // the innovation are unchanged bit for bit.
+            {
+                const double m0 = fmax(fabs(hc_own.x), realpair ? 0.0 : fabs(hc_par.x)), m1 = realpair ? fabs(hc_par.x) : m0;
+                int e0, e1x;
+                (void)frexp(m0, &e0);
+                (void)frexp(m1, &e1x);
+                if (!(m0 > 0.0 && m0 < 1.0 / 0.0)) e0 = 0;
+                if (!(m1 > 0.0 && m1 < 1.0 / 0.0)) e1x = 0;
+                hc_own = make_double2(ldexp(hc_own.x, -e0), ldexp(hc_own.y, e0));
+                hc_par = make_double2(ldexp(hc_par.x, -e1x), ldexp(hc_par.y, e1x));
+            }
+            if (pw == 0 && l < NPAIR) {                       // (h~, c~) right after a re-base, for the recursion waves
+                double2* cst2 = reinterpret_cast<double2*>(ring + Geo::CONST2_OFF) + Geo::row_base(lane);
+                cst2[jr] = make_double2(g0 * hc_own.x, hc_own.y * rg0);
+                if (two) cst2[jr + 1] = make_double2(g1 * hc_par.x, hc_par.y * rg1);
+            }
 #pragma unroll
             for (int it = 0; it < NIT; it++) entry(it, ec0[it], es0[it], e10[it]);
         } else {
@@ -239,7 +275,7 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     for (int j = 0; j < P; j++) S[j] = 0.0;
     const double2* ring_b = nullptr;
     double2* link_b = nullptr;
-    double2 hc_n = make_double2(0.0, 0.0);
+    double2 hc_n = make_double2(0.0, 0.0), hc0 = make_double2(0.0, 0.0);
     unsigned rowm = 0;
     int j0 = 0;                                               // first datum of the current chunk
     auto pass = [&](const int s, const bool more, const bool rebase, const double e) __attribute__((always_inline)) {
@@ -259,8 +295,8 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
                 const double mp = g.partner(mm[j]);
                 S[j] = fma(rc_, mm[j], -(rs_ * mp));
             }
-            ht = mine ? h_row : hc.x;
-            ct = mine ? c_row : hc.y;
+            ht = mine ? hc0.x : hc.x;
+            ct = mine ? hc0.y : hc.y;
         }
         // w~ = S h~ ; var_j = s0 + e + h~.w~ (kfilter.cpp:180-182, 209-210) ; k~ = w~ + c~
         double w, var, k;
@@ -282,6 +318,7 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + Geo::entry(lane);
         link_b = reinterpret_cast<double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + Geo::entry(lane);
         hc_n = ring_b[0];
+        if (c == 0) hc0 = reinterpret_cast<const double2*>(ring + Geo::CONST2_OFF)[Geo::entry(lane)];
         j0 = c * C;
         const unsigned long long fm64 = flag_b[c % 3];
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
@@ -364,8 +401,8 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
     };
     const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
     __syncthreads();                                          // (h_r, c_r) published
-    h_own = reinterpret_cast<const double2*>(ring + Geo::CONST_OFF)[Geo::entry(lane)].x;
     __syncthreads();                                          // barrier 0
+    h_own = reinterpret_cast<const double2*>(ring + Geo::CONST2_OFF)[Geo::entry(lane)].x;    // g_r h_r: h~ at a re-base datum
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c + 1: wave A has finished chunk c
         ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + Geo::entry(lane);

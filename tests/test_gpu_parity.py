@@ -453,7 +453,7 @@ def test_corotating_frame_windows_and_rebases(cpa, p, q):
     plain = ctx.logdensity(np.tile(th, (1100, 1)), ignore_prior=True)[:64]      # throughput kernel
     for other in (pc, plain):
         assert np.array_equal(np.isfinite(other), fin)
-        assert np.max(np.abs(got[fin] - other[fin]) / np.abs(other[fin])) < 1e-11
+        assert np.max(np.abs(got[fin] - other[fin]) / np.abs(other[fin])) < 3e-11       # (2) below is the bar; this one says "same to rounding"
     # (2) against the oracle, at the bar of every other parity test: 1e-10, or -- where the reference's own arithmetic
     # loses digits on clustered roots -- no further from the 50-digit value than the oracle
     from helpers import loglik_truth

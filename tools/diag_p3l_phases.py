@@ -5,7 +5,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["CARMA_LIB_PATH"] = os.path.join(ROOT, "build_diag", "libcarma_mi355_diag.so")
+os.environ["CARMA_LIB_PATH"] = os.environ.get("DIAG_SO", os.path.join(ROOT, "build_diag", "libcarma_mi355_diag.so"))
 import carma_pack_amd as cpa
 from carma_pack_amd.synth import theta_batch
 g = np.load(os.path.join(ROOT, 'tests/golden/carma53_readme.npz'))
