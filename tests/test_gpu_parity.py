@@ -540,6 +540,41 @@ def test_wave_pipeline_real_pairs(cpa, p, q):
         assert np.array_equal(ctx.logdensity(real[i:i + 1], ignore_prior=True), got_r[i:i + 1], equal_nan=True)
 
 
+def test_sampler_states_with_extreme_ma_parameters(cpa, readme):
+    """States the config-2 sampler actually visits: the MA parameters carry no bounds and wander over hundreds of
+    e-folds, which (a) scales the modal coordinates to h_r ~ 1e115, c_r ~ 1e-115 (the co-rotating frame rescales them by
+    exact powers of two, carma_pipe3l.h), (b) gives MA quadratics with q2^2 >> 4 q1, whose small real root the
+    reference's -(q2 - sqrt(disc))/2 gets from a difference that cancels (the kernels take it from the product; the
+    reference's arithmetic is then 1e-5 .. 1e-3 off its own formulas) and (c) where that difference is exactly zero
+    makes the reference's log-density NaN -- kept.  Every launch shape, against the oracle with the quad-precision
+    arbiter at factor 1.0."""
+    from helpers import loglik_truth
+    g = readme
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    ms = _pop_var_stdev(y)
+    th = np.array([
+        [1.9975372608422424, 0.9366632575797602, 16.789804604528694, -2.8459005053663167, -2.5785176726328554, -8.527030455891527, -4.042246704130075, -4.789749463519823, -273.9017045585194, -189.0028062160441, 190.66754446338228],
+        [2.4412041555688764, 1.5020442804124263, 16.244818892766002, -2.544085061938346, -3.5266178124160126, -5.493800731987774, -0.8174389504577778, -2.4983083558227968, 86.96636588039864, -145.2770093883414, -262.81064520024455],
+        [2.654150300311842, 1.1858744491846047, 16.80325373166856, -2.7685429428460906, -3.2201853542962944, -4.797507667631114, 0.12286510905654124, -3.028389811950521, 67.00602986827704, -30.165291852301994, -291.20872808450326],
+        [3.055018346120766, 1.2673282010593487, 16.403675266584564, -2.755014593287507, -3.6868771388194364, -0.8946670513253863, 1.021064666621357, -2.237315448236734, 33.574182488931534, 35.24566024195148, 2.5411645091242945],
+        [1.8525647925407278, 1.2748302998110215, 15.937633272313981, -2.7369904131577463, -2.776973804968544, -5.194834353680233, -0.5291397335336755, -3.038857775554596, 33.378216844936524, 35.020459254449655, -166.3693311489375],
+        [2.12944262, 1.41947836, 16.43347782, -2.74726932, -3.03302348, -3.0162098, 1.67504333, -2.75785743, -76.24036304, 44.24716073, 1.73221414],
+    ])
+    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms)
+    m = orc.OracleModel(t, y, yerr, 5, 3, max_stdev=ms)
+    want = m.logdensity_batch(th)
+    assert np.isfinite(want[:5]).all() and np.isnan(want[5])          # (c): the reference's own NaN
+    arb = lambda i: loglik_truth(t, y, yerr, th[i % 6], 5, 3)[0]   # noqa: E731
+    assert abs(want[3] - arb(3)) > 1e-4 * abs(want[3])                # (b): the reference's arithmetic is that far off
+    for B in (6, 6 * 600, 6 * 12000):                                 # wave pipeline, G-lane producer/consumer, throughput
+        got = ctx.logdensity(np.tile(th, (B // 6, 1)))
+        assert np.array_equal(got, np.tile(got[:6], B // 6), equal_nan=True), ctx.kernel_name(B)
+        assert np.isnan(got[5])
+        assert_parity(got[:5], want[:5], RTOL, ctx.kernel_name(B), arbiter=arb)
+        tr = np.array([arb(i) for i in range(5)])
+        assert np.max(np.abs(got[:5] - tr) / np.abs(tr)) < 1e-12      # and in fact exact to rounding
+
+
 @pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
 def test_prior_like_sweep_never_worse_than_reference(cpa, p):
     """Every order (p, q < p) x 200 random PRIOR-LIKE parameter vectors -- the nastiest inputs the sampler can meet:
