@@ -82,7 +82,7 @@ CARMA_DEV Cx quad_root(double lq1, double lq2, int which)
         // Where the reference's difference is EXACTLY zero (q2^2 > 2^53 * 4 q1) its MA polynomial divides by that root and
         // the log-density is NaN: kept, so that the sampler moves in the same domain as the reference's.
         const double big = -0.5 * (q2 + sq);
-        r.re = which ? (q2 - sq == 0.0 ? 0.0 : q1 / big) : big;
+        r.re = which ? (q2 - sq == 0.0 ? 0.0 : q1 * recip(big)) : big;
         r.im = 0.0;
     } else {
         r.re = -0.5 * q2;

@@ -283,7 +283,7 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         if (more) hc_n = ring_b[(size_t)(s + 1) * Geo::SLOT];
         __builtin_amdgcn_sched_barrier(0);                    // the next pass's entry is requested HERE, a pass ahead
         double ht = hc.x, ct = hc.y;
-        if (rebase) {
+        if (__builtin_expect(rebase, 0)) {
             // S <- A S A^T with the accumulated rotation (kfilter.cpp:204 for the whole window); a row whose own
             // schedule has no re-base here rotates by the identity and keeps its (h~, c~)
             const bool mine = (rowm >> s) & 1u;
@@ -331,8 +331,15 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
             double ev[C];
 #pragma unroll
             for (int s = 0; s < C; s++) ev[s] = series[j0 + s].z;
+            if (fm == 0) {
+                // no re-base in this chunk (the rule for posterior-like parameters): a copy of the passes without the
+                // sixteen skip-branches -- a TAKEN branch over the re-base block costs the wave ~30 cycles, every datum
 #pragma unroll
-            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, ev[s]);
+                for (int s = 0; s < C; s++) pass(s, s + 1 < C, false, ev[s]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, ev[s]);
+            }
         } else {
             // The last, shorter chunk runs as a rolled loop.  Its yerr_j^2 come through LDS (one vector load, lane s <->
             // datum s, staged once; read back one pass ahead like the ring entries): a scalar load inside the pass made
@@ -384,7 +391,7 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
         }
         __builtin_amdgcn_sched_barrier(0);
         double ht = hc.x;
-        if (rebase) {                                         // z <- A z~ (kfilter.cpp:200-201 for the whole window)
+        if (__builtin_expect(rebase, 0)) {                                         // z <- A z~ (kfilter.cpp:200-201 for the whole window)
             const bool mine = (rowm >> s) & 1u;
             const double rc_ = mine ? hc.x : 1.0, rs_ = mine ? hc.y : 0.0;
             const double zp = g.partner(z);
@@ -420,8 +427,13 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
             double yv[C];
 #pragma unroll
             for (int s = 0; s < C; s++) yv[s] = series[j0 + s].y;
+            if (fm == 0) {
 #pragma unroll
-            for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, yv[s]);
+                for (int s = 0; s < C; s++) pass(s, s + 1 < C, false, yv[s]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < C; s++) pass(s, s + 1 < C, (fm >> s) & 1u, yv[s]);
+            }
         } else {
             // last, shorter chunk: y_j staged through LDS (see the covariance wave)
             double* tail = const_cast<double*>(reinterpret_cast<const double*>(ring + Geo::TAIL_OFF)) + C;
