@@ -85,12 +85,18 @@ void sort_dedup(std::vector<double>& t, std::vector<double>& y, std::vector<doub
 std::vector<double> pack_series(const std::vector<double>& t, const std::vector<double>& y, const std::vector<double>& e)
 {
     const size_t n = t.size();
-    std::vector<double> s(4 * n);
+    std::vector<double> s(4 * (n + P3L_PAD_RECORDS));
     for (size_t k = 0; k < n; k++) {
         s[4 * k + 0] = k ? t[k] - t[k - 1] : 0.0;
         s[4 * k + 1] = y[k];
         s[4 * k + 2] = e[k] * e[k];
         s[4 * k + 3] = t[k];
+    }
+    for (size_t k = n; k < n + P3L_PAD_RECORDS; k++) {        // neutral pad records (carma_types.h, p3l_pad)
+        s[4 * k + 0] = 0.0;
+        s[4 * k + 1] = n ? y[n - 1] : 0.0;
+        s[4 * k + 2] = 0.0;
+        s[4 * k + 3] = n ? t[n - 1] : 0.0;
     }
     return s;
 }

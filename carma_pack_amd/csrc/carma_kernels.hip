@@ -92,8 +92,9 @@ __global__ __launch_bounds__(128 * PAIRS) void k_logdens_carma_pc(const double* 
 template <int P>
 __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restrict__ theta, int B, int d, int q,
                                                            const double4* __restrict__ series, int n, Prior pr,
-                                                           int ignore_prior, double* __restrict__ out, int ncu)
+                                                           int ignore_prior, double* __restrict__ out, int ncu, int npad)
 {
+    // n includes npad neutral pad data at the end (carma_types.h, p3l_pad)
     extern __shared__ double4 smem4[];
     const int tid = threadIdx.x, lane64 = tid & 63;
     // Which wave plays which part.  Workgroups i, i + ncu, i + 2 ncu share a CU, and the waves of successive workgroups
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     CARMA_MARK_DECL;
     CARMA_MARK(0);
     if (wave >= 2) {
-        pipe3l_produce<P>(g, wave - 2, theta + e * d, series, n, ring, [](int) {});
+        pipe3l_produce<P>(g, wave - 2, theta + e * d, series, n, npad, ring, [](int) {});
         CARMA_MARK(3);
         CARMA_MARK_DUMP("producer", wave - 2);
         return;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     CARMA_MARK(1);
     // the log prior is evaluated HERE, while the mean wave would otherwise wait for the pipeline to fill, not after the
     // recursion (a serial chain of ~1000 cycles on the critical path of the launch)
-    double lpri = log_prior(m.scale, pr.measerr_dof);
+    double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, theta[e * d], series[n - npad - 1].y, m.mu);
     asm volatile("" : "+v"(lpri));
     CARMA_MARK(2);
     double ll = pipe3l_mean<P>(g, m.mu, series, n, ring);
@@ -310,7 +311,7 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             // covariance wave + mean wave + two producer waves per four evaluations, co-rotating frame
             // (carma_pipe3l.h); 42 KiB of LDS: up to three workgroups per CU
             hipLaunchKernelGGL((k_logdens_carma_p3l<P>), dim3((unsigned)rows), dim3(256), Pipe3LGeom<P>::BYTES, st, theta, B, d, q,
-                               series, n, pr, ignore_prior, out, device_cus());
+                               series, n + p3l_pad(n), pr, ignore_prior, out, device_cus(), p3l_pad(n));
             return hipGetLastError();
         case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);
         case LdShape::PC2: return launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);

@@ -106,8 +106,10 @@ CARMA_DEV double dpp_mov_old(double old, double src)
 // sampler kernel draws the next iteration's random numbers there.
 template <int P, class Tail>
 __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
-                                               const double4* __restrict__ series, int n, Cx* __restrict__ ring, Tail&& tail)
+                                               const double4* __restrict__ series, int n, int npad, Cx* __restrict__ ring,
+                                               Tail&& tail)
 {
+    // n counts the npad neutral pad data at the end (carma_types.h, p3l_pad): their entries are exact zeros
     using Geo = Pipe3LGeom<P>;
     constexpr int C = Geo::C;
     // a lane works on a conjugate PAIR of roots (2 pr, 2 pr + 1): both share |E|, cos and sin, so one exp/sincos
@@ -198,13 +200,14 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
                 const double inv = recip(fma(gc, gc, gs * gs));
                 const double ht = fma(gc, hc_own.x, gs * hc_par.x);
                 const double ct = fma(gc, hc_own.y, gs * hc_par.y) * inv;
-                buf[(size_t)slot * Geo::SLOT] = flag ? Cx{ec, es} : Cx{ht, ct};
+                const bool pad = j0 + slot >= n - npad;
+                buf[(size_t)slot * Geo::SLOT] = pad ? Cx{0.0, 0.0} : (flag ? Cx{ec, es} : Cx{ht, ct});
                 if (two) {
                     const double gc1 = e1 * g1, gs1 = es * g1;
                     const double inv1 = realpair ? recip(gc1 * gc1) : inv;
                     const double hp = fma(gc1, hc_par.x, -gs1 * hc_own.x);
                     const double cp = fma(gc1, hc_par.y, -gs1 * hc_own.y) * inv1;
-                    buf[(size_t)slot * Geo::SLOT + 1] = flag ? Cx{e1, -es} : Cx{hp, cp};
+                    buf[(size_t)slot * Geo::SLOT + 1] = pad ? Cx{0.0, 0.0} : (flag ? Cx{e1, -es} : Cx{hp, cp});
                 }
             }
         };
@@ -360,6 +363,15 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         }
     }
     __syncthreads();                                          // barrier nc
+}
+
+// What npad pad data (carma_types.h, p3l_pad) add to the sums of the mean wave, to be taken out again: each of them has
+// var = s0 and innov = y_last - mu exactly, i.e. contributes -0.5 (log s0 + innov^2 / s0).
+__device__ __forceinline__ double pipe3l_pad_correction(int npad, double sigma_y, double y_last, double mu)
+{
+    const double s0 = sigma_y * sigma_y;                      // as Model::s0
+    const double dd = y_last - mu;
+    return npad ? 0.5 * npad * (log(s0) + dd * (recip(s0) * dd)) : 0.0;
 }
 
 // wave B.  Of the model it needs mu only (and the flags its caller checks): the observation row h_r -- used at the

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
 #if defined(CARMA_STAMPS)
     unsigned long long st5 = 0, st6 = 0, st7 = 0;
 #endif
+    const int npad = p3l_pad(L.n);                         // neutral pad data completing the last chunk (carma_types.h)
     for (int it = 0; it < L.niter; it++) {
         const uint64_t iter = L.iter0 + (uint64_t)it;
         double znorm2 = 0.0;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             // the producers are done two chunks before the recursion waves: in that time they draw random numbers that
             // are functions of key and iteration only -- P0 the NEXT iteration's proposal variates, P1 the logs of the
             // swap uniforms of THIS iteration's exchange
-            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n, ring, [&](int pw) {
+            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [&](int pw) {
                 if (pw == 0) {
                     s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
                 } else if (L.do_exchange && T > 1 && T <= 64) {
@@ -334,12 +335,13 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
                 filter_reset<P, G>(g, m, fc);
                 RowConsts<P> rc;
                 row_consts<P>(g, m, fc, rc);
-                pipe3l_cov<P>(g, m, rc, series, L.n, ring);
+                pipe3l_cov<P>(g, m, rc, series, L.n + npad, ring);
             } else {
                 model_from_theta<P, G, MODEL_FLAGS>(g, thn_lds, L.q, pr, 0, m);
-                double lpri = log_prior(m.scale, pr.measerr_dof);       // before the recursion: off the critical path
+                // before the recursion: off the critical path
+                double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], series[L.n - 1].y, m.mu);
                 asm volatile("" : "+v"(lpri));
-                double ll = pipe3l_mean<P>(g, m.mu, series, L.n, ring);
+                double ll = pipe3l_mean<P>(g, m.mu, series, L.n + npad, ring);
                 ll += lpri;
                 if (m.sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;

@@ -12,6 +12,22 @@ struct Cx {
     double re, im;
 };
 
+// The wave pipeline (carma_pipe3l.h) runs full 16-datum chunks unrolled and a last, shorter chunk as a rolled loop that is
+// ~30 % slower per datum -- and the mean wave's last chunk is what the launch ends on.  A last chunk of 11..15 data is
+// therefore completed to 16 with NEUTRAL pad data (the series in HBM always carries 16 pad records behind the real ones:
+// dt = 0, y = y_last, yerr^2 = 0): the producers write zero ring entries for them, so the state does not move (k~ = 0
+// exactly) and each pad adds exactly var = s0, innov = y_last - mu to the sums, which the kernel takes out again.
+constexpr int P3L_PAD_RECORDS = 16;
+inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    int p3l_pad(int n)
+{
+    const int r = n % 16;
+    return r >= 11 ? 16 - r : 0;
+}
+
 // Arguments of one launch of the persistent PT kernel.
 struct PtLaunch {
     int d, q, n;                 // parameter dimension, MA order, series length
