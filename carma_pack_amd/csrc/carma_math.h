@@ -120,12 +120,12 @@ static inline SinCos sincos_slow(double x)
 // EXACT: the rounding of the products a dt and b dt (relative 2^-53: 3e-14 rad at a phase of 256 rad, 1e-11 at 1e5 rad) is
 // recovered with an FMA and added back after the argument reduction, so the accuracy no longer degrades with |b dt|.
 // dt_lo: the part of the time difference its double does not hold (two-difference of the two times), EXACT only.
-template <bool EXACT = false>
-CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im, double dt_lo = 0.0)
+template <bool EXACT, bool CHECK>
+CARMA_DEV void cexp_step_impl(double a, double b, double dt, double* re, double* im, double dt_lo)
 {
     const double x = a * dt;
     const double ph = b * dt;
-    if (!(fabs(ph) < 1048576.0)) {
+    if (CHECK && !(fabs(ph) < 1048576.0)) {
         // rare: library reduction for huge phases (NaN also lands here)
         const double e = exp_neg(x);
         SinCos sc = sincos_slow(ph);
@@ -197,6 +197,25 @@ CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im, 
     co = ((q + 1) & 2) ? -co : co;
     *re = e * co;
     *im = e * so;
+}
+
+// The huge-phase test is made ONCE PER WAVE: a per-lane test compiles to an exec-masked block in front of the fast path
+// and the branch over it is TAKEN every time -- ~30 cycles of instruction-fetch bubble per evaluation when the SIMD has
+// one or two waves.  If no lane of the wave needs the library reduction (the rule) the wave falls through into the fast
+// path; if one does, every lane runs the per-lane form, in which the fast lanes execute the same instructions as here.
+template <bool EXACT = false>
+CARMA_DEV void cexp_step(double a, double b, double dt, double* re, double* im, double dt_lo = 0.0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool slow = !(fabs(b * dt) < 1048576.0);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+        cexp_step_impl<EXACT, true>(a, b, dt, re, im, dt_lo);
+        return;
+    }
+    cexp_step_impl<EXACT, false>(a, b, dt, re, im, dt_lo);
+#else
+    cexp_step_impl<EXACT, true>(a, b, dt, re, im, dt_lo);
+#endif
 }
 
 }  // namespace carma
