@@ -84,8 +84,8 @@ void sort_dedup(std::vector<double>& t, std::vector<double>& y, std::vector<doub
 // series records {dt_k, y_k, yerr_k^2, t_k}
 std::vector<double> pack_series(const std::vector<double>& t, const std::vector<double>& y, const std::vector<double>& e)
 {
-    const size_t n = t.size();
-    std::vector<double> s(4 * (n + P3L_PAD_RECORDS));
+    const size_t n = t.size(), nt = n + P3L_PAD_RECORDS;
+    std::vector<double> s(6 * nt);
     for (size_t k = 0; k < n; k++) {
         s[4 * k + 0] = k ? t[k] - t[k - 1] : 0.0;
         s[4 * k + 1] = y[k];
@@ -97,6 +97,12 @@ std::vector<double> pack_series(const std::vector<double>& t, const std::vector<
         s[4 * k + 1] = n ? y[n - 1] : 0.0;
         s[4 * k + 2] = 0.0;
         s[4 * k + 3] = n ? t[n - 1] : 0.0;
+    }
+    // behind the records: yerr^2 and y once more as plain arrays -- the recursion waves of the pipeline fetch sixteen
+    // of them per chunk with scalar loads, and contiguous doubles come in two wide loads instead of sixteen
+    for (size_t k = 0; k < nt; k++) {
+        s[4 * nt + k] = s[4 * k + 2];
+        s[5 * nt + k] = s[4 * k + 1];
     }
     return s;
 }

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
         RowConsts<P> rc;
         row_consts<P>(g, m, fc, rc);
         CARMA_MARK(2);
-        pipe3l_cov<P>(g, m, rc, series, n, ring);
+        pipe3l_cov<P>(g, m, rc, series, n, npad, ring);
         CARMA_MARK(3);
         CARMA_MARK_DUMP("covariance", 0);
         return;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, theta[e * d], series[n - npad - 1].y, m.mu);
     asm volatile("" : "+v"(lpri));
     CARMA_MARK(2);
-    double ll = pipe3l_mean<P>(g, m.mu, series, n, ring);
+    double ll = pipe3l_mean<P>(g, m.mu, series, n, npad, ring);
     CARMA_MARK(3);
     ll += lpri;
     const double ninf = -1.0 / 0.0;

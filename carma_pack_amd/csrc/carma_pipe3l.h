@@ -261,8 +261,9 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
 // and the reciprocal refinement is folded into the gain so that the chain, not the issue rate, stays short.
 template <int P>
 __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, const RowConsts<P>& rc,
-                                           const double4* __restrict__ series, int n, Cx* __restrict__ ring)
+                                           const double4* __restrict__ series, int n, int npad, Cx* __restrict__ ring)
 {
+    const double* __restrict__ e_arr = reinterpret_cast<const double*>(series + (n - npad + P3L_PAD_RECORDS));   // yerr^2[]
     using Geo = Pipe3LGeom<P>;
     using RA = RowAsm<P>;
     constexpr int C = Geo::C;
@@ -333,7 +334,7 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
             // LDS returns share a counter, so a scalar load inside the pass would drain the LDS prefetch every step)
             double ev[C];
 #pragma unroll
-            for (int s = 0; s < C; s++) ev[s] = series[j0 + s].z;
+            for (int s = 0; s < C; s++) ev[s] = e_arr[j0 + s];
             if (fm == 0) {
                 // no re-base in this chunk (the rule for posterior-like parameters): a copy of the passes without the
                 // sixteen skip-branches -- a TAKEN branch over the re-base block costs the wave ~30 cycles, every datum
@@ -379,8 +380,10 @@ __device__ __forceinline__ double pipe3l_pad_correction(int npad, double sigma_y
 // part of the set-up (model_from_theta<MODEL_FLAGS>).
 template <int P>
 __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const double4* __restrict__ series, int n,
-                                              const Cx* __restrict__ ring)
+                                              int npad, const Cx* __restrict__ ring)
 {
+    const double* __restrict__ y_arr = reinterpret_cast<const double*>(series + (n - npad + P3L_PAD_RECORDS)) +
+                                       (n - npad + P3L_PAD_RECORDS);                                              // y[]
     using Geo = Pipe3LGeom<P>;
     using RA = RowAsm<P>;
     constexpr int C = Geo::C;
@@ -438,7 +441,7 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
             // y_j: scalar loads, as yerr_j^2 in the covariance wave
             double yv[C];
 #pragma unroll
-            for (int s = 0; s < C; s++) yv[s] = series[j0 + s].y;
+            for (int s = 0; s < C; s++) yv[s] = y_arr[j0 + s];
             if (fm == 0) {
 #pragma unroll
                 for (int s = 0; s < C; s++) pass(s, s + 1 < C, false, yv[s]);

@@ -18,6 +18,7 @@ struct Cx {
 // dt = 0, y = y_last, yerr^2 = 0): the producers write zero ring entries for them, so the state does not move (k~ = 0
 // exactly) and each pad adds exactly var = s0, innov = y_last - mu to the sums, which the kernel takes out again.
 constexpr int P3L_PAD_RECORDS = 16;
+// layout of the series in HBM: double4 records[n + 16] {dt, y, yerr^2, t}, then double yerr2[n + 16], then double y[n + 16]
 inline
 #if defined(__HIPCC__)
     __host__ __device__
