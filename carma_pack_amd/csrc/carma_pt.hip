@@ -267,6 +267,8 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
     int* s_flag = s_src + T;                               // [1] abort seen (+ pad)
     double* s_z = reinterpret_cast<double*>(s_flag + 2);   // [64] next iteration's t8 variates, drawn by producer wave 0
     double* s_lu = s_z + 64;                               // [64] next exchange's log-uniforms (T <= 64), same
+    double* s_step = s_lu + 64;                            // [1] this iteration's adaptation step length (+ pad), same
+    double* s_tha = s_step + 2;                            // [T][d] the ladder's staged parameter vectors (T <= 64)
     const long lad = blockIdx.x / S.wpl;                   // local replica (ladder) index
     const int part = (int)(blockIdx.x % S.wpl);
     const long ch0 = lad * T;                              // first chain of the ladder in the state arrays
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [&](int pw) {
                 if (pw == 0) {
                     s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
+                    if (lane64 == 0) *s_step = ram_adapt_step(d, iter);
                 } else if (L.do_exchange && T > 1 && T <= 64) {
                     const int i = lane64 < T ? lane64 : T - 1;
                     RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             }
             CARMA_STAMP(st4);
             // the adaptation of the proposal factor does not touch the state: it runs while the other workgroups arrive
-            ram_adapt_row(g, ch, d, iter, L.maxiter, alpha, znorm2);
+            ram_adapt_row(g, ch, d, iter, L.maxiter, alpha, znorm2, *s_step);
             CARMA_STAMP(st5);
         }
         if (exch) {
@@ -396,6 +399,11 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             // the ladder's log-posteriors and swap uniforms (keyed by the hotter chain's global slot):
             // lane i of the chain wave owns temperature i, the sweep runs through v_readlane
             if (T <= 64) {
+                // every wave: the ladder's staged parameter vectors into LDS, requested TOGETHER with the log-posteriors
+                // (which vector a chain picks up is known only after the sweep; a load after it was one more trip to L2)
+                for (int i = tid; i < T * d; i += 256)
+                    s_tha[i] = __hip_atomic_load(&st_th[ch0 * d + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int from = cc;
                 if (!producer) {
                     const int i = lane64 < T ? lane64 : T - 1;
                     double lp_i = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -404,11 +412,11 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
                     bool sw;
                     exchange_decide_wave(T, lane64, lp_i, s_dbeta[i], logu_i, src_i, &sw);
                     if (sw && lane64 < T) s_nswap[lane64]++;
-                    const int from = __shfl(src_i, cc, 64);
+                    from = __shfl(src_i, cc, 64);
                     lp = __shfl(lp_i, cc, 64);
-                    if (from != cc && j < d)
-                        ch.th = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                __syncthreads();
+                if (!producer && from != cc && j < d) ch.th = s_tha[from * d + j];
             } else {
                 for (int i = tid; i < T; i += 256) {
                     s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -425,8 +433,8 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
                         ch.th = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     lp = s_lp[cc];
                 }
+                __syncthreads();
             }
-            __syncthreads();
             buf ^= 1;
             nexch++;
             CARMA_STAMP(st7);
@@ -466,7 +474,8 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
 static size_t pt_row_lds(int d, int T)
 {
     (void)d;
-    return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16 + 128 * 8;
+    return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16 + 128 * 8 + 16 +
+           (size_t)(T <= 64 ? T : 0) * PT_DMAX * 8;
 }
 
 template <int P>

@@ -93,12 +93,18 @@ __device__ __forceinline__ bool ram_accept_row(RowChain& ch, double temperature,
 
 // The RAM rank-1 update of the proposal factor (steps.cpp:82-99); independent of the state, so the sampler kernel runs
 // it while the other workgroups of the ladder arrive at the swap rendezvous.
+// step length of the adaptation at `iter` (a function of the iteration alone: a producer wave evaluates it during the
+// filter, so that the cube root is off the chain wave's path)
+__device__ __forceinline__ double ram_adapt_step(int d, uint64_t iter)
+{
+    const double cb = cbrt((double)iter);                   // iter^(2/3) without pow (iter = 0 -> step 1)
+    return fmin(1.0, (double)d / (cb * cb));
+}
+
 __device__ __forceinline__ void ram_adapt_row(const Grp<16>& g, RowChain& ch, int d, uint64_t iter, int maxiter, double alpha,
-                                              double znorm2)
+                                              double znorm2, double step)
 {
     if ((long)iter < (long)maxiter) {
-        const double cb = cbrt((double)iter);               // iter^(2/3) without pow (iter = 0 -> step 1)
-        const double step = fmin(1.0, (double)d / (cb * cb));
         const double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(znorm2);
         ch.v *= fac;
         chol_update_row(g, d, ch, alpha < 0.25);
