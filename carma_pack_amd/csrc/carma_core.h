@@ -517,11 +517,11 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
             rec_n = src.record_s(0);
         }
     }
-    auto pass = [&](const int kk, const int s_in_chunk, auto phase) __attribute__((always_inline)) {
+    auto pass = [&](const int kk, const int s_in_chunk, auto phase, const double4* rnn_in = nullptr) __attribute__((always_inline)) {
         constexpr int PH = decltype(phase)::value;          // RhoPair: step of the trip (0, 1); unused otherwise
         CARMA_STAMP(st0);
         double4 rnn = rnxt;
-        if constexpr (!RhoSrc::kRing) rnn = series[(kk + 2 < n) ? kk + 2 : n - 1];
+        if constexpr (!RhoSrc::kRing) rnn = rnn_in ? *rnn_in : series[(kk + 2 < n) ? kk + 2 : n - 1];
         // the gain goes through LDS (8 B per lane, read back as pairs)
         double kj[(P + 1) & ~1];
         Cx rho = rho_n, rj[P];
@@ -613,8 +613,17 @@ CARMA_DEV double filter_loop_real(const GrpT& g, const Model<P>& m, const Filter
         int kk = 1;
 #pragma unroll 1
         for (; kk + 1 < n; kk += 2) {
-            pass(kk, 0, IntC<0>{});
-            pass(kk + 1, 0, IntC<1>{});
+            // the records of the two steps after this trip: adjacent in memory, one wide scalar load instead of two
+            double4 ra, rb;
+            if (kk + 3 < n) {
+                ra = series[kk + 2];
+                rb = series[kk + 3];
+            } else {
+                ra = series[(kk + 2 < n) ? kk + 2 : n - 1];
+                rb = series[n - 1];
+            }
+            pass(kk, 0, IntC<0>{}, &ra);
+            pass(kk + 1, 0, IntC<1>{}, &rb);
         }
         if (kk < n) pass(kk, 0, IntC<0>{});
     } else {
