@@ -136,7 +136,9 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
     the same Philox keys and formulas: from the same seed and start they must produce the same chains
     (accept/swap decisions identical, values to rounding), saved samples included."""
     from helpers import irregular_series
-    t, y, yerr = irregular_series(80, seed=70 + p)
+    # odd p: 77 data, i.e. a last chunk of 13 that the row kernel's pipeline completes with 3 neutral pad data
+    # (carma_types.h p3l_pad) and the ladder kernel does not
+    t, y, yerr = irregular_series(80 - 3 * (p % 2), seed=70 + p)
     ms = _pop_stdev(y)
     res = {}
     for kern in ("ladder", "row"):
