@@ -196,3 +196,54 @@ def test_sharded_ladder_saves_the_coldest_chain():
         assert_parity(slp.reshape(-1), m.logdensity_batch(flat), 1e-10, "sharded samples %s" % blocks,
                       arbiter=lambda i: loglik_truth(t, y, e, flat[i], P, Q)[0])
         assert np.unique(flat[:, 0]).size > R                     # the chains moved between saves
+
+
+def _two_gpu_worker(rank, port, q):
+    """One process per GPU: rank 0 holds temperatures 0..2, rank 1 temperatures 3..4; the boundary goes over RCCL."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)          # bootstrap only: carries the 128-byte RCCL id
+    try:
+        import carma_pack_amd as cpa
+        from carma_pack_amd import _lib, parallel as par
+        t, y, e = _series()
+        temps = par.ladder_temperatures(TG)
+        comm = _lib.Comm.from_torch(dist, device=rank)
+        Tl, slot0 = (3, 0) if rank == 0 else (2, 3)
+        c = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std(), device=rank)
+        c.pt_create(Tl, R, NITER, seed=SEED, temperatures=temps[slot0:slot0 + Tl])
+        c.pt_shard(TG, slot0, 0)
+        c.pt_start(None)
+        _lib.pt_iterate_sharded([c], NITER, comm)
+        th, lp = c.pt_get_chains()
+        q.put((rank, th, lp, c.pt_boundary_stats()))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_exchange_between_two_gpus():
+    """The same ladder with its two blocks on two GPUs, one process each, boundary rows over RCCL send/recv between the
+    devices (xGMI): the same chain states bit for bit as the one-GPU reference.  Needs two GPUs; the one-GPU box of the
+    round-end run skips it (the path is then covered through send/recv to the process's own rank, above)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    from helpers import queue_get
+    ref = _run(resident=True)
+    (r0, sw0, pr0, s0, th0, lp0), (r1, sw1, pr1, s1, th1, lp1) = ref
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_gpu_worker, args=(r, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted((queue_get(q, procs, 300) for _ in range(2)), key=lambda r: r[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    (_, nth0, nlp0, (npr0, nsw0)), (_, nth1, nlp1, (npr1, nsw1)) = res
+    assert np.array_equal(nth0, th0) and np.array_equal(nlp0, lp0)
+    assert np.array_equal(nth1, th1) and np.array_equal(nlp1, lp1)
+    assert (npr0, nsw0) == (pr0, sw0) and (npr1, nsw1) == (pr1, sw1)
