@@ -95,7 +95,7 @@ std::vector<double> pack_series(const std::vector<double>& t, const std::vector<
     for (size_t k = n; k < n + P3L_PAD_RECORDS; k++) {        // neutral pad records (carma_types.h, p3l_pad)
         s[4 * k + 0] = 0.0;
         s[4 * k + 1] = n ? y[n - 1] : 0.0;
-        s[4 * k + 2] = 0.0;
+        s[4 * k + 2] = 1.0;
         s[4 * k + 3] = n ? t[n - 1] : 0.0;
     }
     // behind the records: yerr^2 and y once more as plain arrays -- the recursion waves of the pipeline fetch sixteen

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     CARMA_MARK(1);
     // the log prior is evaluated HERE, while the mean wave would otherwise wait for the pipeline to fill, not after the
     // recursion (a serial chain of ~1000 cycles on the critical path of the launch)
-    double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, theta[e * d], series[n - npad - 1].y, m.mu);
+    double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, theta[e * d], m.scale, series[n - npad - 1].y, m.mu);
     asm volatile("" : "+v"(lpri));
     CARMA_MARK(2);
     double ll = pipe3l_mean<P>(g, m.mu, series, n, npad, ring);

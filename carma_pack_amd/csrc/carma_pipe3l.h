@@ -367,12 +367,14 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
 }
 
 // What npad pad data (carma_types.h, p3l_pad) add to the sums of the mean wave, to be taken out again: each of them has
-// var = s0 and innov = y_last - mu exactly, i.e. contributes -0.5 (log s0 + innov^2 / s0).
-__device__ __forceinline__ double pipe3l_pad_correction(int npad, double sigma_y, double y_last, double mu)
+// var = 1 * scale + s0 (one FMA, as the covariance wave forms it) and innov = y_last - mu exactly, i.e. contributes
+// -0.5 (log var + innov^2 / var).
+__device__ __forceinline__ double pipe3l_pad_correction(int npad, double sigma_y, double scale, double y_last, double mu)
 {
     const double s0 = sigma_y * sigma_y;                      // as Model::s0
+    const double v = fma(1.0, scale, s0);
     const double dd = y_last - mu;
-    return npad ? 0.5 * npad * (log(s0) + dd * (recip(s0) * dd)) : 0.0;
+    return npad ? 0.5 * npad * (log(v) + dd * (recip(v) * dd)) : 0.0;
 }
 
 // wave B.  Of the model it needs mu only (and the flags its caller checks): the observation row h_r -- used at the

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             } else {
                 model_from_theta<P, G, MODEL_FLAGS>(g, thn_lds, L.q, pr, 0, m);
                 // before the recursion: off the critical path
-                double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], series[L.n - 1].y, m.mu);
+                double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], m.scale, series[L.n - 1].y, m.mu);
                 asm volatile("" : "+v"(lpri));
                 double ll = pipe3l_mean<P>(g, m.mu, series, L.n + npad, npad, ring);
                 ll += lpri;

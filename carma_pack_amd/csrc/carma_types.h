@@ -15,8 +15,9 @@ struct Cx {
 // The wave pipeline (carma_pipe3l.h) runs full 16-datum chunks unrolled and a last, shorter chunk as a rolled loop that is
 // ~30 % slower per datum -- and the mean wave's last chunk is what the launch ends on.  A last chunk of 11..15 data is
 // therefore completed to 16 with NEUTRAL pad data (the series in HBM always carries 16 pad records behind the real ones:
-// dt = 0, y = y_last, yerr^2 = 0): the producers write zero ring entries for them, so the state does not move (k~ = 0
-// exactly) and each pad adds exactly var = s0, innov = y_last - mu to the sums, which the kernel takes out again.
+// dt = 0, y = y_last, yerr^2 = 1): the producers write zero ring entries for them, so the state does not move (k~ = 0
+// exactly) and each pad adds exactly var = scale + s0, innov = y_last - mu to the sums, which the kernel takes out again
+// (yerr^2 = 1 rather than 0 keeps var positive for sigma_y = 0, which the reference's bounds admit).
 constexpr int P3L_PAD_RECORDS = 16;
 // layout of the series in HBM: double4 records[n + 16] {dt, y, yerr^2, t}, then double yerr2[n + 16], then double y[n + 16]
 inline

@@ -378,7 +378,8 @@ def test_edge_cases_nan_inf_tiny_series(cpa, readme):
     ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=_pop_var_stdev(y))
     m = orc.OracleModel(t, y, yerr, 5, 3)
     th0 = g["theta"][0]
-    cases = np.tile(th0, (8, 1))
+    cases = np.tile(th0, (9, 1))
+    cases[8, 0] = 0.0             # sigma_y = 0 is inside the reference's bounds: var_k = scale yerr_k^2 (n = 270 is a padded length)
     cases[0, 0] = np.nan
     cases[1, 3] = np.inf
     cases[2, 4] = -np.inf
@@ -390,6 +391,7 @@ def test_edge_cases_nan_inf_tiny_series(cpa, readme):
         got = ctx.logdensity(cases, ignore_prior=ign)
         want = m.logdensity_batch(cases, ignore_prior=ign)
         assert np.isfinite(got[7]) and abs(got[7] - want[7]) <= 1e-10 * abs(want[7])
+        assert np.isfinite(want[8]) == np.isfinite(got[8])
         assert not np.any(np.isfinite(got[:4])) and not np.any(np.isfinite(want[:4]))
         # where the oracle is finite the GPU agrees; where it is not, the GPU is not finite either
         fin = np.isfinite(want)
