@@ -266,7 +266,10 @@ def main():
         kernel_name = ctx.kernel_name(B)
         traffic_gbs_bytes, traffic_src, pmc_extra = None, None, None
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")), key=os.path.getmtime, reverse=True)
+        import re
+        # newest = highest (round, version) in the path (profiles/r02/pmc_v5.json); file times mean nothing after a checkout
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")),
+                       key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.relpath(f, ROOT))], reverse=True)
         for pmc in cands:
             try:
                 pj = json.load(open(pmc))
