@@ -84,6 +84,11 @@ class _CarmaBase(object):
         return self._ctx.logdensity(np.asarray(thetas, dtype=float).reshape(-1, self._ctx.d),
                                     ignore_prior=self._ignore_prior)
 
+    def minimizeBatch(self, starts, bounds, **kw):
+        """Bounded quasi-Newton searches on -LogDensity from every row of `starts`, in lock-step, host loop in the
+        library (carma_mle_batched): (x, fun, nit, nfev, status)."""
+        return self._ctx.mle_batched(starts, bounds, ignore_prior=self._ignore_prior, **kw)
+
     def getAllSamples(self):
         """Samples of every independent replica: ([R][S][d], [R][S])."""
         return self._all_samples, self._all_logposts

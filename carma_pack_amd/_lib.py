@@ -88,6 +88,9 @@ def _load():
     L.carma_logdensity_batch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
     L.carma_logdensity_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.carma_logdensity_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.carma_mle_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                    C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.carma_mle_batched.restype = C.c_int
     L.carma_logprior.argtypes = [C.c_void_p, _dp]
     L.carma_logprior.restype = C.c_double
     L.carma_kfilter_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp,
@@ -140,7 +143,7 @@ lib = _load()
 EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
-    "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_kfilter_carma",
+    "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_mle_batched", "carma_kfilter_carma",
     "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_normalize_roots", "carma_kf_create_carma", "carma_kf_create_car1",
     "carma_kf_destroy", "carma_kf_n", "carma_kf_filter", "carma_kf_predict", "carma_simulate_carma", "carma_simulate_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
@@ -249,6 +252,24 @@ class Context:
         buf = C.create_string_buffer(128)
         check(lib.carma_logdensity_kernel_name(self._h, int(B), buf, 128), "carma_logdensity_kernel_name")
         return buf.value.decode()
+
+    def mle_batched(self, x0, bounds, maxiter=2000, mem=8, ftol=2.220446049250313e-09, gtol=1e-5, fd_step=1e-6,
+                    ignore_prior=True):
+        """carma_mle_batched: lock-step bounded L-BFGS from every row of x0 on -LogDensity, host loop in the library.
+        bounds = [(lo, hi)] with None for unbounded.  Returns (x [B, d], fun [B], nit [B], nfev [B], status [B])."""
+        x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
+        B, d = x0.shape
+        if d != self.d:
+            raise ValueError("x0 must be [B, %d]" % self.d)
+        lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+        hi = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        x, fun = np.empty((B, d)), np.empty(B)
+        nit, nfev, status = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        check(lib.carma_mle_batched(self._h, ptr(x0), B, ptr(lo), ptr(hi), int(maxiter), int(mem), float(ftol), float(gtol),
+                                    float(fd_step), 1 if ignore_prior else 0, ptr(x), ptr(fun),
+                                    nit.ctypes.data_as(C.c_void_p), nfev.ctypes.data_as(C.c_void_p),
+                                    status.ctypes.data_as(C.c_void_p)), "carma_mle_batched")
+        return x, fun, nit, nfev, status
 
     def logprior(self, theta):
         theta = as_f64(theta)

@@ -22,6 +22,11 @@ class BatchResult(object):
         return "BatchResult(fun=%r, nit=%d, success=%r)" % (self.fun, self.nit, self.success)
 
 
+# status codes of carma_mle_batched (include/carma_mi355.h) in the words this module uses
+STATUS_TEXT = ("converged: projected gradient <= gtol", "converged: relative reduction of f <= ftol",
+               "maximum number of iterations reached", "line search failed")
+
+
 def _project(x, lo, hi):
     return np.minimum(np.maximum(x, lo), hi)
 

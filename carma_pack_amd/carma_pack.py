@@ -531,6 +531,16 @@ class CarmaModel(object):
                 starts[out, j] = rng.uniform(lo, hi, int(out.sum()))
 
         if method == "batched":
+            # the lock-step optimiser inside the library (carma_mle.hip): no interpreter between the launches
+            from .batched_opt import BatchResult, STATUS_TEXT
+            xs, fs, nits, nfevs, sts = proc.minimizeBatch(starts, bnds)
+            results = [BatchResult(xs[i].copy(), float(fs[i]), int(nits[i]), int(nfevs[i]), int(sts[i]) < 2, STATUS_TEXT[int(sts[i])])
+                       for i in range(xs.shape[0])]
+            if return_all:
+                return results
+            results = [r for r in results if np.isfinite(r.fun) and r.fun < 1e299] or results
+            return min(results, key=lambda r: r.fun)
+        if method == "batched_py":                          # the same algorithm as a numpy loop (batched_opt.py)
             from .batched_opt import minimize_batched
             results = minimize_batched(lambda pts: -np.asarray(proc.getLogDensityBatch(pts)), starts, bnds)
             if return_all:

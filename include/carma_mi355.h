@@ -75,6 +75,21 @@ int carma_logdensity_batch(carma_ctx* h, const double* theta, int B, int ignore_
 int carma_logdensity_batch_dev(carma_ctx* h, const double* d_theta, int B, int ignore_prior,
                                double* d_out, void* stream);
 
+/*
+ * CarmaModel.get_mle (src/carmcmc/carma_pack.py:195-260: `ntrials` separate scipy L-BFGS-B searches, one FFI crossing
+ * per function evaluation) as ONE call: B bounded quasi-Newton searches on f(x) = -LogDensity(x) advanced in lock-step
+ * -- per iteration one batched launch evaluates the central-difference stencils of every active start, one more eight
+ * backtracking step lengths of every start; projected L-BFGS update (memory `mem`), stopping rules of L-BFGS-B
+ * (projected gradient <= gtol; relative decrease <= ftol, three iterations in a row after one restart of the memory).
+ * x0 = [B][d] starts; lo / hi = [d] box (NULL or non-finite entries = unbounded); maxiter per start; fd_step = relative
+ * finite-difference step; ignore_prior as carma_logdensity_batch (SetMLE(true), carma_pack.py:242).
+ * Outputs: x = [B][d], fun = [B] (-LogDensity at x), and optionally nit / nfev / status = [B]
+ * (0 converged on the gradient, 1 converged on f, 2 maxiter reached, 3 line search failed).
+ */
+int carma_mle_batched(carma_ctx* h, const double* x0, int B, const double* lo, const double* hi, int maxiter, int mem,
+                      double ftol, double gtol, double fd_step, int ignore_prior, double* x, double* fun, int* nit,
+                      int* nfev, int* status);
+
 /* Which kernel a launch of B evaluations on this context takes (the launch shape depends on B: DESIGN.md section 3);
  * the name as rocprofv3 lists it, without namespace and argument list.  For measurement scripts. */
 int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len);
