@@ -35,6 +35,11 @@ def test_no_cpu_fallback_without_gpu():
         cpa.Context(t, np.sin(t), np.ones(10), 3, 1)
     with pytest.raises(cpa.CarmaError):
         cpa.kfilter_car1(t, np.sin(t), np.ones(10), 1.0, 0.1)
+    # argument checks of the optimiser entry point come before any device work
+    import ctypes as C
+    x = np.zeros(4)
+    assert cpa._lib.lib.carma_mle_batched(None, x.ctypes.data_as(C.c_void_p), 1, None, None, 10, 8, 1e-9, 1e-5, 1e-6, 1,
+                                          x.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), None, None, None) == -22
 
 
 def test_product_never_touches_the_oracle():
