@@ -8,6 +8,8 @@ batched launch, the sampler runs on the GPU, and ``run_mcmc``/``get_mle`` can us
 replicas at once (``nreplicas``).  ``predict``/``simulate``/``assess_fit`` use the batched device
 Predict kernel (one launch for all requested times); plotting bodies are not part of the hot path.
 """
+import os
+
 import numpy as np
 from scipy.optimize import minimize
 
@@ -569,7 +571,16 @@ class CarmaModel(object):
             qmax = pmax - 1
         if pqlist is None:
             pqlist = [(p, q) for p in range(1, pmax + 1) for q in range(min(p, qmax + 1))]
-        MLEs = [self.get_mle(p, q, ntrials=ntrials, njobs=njobs, seed=seed, method=method) for p, q in pqlist]
+        # njobs (reference :131: processes of a multiprocessing pool, -1 = all cores): here THREADS, each driving its own
+        # orders -- every order has its own context and stream, the library calls release the interpreter lock, and the
+        # launches of one order (a few thousand evaluations) leave most of the chip to the others
+        nthreads = (os.cpu_count() or 1) if njobs is not None and njobs < 0 else max(1, int(njobs or 1))
+        if nthreads > 1 and len(pqlist) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(nthreads, len(pqlist))) as pool:
+                MLEs = list(pool.map(lambda pq: self.get_mle(pq[0], pq[1], ntrials=ntrials, seed=seed, method=method), pqlist))
+        else:
+            MLEs = [self.get_mle(p, q, ntrials=ntrials, njobs=njobs, seed=seed, method=method) for p, q in pqlist]
         AICc, best, best_aicc = [], MLEs[0], 1e300
         n = self.time.size
         for mle, (p, q) in zip(MLEs, pqlist):

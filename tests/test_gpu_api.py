@@ -161,6 +161,10 @@ def test_carma_model_mcmc_and_mle(cm, golden_dir):
         assert all(r.nit > 0 and r.nfev > r.nit and isinstance(r.message, str) for r in nat)
     best, pqlist, aicc = model.choose_order(2, ntrials=4, seed=7)
     assert pqlist == [(1, 0), (2, 0), (2, 1)] and len(aicc) == 3 and (model.p, model.q) in pqlist
+    # njobs: the orders driven by a pool of threads (one context and stream per order) -- same searches, same numbers
+    chosen = (model.p, model.q)
+    best4, pq4, aicc4 = model.choose_order(2, ntrials=4, seed=7, njobs=3)
+    assert pq4 == pqlist and aicc4 == aicc and (model.p, model.q) == chosen and np.array_equal(best4.x, best.x)
     sample.add_mle(mle) if sample.p == 2 else None
 
 
