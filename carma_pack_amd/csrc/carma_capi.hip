@@ -227,6 +227,11 @@ carma_ctx* carma_ctx_create(const double* time, const double* y, const double* y
     c->pr.measerr_dof = 50.0;   // src/include/carpack.hpp:63
     carma_ctx_set_prior(reinterpret_cast<carma_ctx*>(c), max_stdev);
     std::vector<double> s = pack_series(c->t, c->y, c->yerr);
+    {
+        int rep = 0;
+        for (int k = 2; k < c->n; k++) rep += (s[4 * (size_t)k] == s[4 * (size_t)(k - 1)]);
+        c->repeated_dt = c->n > 8 && 4 * rep >= c->n;
+    }
     hipError_t e = hipMalloc(&c->d_series, sizeof(double) * s.size());
     if (e == hipSuccess) e = hipMemcpy(c->d_series, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -302,7 +307,7 @@ int carma_logdensity_batch_dev(carma_ctx* h, const double* d_theta, int B, int i
         e = launch_logdens_car1(d_theta, B, reinterpret_cast<const double4*>(c->d_series), c->n, c->pr, d_out, st);
     else
         e = launch_logdens_carma(c->p, d_theta, B, c->d, c->q, reinterpret_cast<const double4*>(c->d_series), c->n, c->pr,
-                                 ignore_prior, d_out, st);
+                                 ignore_prior, d_out, st, c->repeated_dt);
     if (e != hipSuccess) return hip_fail(e, "launch logdensity");
     return CARMA_OK;
 }
@@ -349,7 +354,7 @@ int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len)
 {
     if (!h || !buf || len < 1 || B < 1) return CARMA_EINVAL;
     const Ctx* c = reinterpret_cast<const Ctx*>(h);
-    return logdens_kernel_name(c->p, B, c->n, buf, len) > 0 ? CARMA_OK : CARMA_EINVAL;
+    return logdens_kernel_name(c->p, B, c->n, buf, len, c->repeated_dt) > 0 ? CARMA_OK : CARMA_EINVAL;
 }
 
 int carma_normalize_roots(int p, const double* omega_re_im, double* out)

@@ -42,6 +42,7 @@ struct Ctx {
     int p = 0, q = 0, d = 0, n = 0;
     std::vector<double> t, y, yerr;   // after sort/dedup
     Prior pr{};
+    bool repeated_dt = false;         // >= 25 % of the time steps equal their predecessor (regular cadence)
     double* d_series = nullptr;       // records {dt, y, yerr^2, t}[n + 16 pads], then yerr^2[n + 16], y[n + 16] (carma_types.h)
     double* d_theta = nullptr;        // staging for the host-pointer entry points
     double* d_out = nullptr;

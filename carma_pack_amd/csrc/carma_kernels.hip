@@ -32,7 +32,7 @@ struct GroupOf {
     static constexpr int value = P <= 2 ? 2 : (P <= 4 ? 4 : 8);
 };
 
-template <int P, int G, int WAVES>
+template <int P, int G, int WAVES, bool DTC = false>
 __global__ __launch_bounds__(64 * WAVES) void k_logdens_carma(const double* __restrict__ theta, int B, int d, int q,
                                                              const double4* __restrict__ series, int n, Prior pr,
                                                              int ignore_prior, double* __restrict__ out)
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_logdens_carma(const double* __re
     long e = ((long)blockIdx.x * (64 * WAVES) + tid) / G;
     const bool live = e < B;
     if (!live) e = B - 1;
-    double ll = logdensity_carma<P, G>(g, theta + e * d, q, series, n, pr, ignore_prior);
+    double ll = logdensity_carma<P, G, Grp<G>, DTC>(g, theta + e * d, q, series, n, pr, ignore_prior);
     if (live && g.lane() == 0) out[e] = ll;
 }
 
@@ -291,7 +291,7 @@ static LdShape logdens_shape(long B, int n)
 
 template <int P>
 static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, const double4* series, int n,
-                                   const Prior& pr, int ignore_prior, double* out, hipStream_t st)
+                                   const Prior& pr, int ignore_prior, double* out, hipStream_t st, bool repeated_dt)
 {
     constexpr int G = GroupOf<P>::value;
     constexpr int EPW = 64 / G;   // evaluations per wave
@@ -317,56 +317,65 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
         case LdShape::PC2: return launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);
         case LdShape::PLAIN1:
             // spread the waves over as many CUs as possible (1 wave per workgroup) until the chip is covered
-            hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n, pr,
-                               ignore_prior, out);
+            if (repeated_dt)
+                hipLaunchKernelGGL((k_logdens_carma<P, G, 1, true>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series,
+                                   n, pr, ignore_prior, out);
+            else
+                hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n,
+                                   pr, ignore_prior, out);
             return hipGetLastError();
         case LdShape::PLAIN4:
-            hipLaunchKernelGGL((k_logdens_carma<P, G, 4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, theta, B, d, q,
-                               series, n, pr, ignore_prior, out);
+            if (repeated_dt)
+                hipLaunchKernelGGL((k_logdens_carma<P, G, 4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, theta, B,
+                                   d, q, series, n, pr, ignore_prior, out);
+            else
+                hipLaunchKernelGGL((k_logdens_carma<P, G, 4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, theta, B, d, q,
+                                   series, n, pr, ignore_prior, out);
             return hipGetLastError();
     }
     return hipErrorInvalidValue;
 }
 
 template <int P>
-static int logdens_name_p(long B, int n, char* buf, int len)
+static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
 {
+    const char* dtc = repeated_dt ? ",true" : "";
     constexpr int G = GroupOf<P>::value;
     switch (logdens_shape<P>(B, n)) {
         case LdShape::P3L: return snprintf(buf, len, "k_logdens_carma_p3l<%d>", P);
         case LdShape::PC1: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,1>", P, G);
         case LdShape::PC2: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,2>", P, G);
-        case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1>", P, G);
-        case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4>", P, G);
+        case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1%s>", P, G, dtc);
+        case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4%s>", P, G, dtc);
     }
     return -1;
 }
 
-int logdens_kernel_name(int p, long B, int n, char* buf, int len)
+int logdens_kernel_name(int p, long B, int n, char* buf, int len, bool repeated_dt)
 {
     switch (p) {
         case 1: return snprintf(buf, len, "k_logdens_car1");
-        case 2: return logdens_name_p<2>(B, n, buf, len);
-        case 3: return logdens_name_p<3>(B, n, buf, len);
-        case 4: return logdens_name_p<4>(B, n, buf, len);
-        case 5: return logdens_name_p<5>(B, n, buf, len);
-        case 6: return logdens_name_p<6>(B, n, buf, len);
-        case 7: return logdens_name_p<7>(B, n, buf, len);
+        case 2: return logdens_name_p<2>(B, n, buf, len, repeated_dt);
+        case 3: return logdens_name_p<3>(B, n, buf, len, repeated_dt);
+        case 4: return logdens_name_p<4>(B, n, buf, len, repeated_dt);
+        case 5: return logdens_name_p<5>(B, n, buf, len, repeated_dt);
+        case 6: return logdens_name_p<6>(B, n, buf, len, repeated_dt);
+        case 7: return logdens_name_p<7>(B, n, buf, len, repeated_dt);
         default: return -1;
     }
 }
 
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,
-                                const Prior& pr, int ignore_prior, double* out, hipStream_t st)
+                                const Prior& pr, int ignore_prior, double* out, hipStream_t st, bool repeated_dt)
 {
     (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     switch (p) {
-        case 2: return launch_logdens_p<2>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
-        case 3: return launch_logdens_p<3>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
-        case 4: return launch_logdens_p<4>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
-        case 5: return launch_logdens_p<5>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
-        case 6: return launch_logdens_p<6>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
-        case 7: return launch_logdens_p<7>(theta, B, d, q, series, n, pr, ignore_prior, out, st);
+        case 2: return launch_logdens_p<2>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
+        case 3: return launch_logdens_p<3>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
+        case 4: return launch_logdens_p<4>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
+        case 5: return launch_logdens_p<5>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
+        case 6: return launch_logdens_p<6>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
+        case 7: return launch_logdens_p<7>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
         default: return hipErrorInvalidValue;
     }
 }

@@ -6,11 +6,13 @@
 
 namespace carma {
 
+// repeated_dt: a good part of the series' time steps equal their predecessor (regular cadence): the throughput kernels
+// then run the variant that re-uses the transition factors of such steps (carma_core.h, RhoInline DTC)
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,
-                                const Prior& pr, int ignore_prior, double* out, hipStream_t st);
+                                const Prior& pr, int ignore_prior, double* out, hipStream_t st, bool repeated_dt = false);
 // name of the kernel launch_logdens_* picks for B evaluations of a series of n points (as rocprofv3 prints it, up to
 // the namespace and the argument list)
-int logdens_kernel_name(int p, long B, int n, char* buf, int len);
+int logdens_kernel_name(int p, long B, int n, char* buf, int len, bool repeated_dt = false);
 hipError_t launch_logdens_car1(const double* theta, int B, const double4* series, int n, const Prior& pr, double* out,
                                hipStream_t st);
 hipError_t launch_kfilter_carma(int p, const double* om_re_im, const double* ma, double sigsqr, const double4* series,

@@ -578,6 +578,37 @@ def test_sampler_states_with_extreme_ma_parameters(cpa, readme):
         assert np.max(np.abs(got[:5] - tr) / np.abs(tr)) < 1e-12      # and in fact exact to rounding
 
 
+@pytest.mark.parametrize("p,q", [(2, 1), (5, 3), (7, 4)])
+def test_regular_cadence_series(cpa, p, q):
+    """A regularly sampled series (constant dt, two gaps, a stretch of alternating steps): the throughput kernels run
+    the variant that re-uses the transition factors of steps whose dt repeats (carma_core.h, RhoInline / RhoPair DTC).
+    Every launch shape against the oracle; real-pair thetas in the batch so that both factor sources are exercised."""
+    from helpers import loglik_truth
+    n = 150
+    t = 2.0 * np.arange(n, dtype=float)
+    t[60:] += 37.0
+    t[110:] += 11.5
+    t[20:40:2] += 0.5                                             # alternating steps 2.5 / 1.5
+    rng = np.random.default_rng(4300 + 10 * p + q)
+    y = 5.0 + np.sin(t / 9.0) + 0.3 * rng.standard_normal(n)
+    yerr = np.full(n, 0.3) * rng.uniform(0.8, 1.2, n)
+    ctx = cpa.Context(t, y, yerr, p, q)
+    assert ctx.kernel_name(70000).endswith(",true>")
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(32)])
+    r1 = 10.0 ** rng.uniform(-2.0, -0.5, 8)
+    th[:8, 3], th[:8, 4] = np.log(r1 * r1 * 7.0), np.log(r1 * 8.0)  # one quadratic factor with two real roots
+    want = m.logdensity_batch(th, ignore_prior=True)
+    for B in (32, 3200, 9600, 70016):
+        got = ctx.logdensity(np.tile(th, (B // 32, 1)), ignore_prior=True)
+        assert np.array_equal(got, np.tile(got[:32], B // 32), equal_nan=True), ctx.kernel_name(B)
+        assert_parity(got[:32], want, RTOL, "regular cadence p=%d q=%d %s" % (p, q, ctx.kernel_name(B)),
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
+    # an irregular series keeps the plain variant
+    ti = np.cumsum(rng.uniform(1.0, 3.0, n))
+    assert not cpa.Context(ti, y, yerr, p, q).kernel_name(70000).endswith(",true>")
+
+
 @pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
 def test_prior_like_sweep_never_worse_than_reference(cpa, p):
     """Every order (p, q < p) x 200 random PRIOR-LIKE parameter vectors -- the nastiest inputs the sampler can meet:
