@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight leg")
     ap.add_argument("--no-throughput", action="store_true", help="skip the throughput-regime leg (B = 65536)")
     ap.add_argument("--no-ladder", action="store_true", help="skip the ladder-sharded leg (BASELINE configs[3] shape)")
+    ap.add_argument("--ladder-timeout", type=float, default=180.0,
+                    help="N > 1: seconds after which the run ends without the ladder-sharded leg (it is the only leg with an "
+                         "exchange between the ranks)")
     ap.add_argument("--ladder-iters", type=int, default=150)
     args = ap.parse_args()
 
@@ -246,14 +249,7 @@ def main():
                           "note": "algorithmic flop count of the reference's complex recursion (SURVEY.md 8d)"},
         }
 
-    # ---- ONE ladder sharded across the ranks (BASELINE configs[3]: CARMA(7,6), n = 10^4, 8 temperatures) -------
-    ladder = None
-    if not args.no_ladder and 8 % world == 0:
-        try:
-            ladder = ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, args.ladder_iters)
-        except Exception as ex:              # the headline line must not depend on this leg
-            ladder = {"metric": "MCMC iterations/s of ONE temperature ladder sharded across the ranks", "error": repr(ex)}
-
+    res = None
     if rank == 0:
         value = world * B * args.steps / elapsed
         bytes_per_eval = 24 * n + 8 * d + 8
@@ -339,6 +335,35 @@ def main():
             res["pipelined"] = pipelined
         if tput is not None:
             res["throughput"] = tput
+
+    # ---- ONE ladder sharded across the ranks (BASELINE configs[3]: CARMA(7,6), n = 10^4, 8 temperatures) -------
+    # Last, and at N > 1 under a watchdog: this leg is the only one with a data-path exchange (RCCL send/recv between the
+    # ranks), and the headline line must not depend on it -- neither on an exception nor on a collective that never
+    # returns.  If the leg has not finished in time every rank leaves; rank 0 prints the line without it first.
+    ladder = None
+    if not args.no_ladder and 8 % world == 0:
+        LADDER_TEXT = "MCMC iterations/s of ONE temperature ladder sharded across the ranks"
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    res["ladder_sharded"] = {"metric": LADDER_TEXT, "error": "no result after %d s" % args.ladder_timeout}
+                    print(json.dumps(res), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(args.ladder_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            ladder = ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, args.ladder_iters)
+        except Exception as ex:
+            ladder = {"metric": LADDER_TEXT, "error": repr(ex)}
+        if watchdog is not None:
+            watchdog.cancel()
+
+    if rank == 0:
         if ladder is not None:
             res["ladder_sharded"] = ladder
         if world == 1 and not args.no_cpu:

@@ -64,3 +64,17 @@ def test_two_ranks_sharing_the_gpu():
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 2 * 1024) < 1e-6 * 2048          # whole-job aggregate
     ld = j["ladder_sharded"]                                                 # one ladder of 8 temperatures, 4 per rank
     assert ld["temperatures_per_rank"] == 4 and ld["scaling"] == "strong" and 0.0 < ld["boundary_swap_rate_rank0"] < 1.0
+
+
+def test_ladder_leg_cannot_hold_the_line_back():
+    """The ladder-sharded leg is the only one with an exchange between the ranks; a collective that never returns must not
+    cost the run its JSON line: with a watchdog of 10 ms every rank leaves and rank 0 prints the line without the leg."""
+    env = dict(os.environ, CARMA_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "50", "--warmup", "5", "--no-mcmc", "--no-pipelined", "--no-throughput",
+                        "--ladder-iters", "200", "--ladder-timeout", "0.01"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["value"] > 1e6 and "no result after" in j["ladder_sharded"]["error"]
