@@ -1,4 +1,4 @@
-// carma_pipe3l.h -- the wave pipeline of the latency regime (<= 1024 evaluations), in a CO-ROTATING FRAME (gfx950 only).
+// carma_pipe3l.h -- the wave pipeline of the latency regime (<= 3072 evaluations), in a CO-ROTATING FRAME (gfx950 only).
 // One evaluation per 16-lane DPP row, four evaluations per workgroup; the step is cut between the covariance recursion
 // (which does not depend on the data) and the mean recursion, and the two halves run on different SIMDs one chunk apart.
 //
@@ -12,15 +12,21 @@
 // element the arithmetic is the same as the rotated recursion up to the scale factors e^{+-Re(omega) dt}, which
 // cancel in every product (numpy prototype tests/tools/proto/lazy_frame.py: the same error against the reference
 // restatement as the stepwise rotation, 1e-12 at worst over the bench batch).
-// RE-BASE: before |Re omega| dt_acc could overflow the scale factors or |Im omega| dt_acc cost angle accuracy the
-// accumulated rotation is applied for real (S <- A S A^T, z <- A z~; column mix by DPP, row mix with the pair partner) and the
-// frame restarts at the identity.  The schedule is a time grid per evaluation: datum j is a re-base datum when
+// RE-BASE: before |Re omega| dt_acc could overflow the scale factors the accumulated rotation is applied for real
+// (S <- A S A^T, z <- A z~; column mix by DPP, row mix with the pair partner) and the frame restarts -- not at the identity
+// but HALF A WINDOW AHEAD, at the scale g_r = e^{-Re omega_r W/2}, so that a root's scale factor runs from e^+200 to e^-200
+// over a window instead of from 1 to e^-200: windows twice as long for the same bound on S.  (The phase does not limit the
+// window: the producers recover the rounding of Im omega x dt_acc with an FMA.)  The modal coordinates themselves are
+// rescaled by exact powers of two so that |h_r| is of order one -- the sampler's unconstrained MA parameters otherwise
+// give h_r ~ 1e115, c_r ~ 1e-115.  The schedule is a time grid per evaluation: datum j is a re-base datum when
 // floor(t_j 2^ex) != floor(t_{j-1} 2^ex), 2^-ex <= min over the roots of (LIM_RE / |Re omega|, LIM_IM / |Im omega|);
 // the accumulated time of a non-re-base datum is therefore < 2^-ex.  (Dyadic cells nest: the waves branch on the
 // union of the four evaluations' masks -- that of the finest grid -- and a row without a re-base of its own at such a
 // datum rotates by the identity, so an evaluation's result does not depend on its neighbours in the batch.)  A
-// re-base datum's ring entry holds the accumulated (E cos, E sin) instead of (h~, c~) -- there h~ = h, c~ = c --
-// and a 16-bit mask per chunk tells the recursion waves which data those are.  The producers need h and c: they
+// re-base datum's ring entry holds the accumulated (E cos, E sin) instead of (h~, c~) -- there h~ = g h, c~ = c / g,
+// published once by the producers -- and a 16-bit mask per chunk tells the recursion waves which data those are; a
+// chunk whose mask is zero (the rule for posterior-like parameters) runs a copy of the passes without any check.
+// A last chunk of 11..15 data is completed to 16 with neutral pad data (carma_types.h, p3l_pad).  The producers need h and c: they
 // evaluate the exp/sincos of chunk 0 while the recursion waves set the model up, wait for the covariance wave to
 // publish (h_r, c_r), and only then form the entries of chunk 0.
 //
