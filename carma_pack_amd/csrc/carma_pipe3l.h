@@ -79,11 +79,13 @@ struct Pipe3LGeom {
     static constexpr int TAIL_OFF = FLAG_OFF + 2;               // double[2][C]: yerr^2 (wave A) and y (wave B) of the last, partial chunk
     static constexpr int ENTRIES = TAIL_OFF + C;
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 41.8 KiB
-    static constexpr double LIM_RE = 400.0;                     // |Re omega| x window: the scale factor of a root runs from
-                                                                // e^+200 at a re-base to e^-200 at the end of the window (the
+    static constexpr double LIM_RE = 600.0;                     // |Re omega| x window: the scale factor of a root runs from
+                                                                // e^+300 at a re-base to e^-300 at the end of the window (the
                                                                 // frame starts HALF a window ahead), so S carries factors within
-                                                                // e^+-400 (5e173: room for variances from 1e-130 to 1e130)
-                                                                // -- twice the window of a frame that starts at the identity
+                                                                // e^+-600 (4e260) -- three times the window of a frame that
+                                                                // starts at the identity and stops at e^-200.  The modal
+                                                                // coordinates are rescaled so that S itself is of order one
+                                                                // (times the conditioning of the modal basis, < 1e13) in any units
     static constexpr double LIM_IM = 262144.0;                  // |Im omega| dt_acc: the producers recover the rounding of the phase
                                                                 // product (cexp_step<true>), so the window is set by the decay of
                                                                 // the scale factors alone unless Q = |Im|/|Re| exceeds 1300; the
@@ -128,6 +130,12 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     // a quadratic factor with positive discriminant puts two different REAL roots into the pair: the second one then
     // gets its own exponential (no sine / cosine either way)
     const Cx w1 = two ? own_ar_root<P>(theta, jr + 1) : w;
+    int esig = 0;                                             // binary exponent of sigma_y = theta[0] (see the rescaling below)
+    {
+        const double sg = fabs(theta[0]);
+        (void)frexp(sg, &esig);
+        if (!(sg > 0.0 && sg < 1.0 / 0.0)) esig = 0;
+    }
     const bool realpair = two && w.im == 0.0;
     const int nc = (n + C - 1) / C;
     if (pw == 0 && l >= P) {                                  // entries of the idle lanes: exact zeros
@@ -238,8 +246,10 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
                 (void)frexp(m1, &e1x);
                 if (!(m0 > 0.0 && m0 < 1.0 / 0.0)) e0 = 0;
                 if (!(m1 > 0.0 && m1 < 1.0 / 0.0)) e1x = 0;
-                hc_own = make_double2(ldexp(hc_own.x, -e0), ldexp(hc_own.y, e0));
-                hc_par = make_double2(ldexp(hc_par.x, -e1x), ldexp(hc_par.y, e1x));
+                // ... and by the power of two of sigma_y = sqrt(s0) on top: |h_r| ~ sigma_y, c_r ~ sigma_y, D of order one
+                // whatever units the data come in, so that the frame's e^+-LIM_RE has the whole exponent range to itself
+                hc_own = make_double2(ldexp(hc_own.x, esig - e0), ldexp(hc_own.y, e0 - esig));
+                hc_par = make_double2(ldexp(hc_par.x, esig - e1x), ldexp(hc_par.y, e1x - esig));
             }
             if (pw == 0 && l < NPAIR) {                       // (h~, c~) right after a re-base, for the recursion waves
                 double2* cst2 = reinterpret_cast<double2*>(ring + Geo::CONST2_OFF) + Geo::row_base(lane);

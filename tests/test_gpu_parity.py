@@ -609,6 +609,34 @@ def test_regular_cadence_series(cpa, p, q):
     assert not cpa.Context(ti, y, yerr, p, q).kernel_name(70000).endswith(",true>")
 
 
+@pytest.mark.parametrize("unit", [1e-60, 1e-7, 1e9, 1e45])
+def test_units_of_the_data_do_not_matter(cpa, unit):
+    """Fluxes in erg/s or in units of 1e-60: the co-rotating frame keeps e^+-600 of exponent range for itself, so the
+    modal coordinates are rescaled to be of order one whatever the data's units (carma_pipe3l.h).  The same series and
+    parameter vectors multiplied through by `unit`, every launch shape, against the oracle on the scaled problem."""
+    from helpers import loglik_truth
+    p, q = 5, 3
+    rng = np.random.default_rng(77)
+    n = 150
+    dt = rng.uniform(0.2, 2.0, n)
+    dt[rng.integers(5, n - 5, 4)] = 10.0 ** rng.uniform(1.0, 3.0, 4)
+    t = np.cumsum(dt)
+    y0 = 3.0 + np.sin(t / 3.0) + 0.3 * rng.standard_normal(n)
+    e0 = np.full(n, 0.3) * rng.uniform(0.7, 1.3, n)
+    th0 = np.array([prior_like_theta(rng, p, q, t, y0) for _ in range(24)])
+    y, yerr, th = unit * y0, unit * e0, th0.copy()
+    th[:, 0] *= unit
+    th[:, 2] *= unit
+    ctx = cpa.Context(t, y, yerr, p, q)
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    want = m.logdensity_batch(th, ignore_prior=True)
+    assert np.isfinite(want).sum() >= 20
+    for B in (24, 3600, 72000):
+        got = ctx.logdensity(np.tile(th, (B // 24, 1)), ignore_prior=True)[:24]
+        assert_parity(got, want, RTOL, "unit %g %s" % (unit, ctx.kernel_name(B)),
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
+
+
 @pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
 def test_prior_like_sweep_never_worse_than_reference(cpa, p):
     """Every order (p, q < p) x 200 random PRIOR-LIKE parameter vectors -- the nastiest inputs the sampler can meet:
