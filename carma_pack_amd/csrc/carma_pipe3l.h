@@ -335,22 +335,26 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c
+        // yerr_j^2 is wave-uniform: the chunk's sixteen values in two wide scalar loads from the plain array behind the
+        // records (scalar-memory and LDS returns share a counter, so a scalar load inside a pass would drain the LDS
+        // prefetch every step).  Requested FIRST, so that their latency runs under that of the LDS reads below.
+        j0 = c * C;
+        const int len = (n - c * C < C) ? n - c * C : C;
+        double ev[C];
+        if (len == C) {
+#pragma unroll
+            for (int s = 0; s < C; s++) ev[s] = e_arr[j0 + s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + Geo::entry(lane);
         link_b = reinterpret_cast<double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + Geo::entry(lane);
         hc_n = ring_b[0];
         if (c == 0) hc0 = reinterpret_cast<const double2*>(ring + Geo::CONST2_OFF)[Geo::entry(lane)];
-        j0 = c * C;
         const unsigned long long fm64 = flag_b[c % 3];
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
         const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
-        const int len = (n - c * C < C) ? n - c * C : C;
         if (len == C) {
-            // yerr_j^2 is wave-uniform: sixteen scalar loads from the series itself, waited for ONCE (scalar-memory and
-            // LDS returns share a counter, so a scalar load inside the pass would drain the LDS prefetch every step)
-            double ev[C];
-#pragma unroll
-            for (int s = 0; s < C; s++) ev[s] = e_arr[j0 + s];
             if (fm == 0) {
                 // no re-base in this chunk (the rule for posterior-like parameters): a copy of the passes without the
                 // sixteen skip-branches -- a TAKEN branch over the re-base block costs the wave ~30 cycles, every datum
@@ -445,21 +449,24 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
     h_own = reinterpret_cast<const double2*>(ring + Geo::CONST2_OFF)[Geo::entry(lane)].x;    // g_r h_r: h~ at a re-base datum
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c + 1: wave A has finished chunk c
+        // y_j: two wide scalar loads, requested first (as yerr_j^2 in the covariance wave)
+        j0 = c * C;
+        const int len = (n - c * C < C) ? n - c * C : C;
+        double yv[C];
+        if (len == C) {
+#pragma unroll
+            for (int s = 0; s < C; s++) yv[s] = y_arr[j0 + s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + Geo::entry(lane);
         link_b = reinterpret_cast<const double2*>(ring + Geo::LINK_OFF) + (size_t)(c & 1) * C * Geo::SLOT + Geo::entry(lane);
         hc_n = ring_b[0];
         lk_n = link_b[0];
-        j0 = c * C;
         const unsigned long long fm64 = flag_b[c % 3];
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
         const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
-        const int len = (n - c * C < C) ? n - c * C : C;
         if (len == C) {
-            // y_j: scalar loads, as yerr_j^2 in the covariance wave
-            double yv[C];
-#pragma unroll
-            for (int s = 0; s < C; s++) yv[s] = y_arr[j0 + s];
             if (fm == 0) {
 #pragma unroll
                 for (int s = 0; s < C; s++) pass(s, s + 1 < C, false, yv[s]);
