@@ -14,6 +14,7 @@
 // series (24 B/datum, shared by every evaluation and L2/scalar-cache resident) + 8(d+1) B/eval.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -250,26 +251,29 @@ __global__ __launch_bounds__(64) void k_simulate_car1(double sigsqr, double omeg
 }
 
 // ---------------------------------------------------------------------------------------------
-// Largest launch (in workgroups of four evaluations) that takes the wave pipeline of carma_pipe3l.h: three workgroups
-// per CU (measured, tools/tput_probe.py).  CARMA_TUNE_P3L_ROWS overrides it for such measurements; read once.
-static int device_cus()
+// CUs of the CURRENT device, cached per device (contexts may live on different, or differently partitioned, devices)
+int device_cus()
 {
-    static const int v = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        return n;
-    }();
-    return v;
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
+// Largest launch (in workgroups of four evaluations) that takes the wave pipeline of carma_pipe3l.h: three workgroups
+// per CU (measured, tools/tput_probe.py).  CARMA_TUNE_P3L_ROWS overrides it for such measurements; read once.
 static long p3l_max_rows()
 {
-    static const long v = [] {
+    static const long tune = [] {
         const char* e = getenv("CARMA_TUNE_P3L_ROWS");
-        return e ? atol(e) : 768L;
+        return e ? atol(e) : -1L;
     }();
-    return v;
+    return tune >= 0 ? tune : 3L * device_cus();      // three workgroups per CU (registers and LDS allow exactly that)
 }
 
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)

@@ -6,6 +6,9 @@
 
 namespace carma {
 
+// compute units of the current device (cached per device)
+int device_cus();
+
 // repeated_dt: a good part of the series' time steps equal their predecessor (regular cadence): the throughput kernels
 // then run the variant that re-uses the transition factors of such steps (carma_core.h, RhoInline DTC)
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,

@@ -198,12 +198,7 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
         // wins while a CU holds at most one ladder (12.3k vs 8.0k it/s at 16 x 256) and loses once the ladders queue up
         // for the SIMDs (3.1k vs 4.0k it/s at 16 x 1024, tools/mcmc_bigR_probe.py; the plain chain waves share the
         // exp/sincos inside root pairs, RhoPair).  CARMA_PT_PLAIN=0/1 overrides.
-        static const int ncu = [] {
-            int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            return n;
-        }();
-        bool plain = L.R > (long)ncu;
+        bool plain = L.R > (long)device_cus();
         static const int force_plain = [] {                 // CARMA_PT_PLAIN=0/1, read once
             const char* fp = getenv("CARMA_PT_PLAIN");
             return fp ? (fp[0] == '1' ? 1 : 0) : -1;
@@ -233,40 +228,57 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
 //
 // Why: with one ladder per workgroup (k_pt) a CU hosts 2 chain waves + 2 producer waves, and a Kalman
 // step costs the CU ~2200 SIMD-cycles -- the kernel is bound by the issue rate of ONE CU while 3/4 of
-// the chip idles (16 temperatures x 64 replicas use 64 of 256 CUs).  The row loop needs ~450 cycles per
+// the chip idles (16 temperatures x 64 replicas use 64 of 256 CUs).  The row loop needs ~200 cycles per
 // step and chain instead of ~560, and spreading the ladder gives every group of 4 chains its own CU.
 // The price is that the swap sweep crosses workgroups: once per iteration the ladder's workgroups
 // publish (theta, log-posterior) to global memory, meet at an arrival counter (all of them are
-// resident: the host only picks this kernel when the whole grid fits the chip), and every workgroup
-// replays the same hot->cold decisions (exchange_decide, same counter-based uniforms) for its ladder.
-// Staging is double buffered, so a workgroup can run at most one exchange ahead of the slowest one.
-// The launch is cooperative (the runtime guarantees co-residency of the grid).  A barrier that nevertheless does not
-// complete within ~seconds sets abort_flag and the launch ends -- the host restores the chunk and re-runs it with the
-// ladder kernel -- instead of hanging the GPU.
-template <int P>
-__global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
-                                                const double* __restrict__ temps, double* __restrict__ theta,
-                                                double* __restrict__ logpost, double* __restrict__ chol,
-                                                unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,
-                                                double* __restrict__ samples, double* __restrict__ sample_lp)
+// resident: the launch is cooperative), and every workgroup replays the same hot->cold decisions
+// (exchange_decide, same counter-based uniforms) for its ladder.  Staging is double buffered, so a
+// workgroup can run at most one exchange ahead of the slowest one.  A rendezvous that nevertheless does
+// not complete within ~seconds sets abort_flag and the launch ends -- the host restores the chunk and
+// re-runs it with the ladder kernel -- instead of hanging the GPU.
+//
+// Round 3: EVERY PART HAS ITS OWN LOOP.  The four waves of a workgroup play four parts (covariance recursion, mean
+// recursion, two producers).  In round 2 they shared one iteration loop and branched on the part inside it, so every
+// part's values were live across every other part's code: 256 VGPRs + 108 AGPRs, one workgroup per CU.  Now each part
+// runs its own loop (the waves meet at barriers only, which count arrivals, not program counters), and the register
+// count is that of the hungriest part alone: the chains (theta, the proposal, column j of the RAM Cholesky factor in
+// lane j: carma_pt_row.h) stay with the covariance wave, the leanest one (72 registers for the recursion + 40 for the
+// chain), and the kernel fits the 168 registers that let THREE workgroups share a CU -- what 16 x 65..192 ladders need
+// to keep this kernel.  The swap step is split between the two recursion waves: the chain wave accepts, publishes its
+// chains, then adapts the proposal factor and forms the next proposal's (z, R^T z); MEANWHILE the mean wave -- idle
+// once it has handed the log-density over -- waits for the ladder at the rendezvous, fetches the staged log-posteriors
+// and parameter vectors and replays the sweep.  The two meet at a barrier, the chain wave picks up what the sweep
+// assigned to its rows, adds R^T z and the next filter starts.
+// MINW = workgroups of this kernel a CU is to hold (waves per SIMD): 2 -> up to 256 registers, nothing spilled; 3 -> 168
+// registers, where the cold code of the swap step and of the random-number tails spills a few values around itself (the
+// recursion loops do not).  The host takes MINW = 3 only for grids of more than two workgroups per CU.
+template <int P, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
+                                                   const double* __restrict__ temps, double* __restrict__ theta,
+                                                   double* __restrict__ logpost, double* __restrict__ chol,
+                                                   unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,
+                                                   double* __restrict__ samples, double* __restrict__ sample_lp)
 {
     constexpr int G = 16, CPW = 4;                         // lanes per chain, chains per workgroup
     extern __shared__ double4 smem4[];
     const int tid = threadIdx.x, lane64 = tid & 63;
-    const int wave = tid >> 6;                             // 0: chains + covariance recursion, 1: mean recursion, 2, 3: producers
-    const bool producer = wave != 0;                        // "not the chain-owning wave"
+    // which wave plays which part: as in k_logdens_carma_p3l (workgroups i, i + ncu, i + 2 ncu share a CU)
+    //                 part of wave:  0  1  2  3      (0 covariance + chains, 1 mean + swap sweep, 2 / 3 producers)
+    const int round = (blockIdx.x >= (unsigned)S.ncu) + (blockIdx.x >= 2u * (unsigned)S.ncu);
+    const int wave = ((round == 0 ? 0xE4 : round == 1 ? 0xD2 : 0x36) >> (2 * (tid >> 6))) & 3;
     const int d = L.d, T = L.T;
     Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3l.h rings
     double* s_thn = reinterpret_cast<double*>(ring + Pipe3LGeom<P>::ENTRIES);  // [CPW][16] proposals
     double* s_ll = s_thn + CPW * PT_DMAX;                  // [CPW] log-density of the proposals (mean wave -> chain wave)
-    double* s_lp = s_ll + CPW;                             // [T] the ladder's log-posteriors (exchange)
+    double* s_lp = s_ll + CPW;                             // [T] the ladder's log-posteriors after the sweep
     double* s_dbeta = s_lp + T;
     double* s_logu = s_dbeta + T;
     unsigned* s_nswap = reinterpret_cast<unsigned*>(s_logu + T);
-    int* s_src = reinterpret_cast<int*>(s_nswap + T);
+    int* s_src = reinterpret_cast<int*>(s_nswap + T);      // [T] whose parameter vector temperature i holds after the sweep
     int* s_flag = s_src + T;                               // [1] abort seen (+ pad)
     double* s_z = reinterpret_cast<double*>(s_flag + 2);   // [64] next iteration's t8 variates, drawn by producer wave 0
-    double* s_lu = s_z + 64;                               // [64] next exchange's log-uniforms (T <= 64), same
+    double* s_lu = s_z + 64;                               // [64] this exchange's log-uniforms (T <= 64), producer wave 1
     double* s_step = s_lu + 64;                            // [1] this iteration's adaptation step length (+ pad), same
     double* s_tha = s_step + 2;                            // [T][d] the ladder's staged parameter vectors (T <= 64)
     const long lad = blockIdx.x / S.wpl;                   // local replica (ladder) index
@@ -286,60 +298,48 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
     // rows past the ladder's end shadow its last chain: uniform control flow, nothing written back
     const int cc = active ? c : T - 1;
     double* thn_lds = s_thn + row * PT_DMAX;
-    // chain state in registers (carma_pt_row.h): lane j owns component j and column j of R
-    RowChain ch;
-    ch.th = j < d ? theta[(ch0 + cc) * d + j] : 0.0;
-    ch.thn = ch.th;
-    ch.z = ch.v = 0.0;
-#pragma unroll
-    for (int k = 0; k < PT_DMAX; k++) ch.Rc[k] = (j < d && k <= j) ? chol[(ch0 + cc) * d * d + (size_t)k * d + j] : 0.0;
     const uint32_t chain_base = (uint32_t)((L.replica0 + lad) * L.T_global + L.slot0);
-    RngKey key{L.seed0, L.seed1, chain_base + (uint32_t)cc};
-    double lp = logpost[ch0 + cc];
-    const double temperature = temps[cc];
-    unsigned nacc = 0, nexch = 0;
-    int buf = 0;
+    const RngKey key{L.seed0, L.seed1, chain_base + (uint32_t)cc};
+    const int npad = p3l_pad(L.n);                         // neutral pad data completing the last chunk (carma_types.h)
+    const bool exch = L.do_exchange && T > 1;
     const size_t nchain_all = (size_t)L.R * T;
     __syncthreads();
+    // Barriers of one iteration, the same for every part: "proposals visible", the pipeline's own (carma_pipe3l.h),
+    // "log-densities visible", "sweep done".
 
-    CARMA_STAMP_DECL;
-#if defined(CARMA_STAMPS)
-    unsigned long long st5 = 0, st6 = 0, st7 = 0;
-#endif
-    const int npad = p3l_pad(L.n);                         // neutral pad data completing the last chunk (carma_types.h)
-    for (int it = 0; it < L.niter; it++) {
-        const uint64_t iter = L.iter0 + (uint64_t)it;
-        double znorm2 = 0.0;
-        CARMA_STAMP(st0);
-        if (!producer) znorm2 = ram_propose_row(g, ch, d, iter, key, thn_lds, it > 0 ? s_z + lane64 : nullptr);
-        CARMA_STAMP(st1);
-        __syncthreads();                                   // proposals visible to the producer wave
-        CARMA_STAMP(st2);
-        // the wave pipeline of carma_pipe3l.h on the proposals; the mean wave hands the log-density back
-        if (wave >= 2) {
-            // the producers are done two chunks before the recursion waves: in that time they draw random numbers that
-            // are functions of key and iteration only -- P0 the NEXT iteration's proposal variates, P1 the logs of the
-            // swap uniforms of THIS iteration's exchange
+    if (wave >= 2) {
+        // ---- producers.  They are done two chunks before the recursion waves: in that time they draw random numbers
+        // that are functions of key and iteration only -- P0 the NEXT iteration's proposal variates and this iteration's
+        // adaptation step length, P1 the logs of the swap uniforms of THIS iteration's exchange
+        for (int it = 0; it < L.niter; it++) {
+            const uint64_t iter = L.iter0 + (uint64_t)it;
+            __syncthreads();                               // proposals visible
             pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [&](int pw) {
                 if (pw == 0) {
                     s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
                     if (lane64 == 0) *s_step = ram_adapt_step(d, iter);
-                } else if (L.do_exchange && T > 1 && T <= 64) {
+                } else if (exch && T <= 64) {
                     const int i = lane64 < T ? lane64 : T - 1;
                     RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
                     s_lu[lane64] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
                 }
             });
-        } else {
-            Model<P> m;
-            if (wave == 0) {
-                model_from_theta<P, G, MODEL_CONSTS>(g, thn_lds, L.q, pr, 0, m);
-                FilterConsts<P> fc;
-                filter_reset<P, G>(g, m, fc);
-                RowConsts<P> rc;
-                row_consts<P>(g, m, fc, rc);
-                pipe3l_cov<P>(g, m, rc, series, L.n + npad, npad, ring);
-            } else {
+            __syncthreads();                               // log-densities visible
+            __syncthreads();                               // sweep done
+            if (*s_flag) break;
+        }
+        return;
+    }
+
+    if (wave == 1) {
+        // ---- mean recursion of the four proposals, then the ladder's swap sweep (steps.hpp:318-362)
+        unsigned nexch = 0;
+        int buf = 0;
+        for (int it = 0; it < L.niter; it++) {
+            const uint64_t iter = L.iter0 + (uint64_t)it;
+            __syncthreads();                               // proposals visible
+            {
+                Model<P> m;
                 model_from_theta<P, G, MODEL_FLAGS>(g, thn_lds, L.q, pr, 0, m);
                 // before the recursion: off the critical path
                 double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], m.scale, series[L.n - 1].y, m.mu);
@@ -349,112 +349,161 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
                 if (m.sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;
             }
-        }
-        __syncthreads();                                   // log-densities visible to the chain wave
-        const bool exch = L.do_exchange && T > 1;
-        double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
-        double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
-        if (wave == 0) {
-            const double ll = s_ll[row];
-            CARMA_STAMP(st3);
-            double alpha;
-            if (ram_accept_row(ch, temperature, iter, key, ll, &lp, &alpha)) nacc++;
+            __syncthreads();                               // log-densities visible to the chain wave
             if (exch) {
-                // publish this workgroup's chains and ARRIVE at the ladder's rendezvous.  Agent-scope (write-through)
-                // stores and loads for the staged values instead of a device-wide fence: a release/acquire fence at
-                // agent scope writes back and invalidates the whole L2 of the XCD, and with 256 workgroups doing that
-                // every iteration the swap cost grew from 4 to 20 us (the L2-resident series had to be re-fetched each
-                // time).  The stores are complete (vmcnt) before the arrival counter is bumped; both by this wave.
-                if (active) {
-                    if (j < d) __hip_atomic_store(&st_th[(ch0 + c) * d + j], ch.th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (j == 0) __hip_atomic_store(&st_lp[ch0 + c], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_s_waitcnt(0);
-                if (tid == 0) __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            CARMA_STAMP(st4);
-            // the adaptation of the proposal factor does not touch the state: it runs while the other workgroups arrive
-            ram_adapt_row(g, ch, d, iter, L.maxiter, alpha, znorm2, *s_step);
-            CARMA_STAMP(st5);
-        }
-        if (exch) {
-            if (tid == 0) {
-                const unsigned target = (unsigned)S.wpl * (nexch + 1);
-                unsigned spins = 0;
-                while (__hip_atomic_load(&S.counter[lad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    if (__hip_atomic_load(S.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                        ++spins > 20000000u) {
-                        __hip_atomic_store(S.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        *s_flag = 1;
-                        break;
+                const double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
+                const double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
+                // wait for the ladder: every workgroup's chain wave bumps the counter once its chains are staged
+                int aborted = 0;
+                if (lane64 == 0) {
+                    const unsigned target = (unsigned)S.wpl * (nexch + 1);
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&S.counter[lad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (__hip_atomic_load(S.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                            ++spins > 20000000u) {
+                            __hip_atomic_store(S.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *s_flag = 1;
+                            aborted = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
                     }
-                    __builtin_amdgcn_s_sleep(4);
                 }
+                aborted = __builtin_amdgcn_readfirstlane(aborted);
+                if (!aborted) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (T <= 64) {
+                        // the ladder's staged parameter vectors into LDS, requested TOGETHER with the log-posteriors
+                        // (which vector a chain picks up is known only after the sweep; a load after it was one more
+                        // trip to L2).  Lane i owns temperature i, the sweep runs through v_readlane.
+                        for (int i = lane64; i < T * d; i += 64)
+                            s_tha[i] = __hip_atomic_load(&st_th[ch0 * d + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int i = lane64 < T ? lane64 : T - 1;
+                        double lp_i = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double logu_i = s_lu[lane64];           // drawn by producer wave 1 during the filter
+                        int src_i = i;
+                        bool sw;
+                        exchange_decide_wave(T, lane64, lp_i, s_dbeta[i], logu_i, src_i, &sw);
+                        if (lane64 < T) {
+                            if (sw) s_nswap[lane64]++;
+                            s_lp[lane64] = lp_i;
+                            s_src[lane64] = src_i;
+                        }
+                    } else {
+                        for (int i = lane64; i < T; i += 64) {
+                            s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_src[i] = i;
+                            RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
+                            s_logu[i] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+                        }
+                        g.sync();
+                        if (lane64 == 0) exchange_decide(T, s_lp, s_dbeta, s_logu, s_src, s_nswap);
+                    }
+                }
+                buf ^= 1;
+                nexch++;
             }
-            __syncthreads();
-            CARMA_STAMP(st6);
-            if (*s_flag) break;                            // uniform: the whole workgroup leaves
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // the ladder's log-posteriors and swap uniforms (keyed by the hotter chain's global slot):
-            // lane i of the chain wave owns temperature i, the sweep runs through v_readlane
-            if (T <= 64) {
-                // every wave: the ladder's staged parameter vectors into LDS, requested TOGETHER with the log-posteriors
-                // (which vector a chain picks up is known only after the sweep; a load after it was one more trip to L2)
-                for (int i = tid; i < T * d; i += 256)
-                    s_tha[i] = __hip_atomic_load(&st_th[ch0 * d + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int from = cc;
-                if (!producer) {
-                    const int i = lane64 < T ? lane64 : T - 1;
-                    double lp_i = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double logu_i = s_lu[lane64];               // drawn by producer wave 1 during the filter
-                    int src_i = i;
-                    bool sw;
-                    exchange_decide_wave(T, lane64, lp_i, s_dbeta[i], logu_i, src_i, &sw);
-                    if (sw && lane64 < T) s_nswap[lane64]++;
-                    from = __shfl(src_i, cc, 64);
-                    lp = __shfl(lp_i, cc, 64);
-                }
-                __syncthreads();
-                if (!producer && from != cc && j < d) ch.th = s_tha[from * d + j];
-            } else {
-                for (int i = tid; i < T; i += 256) {
-                    s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_src[i] = i;
-                    RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
-                    s_logu[i] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
-                }
-                __syncthreads();
-                if (tid == 0) exchange_decide(T, s_lp, s_dbeta, s_logu, s_src, s_nswap);
-                __syncthreads();
-                if (!producer) {
-                    const int from = s_src[cc];
-                    if (from != cc && j < d)
-                        ch.th = __hip_atomic_load(&st_th[(ch0 + from) * d + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lp = s_lp[cc];
-                }
-                __syncthreads();
-            }
-            buf ^= 1;
-            nexch++;
-            CARMA_STAMP(st7);
-#if defined(CARMA_STAMPS)
-            if (blockIdx.x == 0 && tid == 0 && it == L.niter - 1)
-                printf("pt_row stamps (cycles): propose %llu  barrier %llu  model+reset+filter %llu  accept+publish %llu  adapt %llu  "
-                       "rendezvous %llu  decide+gather %llu\n",
-                       st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6);
-#endif
+            __syncthreads();                               // sweep done
+            if (*s_flag) break;
         }
-        if (L.save_thin > 0 && ((it + 1) % L.save_thin) == 0 && part == 0 && tid < G) {
+        if (part == 0)
+            for (int i = lane64; i < T; i += 64) nswap[ch0 + i] += s_nswap[i];
+        return;
+    }
+
+    // ---- covariance recursion + the chains: state in registers (carma_pt_row.h), lane j owns component j and column j of R
+    RowChain ch;
+    ch.th = j < d ? theta[(ch0 + cc) * d + j] : 0.0;
+    ch.thn = ch.th;
+#pragma unroll
+    for (int k = 0; k < PT_DMAX; k++) ch.Rc[k] = (j < d && k <= j) ? chol[(ch0 + cc) * d * d + (size_t)k * d + j] : 0.0;
+    double lp = logpost[ch0 + cc];
+    const double temperature = temps[cc];
+    unsigned nacc = 0;
+    int buf = 0;
+    // (z, v = R^T z) of the first proposal; those of the later ones are formed while the ladder meets for the swap
+    double znorm2 = ram_draw_row(g, ch, d, rng_student_t8(key, L.iter0, (uint32_t)(j < d ? j : 0)));
+
+    CARMA_STAMP_DECL;
+#if defined(CARMA_STAMPS)
+    unsigned long long st5 = 0, st6 = 0, st7 = 0;
+#endif
+    for (int it = 0; it < L.niter; it++) {
+        const uint64_t iter = L.iter0 + (uint64_t)it;
+        CARMA_STAMP(st0);
+        ch.thn = ch.th + ch.v;                             // steps.cpp:72-73
+        if (j < d) thn_lds[j] = ch.thn;
+        __syncthreads();                                   // proposals visible to the other three waves
+        CARMA_STAMP(st1);
+        {
+            Model<P> m;
+            model_from_theta<P, G, MODEL_CONSTS>(g, thn_lds, L.q, pr, 0, m);
+            FilterConsts<P> fc;
+            filter_reset<P, G>(g, m, fc);
+            RowConsts<P> rc;
+            row_consts<P>(g, m, fc, rc);
+            pipe3l_cov<P>(g, m, rc, series, L.n + npad, npad, ring);
+        }
+        CARMA_STAMP(st2);
+        __syncthreads();                                   // log-densities visible
+        CARMA_STAMP(st3);
+        double alpha;
+        if (ram_accept_row(ch, temperature, iter, key, s_ll[row], &lp, &alpha)) nacc++;
+        if (exch) {
+            // publish this workgroup's chains and ARRIVE at the ladder's rendezvous.  Agent-scope (write-through)
+            // stores and loads for the staged values instead of a device-wide fence: a release/acquire fence at
+            // agent scope writes back and invalidates the whole L2 of the XCD, and with 256 workgroups doing that
+            // every iteration the swap cost grew from 4 to 20 us (the L2-resident series had to be re-fetched each
+            // time).  The stores are complete (vmcnt) before the arrival counter is bumped; both by this wave.
+            double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
+            double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
+            if (active) {
+                if (j < d) __hip_atomic_store(&st_th[(ch0 + c) * d + j], ch.th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j == 0) __hip_atomic_store(&st_lp[ch0 + c], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0);
+            if (lane64 == 0) __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            buf ^= 1;
+        }
+        CARMA_STAMP(st4);
+        // Neither the adaptation of the proposal factor (steps.cpp:82-99) nor the next proposal's (z, R^T z) touch the
+        // state: they run while the mean wave waits for the ladder and replays the sweep.  (The tail of the producers --
+        // s_z, s_step -- is behind the pipeline's last barrier.)
+        ram_adapt_row(g, ch, d, iter, L.maxiter, alpha, znorm2, *s_step);
+        znorm2 = ram_draw_row(g, ch, d, s_z[lane64]);
+        CARMA_STAMP(st5);
+        __syncthreads();                                   // sweep done
+        CARMA_STAMP(st6);
+        if (*s_flag) break;
+        if (exch) {
+            const int from = s_src[cc];
+            lp = s_lp[cc];
+            if (from != cc && j < d) {
+                if (T <= 64)
+                    ch.th = s_tha[from * d + j];
+                else
+                    ch.th = __hip_atomic_load(&S.stage_th[(size_t)(buf ^ 1) * nchain_all * d + (ch0 + from) * d + j], __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        CARMA_STAMP(st7);
+#if defined(CARMA_STAMPS)
+        if (blockIdx.x == 0 && lane64 == 0 && it == L.niter - 1)
+            printf("pt_row stamps (cycles): propose+barrier %llu  model+reset+filter %llu  wait for ll %llu  accept+publish %llu  "
+                   "adapt+draw %llu  wait for sweep %llu  pick up %llu\n",
+                   st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6);
+#endif
+        if (L.save_thin > 0 && ((it + 1) % L.save_thin) == 0 && part == 0 && lane64 < G) {
             // coldest chain of the ladder (Sampler::SaveValues, src/samplers.cpp:118-124): row 0 of part 0
             const long s = L.save_offset + (it + 1) / L.save_thin - 1;
             if (s < L.sample_cap) {
                 if (j < d) samples[(lad * L.sample_cap + s) * d + j] = ch.th;
-                if (tid == 0) sample_lp[lad * L.sample_cap + s] = lp;
+                if (lane64 == 0) sample_lp[lad * L.sample_cap + s] = lp;
             }
         }
     }
-    if (!producer && active) {
+    if (active) {
         if (j < d) {
             theta[(ch0 + c) * d + j] = ch.th;
 #pragma unroll
@@ -466,56 +515,58 @@ __global__ __launch_bounds__(256) void k_pt_row(PtLaunch L, PtRowSync S, const d
             naccept[ch0 + c] += nacc;
         }
     }
-    __syncthreads();
-    if (part == 0)
-        for (int i = tid; i < T; i += 256) nswap[ch0 + i] += s_nswap[i];
 }
 
 static size_t pt_row_lds(int d, int T)
 {
     (void)d;
+    // rings, proposals [4][16], s_ll [4], s_lp / s_dbeta / s_logu [T], s_nswap + s_src [T] (4 B each), flag, s_z / s_lu [64], step, s_tha
     return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16 + 128 * 8 + 16 +
            (size_t)(T <= 64 ? T : 0) * PT_DMAX * 8;
 }
 
 template <int P>
-static const void* pt_row_fn()
+static const void* pt_row_fn(int minw)
 {
-    return reinterpret_cast<const void*>(&k_pt_row<P>);
+    return minw >= 3 ? reinterpret_cast<const void*>(&k_pt_row<P, 3>) : reinterpret_cast<const void*>(&k_pt_row<P, 2>);
 }
 
-static const void* pt_row_fn_p(int p)
+static const void* pt_row_fn_p(int p, int minw)
 {
     switch (p) {
-        case 2: return pt_row_fn<2>();
-        case 3: return pt_row_fn<3>();
-        case 4: return pt_row_fn<4>();
-        case 5: return pt_row_fn<5>();
-        case 6: return pt_row_fn<6>();
-        case 7: return pt_row_fn<7>();
+        case 2: return pt_row_fn<2>(minw);
+        case 3: return pt_row_fn<3>(minw);
+        case 4: return pt_row_fn<4>(minw);
+        case 5: return pt_row_fn<5>(minw);
+        case 6: return pt_row_fn<6>(minw);
+        case 7: return pt_row_fn<7>(minw);
         default: return nullptr;
     }
 }
 
 long pt_row_capacity(int p, int d, int T, int n)
 {
-    const void* fn = pt_row_fn_p(p);
+    const void* fn = pt_row_fn_p(p, 3);
     if (!fn || n < 32 || T < 1) return 0;
     const size_t lds = pt_row_lds(d, T);
     if (lds > 160 * 1024) return 0;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 0;
-    int dev = 0, ncu = 0;
+    int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    // One workgroup per CU: beyond that the ladder kernel (8 chains per wave) has the better throughput.  Whether
-    // the grid really is co-resident is checked by the cooperative launch itself (launch_pt_row_p).
     int coop = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return 0;
-    static const long per_cu = [] {
+    // Workgroups the device holds at once: what registers (168 -> three waves per SIMD) and LDS allow per CU, as the
+    // runtime counts them -- the cooperative launch (launch_pt_row_p) checks the same thing again.  Beyond that the
+    // ladder kernel (8 chains per wave) takes over.
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) return 0;
+    static const long tune = [] {
         const char* e = getenv("CARMA_TUNE_PT_ROW_WGS_PER_CU");      // measurements only; read once
-        return e ? atol(e) : 1L;
+        return e ? atol(e) : 0L;
     }();
-    return (long)ncu * per_cu;
+    if (tune > 0 && tune < per_cu) per_cu = (int)tune;
+    if (per_cu > 3) per_cu = 3;
+    return (long)device_cus() * per_cu;
 }
 
 template <int P>
@@ -524,26 +575,24 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
                                   unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
 {
     const size_t lds = pt_row_lds(L.d, L.T);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pt_row<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+    const long grid = (long)L.R * S.wpl;
+    const int minw = grid > 2L * S.ncu ? 3 : 2;             // the 168-register build only where three workgroups share a CU
+    const void* fn = pt_row_fn<P>(minw);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    // COOPERATIVE launch: the swap step is a rendezvous of the ladder's workgroups through global memory, so the whole
-    // grid has to be resident at once.  The runtime checks that (hipErrorCooperativeLaunchTooLarge otherwise, and the
-    // host falls back to the ladder kernel) and schedules the grid as a gang, instead of this code assuming it.
-    if (S.wpl == 1) {
-        // the whole ladder (block) in one workgroup: the rendezvous has a single participant, no co-residency needed --
-        // an ordinary launch (a cooperative one costs ~2 ms on this stack, which matters when the ladder is sharded
-        // across GPUs and every iteration is a launch of its own)
-        hipLaunchKernelGGL((k_pt_row<P>), dim3((unsigned)L.R), dim3(256), lds, st, L, S, series, pr, temps, theta, logpost, chol,
-                           naccept, nswap, samples, sample_lp);
-        return hipGetLastError();
-    }
     PtLaunch La = L;
     PtRowSync Sa = S;
     Prior pra = pr;
     void* args[] = {&La, &Sa, (void*)&series, &pra, (void*)&temps, &theta, &logpost, &chol, &naccept, &nswap, &samples, &sample_lp};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_pt_row<P>), dim3((unsigned)((long)L.R * S.wpl)), dim3(256),
-                                      args, (unsigned)lds, st);
+    if (S.wpl == 1)
+        // the whole ladder (block) in one workgroup: the rendezvous has a single participant, no co-residency needed --
+        // an ordinary launch (a cooperative one costs ~2 ms on this stack, which matters when the ladder is sharded
+        // across GPUs and every iteration is a launch of its own)
+        return hipLaunchKernel(fn, dim3((unsigned)grid), dim3(256), args, lds, st);
+    // COOPERATIVE launch: the swap step is a rendezvous of the ladder's workgroups through global memory, so the whole
+    // grid has to be resident at once.  The runtime checks that (hipErrorCooperativeLaunchTooLarge otherwise, and the
+    // host falls back to the ladder kernel) and schedules the grid as a gang, instead of this code assuming it.
+    return hipLaunchCooperativeKernel(fn, dim3((unsigned)grid), dim3(256), args, (unsigned)lds, st);
 }
 
 hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const double4* series, const Prior& pr,

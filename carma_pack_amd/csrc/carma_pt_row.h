@@ -23,14 +23,13 @@ struct RowChain {
     double Rc[PT_DMAX];     // column j of R
 };
 
-// z ~ t_8^d, thn = th + R^T z (steps.cpp:60-73).  Returns |z|^2.  thn is also stored to thn_lds[j] for
-// the model code and the producer wave.
-// `zpre` (may be null): this lane's t8 variate drawn ahead of time by a producer wave (same key, iteration, index)
-__device__ __forceinline__ double ram_propose_row(const Grp<16>& g, RowChain& ch, int d, uint64_t iter, const RngKey& key,
-                                                  double* thn_lds, const double* zpre)
+// Unit draw z and v = R^T z of a proposal (steps.cpp:60-73); returns |z|^2.  The proposal itself is thn = th + v: the
+// sampler kernel forms (z, v) of the NEXT iteration while the ladder's other workgroups arrive at the swap rendezvous --
+// the factor R is final by then (the adaptation has run), only th may still change hands -- so that one addition is all
+// that is left between the swap and the next filter.
+__device__ __forceinline__ double ram_draw_row(const Grp<16>& g, RowChain& ch, int d, double zj)
 {
     const int j = g.lane();
-    const double zj = zpre ? *zpre : rng_student_t8(key, iter, (uint32_t)(j < d ? j : 0));
     ch.z = j < d ? zj : 0.0;
     double znorm2 = 0.0, acc = 0.0;
     static_for<0, PT_DMAX>([&](auto kc) {
@@ -42,9 +41,6 @@ __device__ __forceinline__ double ram_propose_row(const Grp<16>& g, RowChain& ch
         }
     });
     ch.v = acc;
-    ch.thn = ch.th + acc;
-    if (j < d) thn_lds[j] = ch.thn;
-    g.sync();
     return znorm2;
 }
 

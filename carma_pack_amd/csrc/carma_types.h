@@ -55,6 +55,7 @@ struct PtRowSync {
     unsigned* counter;       // [R] arrivals of the ladder's workgroups (zeroed before every launch)
     unsigned* abort_flag;    // [1] set when a barrier timed out (the launch then ends early)
     int wpl;                 // workgroups per ladder = ceil(T / 4)
+    int ncu;                 // compute units of the device: workgroups i, i + ncu, i + 2 ncu share a CU (wave parts)
 };
 
 }  // namespace carma

@@ -9,7 +9,7 @@ t, y, yerr = g['t'], g['y'], g['yerr']
 ms = 10*np.sqrt(np.mean(y*y)-np.mean(y)**2)
 print("CARMA_TUNE_PT_ROW_WGS_PER_CU=%s CARMA_PT_KERNEL=%s" % (os.environ.get("CARMA_TUNE_PT_ROW_WGS_PER_CU", "(default)"),
                                                               os.environ.get("CARMA_PT_KERNEL", "(auto)")))
-for R in (64, 96, 128, 192, 256, 512):
+for R in (64, 96, 128, 160, 192, 256, 512):
     ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms)
     ctx.pt_create(16, R, adapt_iters=10**9, seed=3)
     ctx.pt_start(None)
