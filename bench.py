@@ -416,38 +416,83 @@ def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):
     return res
 
 
+def _host_cpus():
+    """CPUs this process may actually use: the affinity mask, cut by the cgroup CPU quota when there is one."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:             # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return aff, quota, model
+
+
 def cpu_baseline(t, y, yerr, p, q, max_stdev, theta, budget_s):
-    """The CPU oracle (a port of kfilter.cpp + carpack LogDensity; the reference's own C++ is
-    unbuildable here) timed on this box's host cores on a bounded sample of the same workload."""
+    """The CPU comparator of SURVEY.md 8(d): the oracle's restatement of kfilter.cpp + carpack LogDensity (the
+    reference's own C++ is unbuildable here) built -O3 -march=native ON THIS BOX, timed on its host cores on a bounded
+    sample of the same workload: one thread and all usable cores (OpenMP over evaluations), median of >= 3 repetitions."""
     import oracle as orc
-    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=max_stdev)
-    cores = os.cpu_count() or 1
-    cores = min(cores, orc.max_threads())
+    m = orc.NativeComparator(t, y, yerr, p, q, max_stdev)
+    aff, quota, model = _host_cpus()
+    cores = max(1, min(aff, m.max_threads(), int(quota) if quota and quota >= 1 else aff))
     B = theta.shape[0]
-    # single thread: ~1/3 of the budget
-    t0 = time.perf_counter()
-    reps1 = 0
-    while time.perf_counter() - t0 < budget_s / 3.0:
-        m.logdensity_batch(theta, nthreads=1)
-        reps1 += 1
-    v1 = reps1 * B / (time.perf_counter() - t0)
-    # all cores: a larger tile so OpenMP start-up is amortised
-    big = np.tile(theta, (max(1, 8 * cores * 1024 // B // 8), 1))
-    m.logdensity_batch(big, nthreads=cores)
-    t0 = time.perf_counter()
-    repsN = 0
-    while time.perf_counter() - t0 < budget_s * 2.0 / 3.0:
-        m.logdensity_batch(big, nthreads=cores)
-        repsN += 1
-    vN = repsN * big.shape[0] / (time.perf_counter() - t0)
+
+    def rate(batch, nthreads, seconds, min_reps=3):
+        m.logdensity_batch(batch[: max(64, batch.shape[0] // 8)], nthreads=nthreads)      # warm the threads up
+        rates = []
+        t_end = time.perf_counter() + seconds
+        while len(rates) < min_reps or time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            m.logdensity_batch(batch, nthreads=nthreads)
+            rates.append(batch.shape[0] / (time.perf_counter() - t0))
+            if len(rates) >= 200:
+                break
+        return float(np.median(rates)), len(rates)
+
+    v1, reps1 = rate(theta, 1, budget_s * 0.25)
+    # all cores: a tile of ~1024 evaluations per thread so that OpenMP start-up and the static schedule's tail are amortised
+    big = np.tile(theta, (max(1, cores * 1024 // B), 1))
+    vN, repsN = rate(big, cores, budget_s * 0.45)
+    # where the scaling goes: the same tile on fewer threads (median of 3 each)
+    scaling = {}
+    for nt in sorted({2, 4, 8, 16, 32, 64, cores // 2}):
+        if 1 < nt < cores:
+            scaling[str(nt)] = rate(np.tile(theta, (max(1, nt * 1024 // B), 1)), nt, 0.0)[0]
+    scaling["1"], scaling[str(cores)] = v1, vN
     return {
         "value": vN,
         "unit": "evals/s",
         "cores": cores,
         "kind": "port",
-        "sample": "the step's own 1024-theta batch (CARMA(5,3), n=270): %d evals on %d OpenMP threads "
-                  "(+ %d evals single-threaded)" % (repsN * big.shape[0], cores, reps1 * B),
+        "build": "gcc -O3 -march=native -fopenmp (no fast-math), built on this box; the parity oracle is a separate "
+                 "-O2 -ffp-contract=off build of the same source",
+        "cpu_model": model,
+        "cpus_in_affinity_mask": aff,
+        "cgroup_cpu_quota": quota,
+        "os_cpu_count": os.cpu_count(),
+        "sample": "the step's own 1024-theta batch (CARMA(5,3), n=270): %d x %d evals on %d OpenMP threads, "
+                  "%d x %d evals on one thread; medians" % (repsN, big.shape[0], cores, reps1, B),
         "single_thread_value": v1,
+        "parallel_efficiency": vN / v1 / cores,
+        "thread_scaling": scaling,
     }
 
 

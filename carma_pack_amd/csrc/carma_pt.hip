@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     // which wave plays which part: as in k_logdens_carma_p3l (workgroups i, i + ncu, i + 2 ncu share a CU)
     //                 part of wave:  0  1  2  3      (0 covariance + chains, 1 mean + swap sweep, 2 / 3 producers)
     const int round = (blockIdx.x >= (unsigned)S.ncu) + (blockIdx.x >= 2u * (unsigned)S.ncu);
-    const int wave = ((round == 0 ? 0xE4 : round == 1 ? 0xD2 : 0x36) >> (2 * (tid >> 6))) & 3;
+    const int wave = ((round == 0 ? 0xE4 : round == 1 ? (S.rot & 0xff) : (S.rot >> 8)) >> (2 * (tid >> 6))) & 3;
     const int d = L.d, T = L.T;
     Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3l.h rings
     double* s_thn = reinterpret_cast<double*>(ring + Pipe3LGeom<P>::ENTRIES);  // [CPW][16] proposals
@@ -308,23 +308,24 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     // "log-densities visible", "sweep done".
 
     if (wave >= 2) {
-        // ---- producers.  They are done two chunks before the recursion waves: in that time they draw random numbers
-        // that are functions of key and iteration only -- P0 the NEXT iteration's proposal variates and this iteration's
-        // adaptation step length, P1 the logs of the swap uniforms of THIS iteration's exchange
+        // ---- producers.  Behind the pipeline's last barrier -- the mean wave still has a chunk to go, then come the
+        // Metropolis decisions -- they draw the random numbers that are functions of key and iteration only: P0 the NEXT
+        // iteration's proposal variates and this iteration's adaptation step length, P1 the logs of the swap uniforms of
+        // THIS iteration's exchange.  (Outside pipe3l_produce: nothing of the pipeline is live across these draws, which
+        // is what keeps the 168-register build of this loop free of spills.)
         for (int it = 0; it < L.niter; it++) {
             const uint64_t iter = L.iter0 + (uint64_t)it;
             __syncthreads();                               // proposals visible
-            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [&](int pw) {
-                if (pw == 0) {
-                    s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
-                    if (lane64 == 0) *s_step = ram_adapt_step(d, iter);
-                } else if (exch && T <= 64) {
-                    const int i = lane64 < T ? lane64 : T - 1;
-                    RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
-                    s_lu[lane64] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
-                }
-            });
-            __syncthreads();                               // log-densities visible
+            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [](int) {});
+            if (wave == 2) {
+                s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
+                if (lane64 == 0) *s_step = ram_adapt_step(d, iter);
+            } else if (exch && T <= 64) {
+                const int i = lane64 < T ? lane64 : T - 1;
+                RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
+                s_lu[lane64] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+            }
+            __syncthreads();                               // log-densities (and these draws) visible
             __syncthreads();                               // sweep done
             if (*s_flag) break;
         }
@@ -350,6 +351,11 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 if (j == 0) s_ll[row] = ll;
             }
             __syncthreads();                               // log-densities visible to the chain wave
+            __builtin_amdgcn_s_setprio(3);                 // the ladder waits for this sweep (back to 1 in pipe3l_mean)
+#if defined(CARMA_STAMPS)
+            unsigned long long b0 = 0, b1 = 0, b2 = 0;
+            CARMA_STAMP(b0);
+#endif
             if (exch) {
                 const double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
                 const double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
@@ -370,6 +376,9 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                     }
                 }
                 aborted = __builtin_amdgcn_readfirstlane(aborted);
+#if defined(CARMA_STAMPS)
+                CARMA_STAMP(b1);
+#endif
                 if (!aborted) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (T <= 64) {
@@ -403,6 +412,12 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 buf ^= 1;
                 nexch++;
             }
+#if defined(CARMA_STAMPS)
+            CARMA_STAMP(b2);
+            if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane64 == 0 && it == L.niter - 1)
+                printf("pt_row mean wave, workgroup %u (cycles): ll handed over at %llu | rendezvous wait %llu  fetch + sweep %llu\n", blockIdx.x,
+                       b0 % 100000000ull, b1 - b0, b2 - b1);
+#endif
             __syncthreads();                               // sweep done
             if (*s_flag) break;
         }
@@ -468,8 +483,8 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
         }
         CARMA_STAMP(st4);
         // Neither the adaptation of the proposal factor (steps.cpp:82-99) nor the next proposal's (z, R^T z) touch the
-        // state: they run while the mean wave waits for the ladder and replays the sweep.  (The tail of the producers --
-        // s_z, s_step -- is behind the pipeline's last barrier.)
+        // state: they run while the mean wave waits for the ladder and replays the sweep.  (The producers' draws --
+        // s_z, s_step -- are behind the "log-densities visible" barrier.)
         ram_adapt_row(g, ch, d, iter, L.maxiter, alpha, znorm2, *s_step);
         znorm2 = ram_draw_row(g, ch, d, s_z[lane64]);
         CARMA_STAMP(st5);
@@ -489,10 +504,10 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
         }
         CARMA_STAMP(st7);
 #if defined(CARMA_STAMPS)
-        if (blockIdx.x == 0 && lane64 == 0 && it == L.niter - 1)
-            printf("pt_row stamps (cycles): propose+barrier %llu  model+reset+filter %llu  wait for ll %llu  accept+publish %llu  "
+        if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane64 == 0 && it == L.niter - 1)
+            printf("pt_row chain wave, workgroup %u: iteration starts at %llu | propose+barrier %llu  model+reset+filter %llu  wait for ll %llu  accept+publish %llu  "
                    "adapt+draw %llu  wait for sweep %llu  pick up %llu\n",
-                   st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6);
+                   blockIdx.x, st0 % 100000000ull, st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6);
 #endif
         if (L.save_thin > 0 && ((it + 1) % L.save_thin) == 0 && part == 0 && lane64 < G) {
             // coldest chain of the ladder (Sampler::SaveValues, src/samplers.cpp:118-124): row 0 of part 0
@@ -582,6 +597,17 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     if (e != hipSuccess) return e;
     PtLaunch La = L;
     PtRowSync Sa = S;
+    // Which wave plays which part in the workgroups that share a CU (i, i + ncu, i + 2 ncu).  An ordinary launch places
+    // them as k_logdens_carma_p3l's are placed (same tables); the workgroups of a COOPERATIVE launch all land with the
+    // same wave -> SIMD pattern (tools/ubench/wave_placement.hip with a second argument 1,
+    // profiles/r03/wave_placement_coop.txt), so the parts simply trade places: (cov, mean, P0, P1), (P0, P1, cov, mean),
+    // (mean, cov, P1, P0) -- every SIMD gets one covariance or mean wave of each kind at most.
+    static const long tune_rot = [] {
+        const char* e = getenv("CARMA_TUNE_PT_ROW_ROT");                        // measurements only; read once
+        return e ? strtol(e, nullptr, 16) : -1L;
+    }();
+    Sa.rot = S.wpl == 1 ? 0x36D2 : 0xB14E;
+    if (tune_rot >= 0) Sa.rot = (int)tune_rot;
     Prior pra = pr;
     void* args[] = {&La, &Sa, (void*)&series, &pra, (void*)&temps, &theta, &logpost, &chol, &naccept, &nswap, &samples, &sample_lp};
     if (S.wpl == 1)

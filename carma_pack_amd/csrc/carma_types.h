@@ -55,7 +55,9 @@ struct PtRowSync {
     unsigned* counter;       // [R] arrivals of the ladder's workgroups (zeroed before every launch)
     unsigned* abort_flag;    // [1] set when a barrier timed out (the launch then ends early)
     int wpl;                 // workgroups per ladder = ceil(T / 4)
-    int ncu;                 // compute units of the device: workgroups i, i + ncu, i + 2 ncu share a CU (wave parts)
+    int ncu;                 // compute units of the device: workgroups i, i + ncu, i + 2 ncu share a CU
+    int rot;                 // which wave plays which part in the second (bits 0-7) and third (bits 8-15) workgroup of a CU:
+                             // 2 bits per wave, set by the launcher (the placement differs between launch kinds)
 };
 
 }  // namespace carma

@@ -4,6 +4,7 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 import this package.  ``carma_pack_amd`` (the product) never does.
 """
 from .oracle import (  # noqa: F401
+    NativeComparator,
     OracleModel,
     ar_roots,
     build,

@@ -129,7 +129,11 @@ def test_gpu_matches_emulator_trajectory(cpa):
 
 
 @pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1), (3, 1, 1, 5), (3, 1, 2, 1),
-                                     (4, 2, 17, 2), (2, 0, 33, 1), (3, 2, 64, 1), (2, 1, 70, 1)])
+                                     (4, 2, 17, 2), (2, 0, 33, 1), (3, 2, 64, 1), (2, 1, 70, 1),
+                                     # grids of more than one workgroup per CU (round 3): 160 x 2 = 320 workgroups (two per
+                                     # CU on some CUs, the 236-register build), 180 x 3 = 540 and 96 x 8 = 768 (three per CU,
+                                     # the 168-register build)
+                                     (5, 3, 8, 160), (3, 1, 12, 180), (7, 6, 30, 96)])
 def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkeypatch):
     """The two sampler kernels -- k_pt (one workgroup per ladder) and k_pt_row (one chain per DPP row,
     ladder spread over workgroups, register-resident RAM step, cross-workgroup swap rendezvous) -- use

@@ -1,7 +1,7 @@
 // Where do the waves of co-resident workgroups land?  Grid of NWG workgroups x 256 threads with 42 KiB of dynamic LDS
 // (k_logdens_carma_p3l's shape); every wave records its HW_ID / XCC_ID and spins long enough for the whole grid to be
 // resident.  Prints, per (xcc, se, cu), the SIMD of every (workgroup, wave).
-//   hipcc -O2 --offload-arch=gfx950 tools/ubench/wave_placement.hip -o /tmp/wave_placement && /tmp/wave_placement 512
+//   hipcc -O2 --offload-arch=gfx950 tools/ubench/wave_placement.hip -o /tmp/wave_placement && /tmp/wave_placement 512 [1 = cooperative launch]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -26,9 +26,17 @@ __global__ void k_where(unsigned* out, int spin)
 int main(int argc, char** argv)
 {
     const int nwg = argc > 1 ? atoi(argv[1]) : 512;
+    const bool coop = argc > 2 && atoi(argv[2]) != 0;         // second argument 1: cooperative launch (the row sampler's)
     unsigned* d;
     hipMalloc(&d, sizeof(unsigned) * 8 * nwg);
-    hipLaunchKernelGGL(k_where, dim3(nwg), dim3(256), 42 * 1024, 0, d, 20000);
+    if (coop) {
+        int spin = 20000;
+        void* args[] = {&d, &spin};
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_where), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_where), dim3(nwg), dim3(256), args, 47 * 1024, 0);
+        printf("cooperative launch: %s\n", hipGetErrorString(e));
+    } else
+        hipLaunchKernelGGL(k_where, dim3(nwg), dim3(256), 42 * 1024, 0, d, 20000);
     hipDeviceSynchronize();
     std::vector<unsigned> h(8 * nwg);
     hipMemcpy(h.data(), d, sizeof(unsigned) * 8 * nwg, hipMemcpyDeviceToHost);
