@@ -656,6 +656,52 @@ def test_prior_like_sweep_never_worse_than_reference(cpa, p):
         got = ctx.logdensity(th)
         fin = np.isfinite(want)
         narb += int(np.sum(np.abs(got[fin] - want[fin]) > RTOL * np.abs(want[fin])))
+        # how many go to the arbiter: 0.37 % over all orders, up to 1.8 % for p = 6 (three complex pairs cluster most
+        # often; profiles/r02/parity_sweep_v5.txt) -- 4 % is the allowance here, 1 % the default elsewhere
         assert_parity(got, want, RTOL, "sweep p=%d q=%d" % (p, q),
-                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.04)
     print("p=%d: %d of %d evaluations arbitrated against 50-digit arithmetic" % (p, narb, 200 * p))
+
+
+def test_config3_series_against_the_reference_python(cpa, golden_dir):
+    """BASELINE configs[3] at full size (CARMA(7,6), n = 10 000) against vectors the REFERENCE's Python produced
+    (KalmanFilterDeprecated, tests/golden/make_golden_hard.py): log-likelihood of the generating parameters, of
+    posterior-like neighbours and of prior-like draws (one with cond(EigenMat) 6e11), and the strided Kalman
+    mean / variance through the KalmanFilterp entry point."""
+    g = np.load(os.path.join(golden_dir, "config3_carma76_n10000.npz"))
+    t, y, e = g["t"], g["y"], g["yerr"]
+    p, q, stride = int(g["p"]), int(g["q"]), int(g["stride"])
+    ctx = cpa.Context(t, y, e, p, q)
+    th = g["theta"]
+    ll = ctx.logdensity(th, ignore_prior=True) - np.array([ctx.logprior(x) for x in th])
+    from helpers import loglik_truth
+    worst = assert_parity(ll, g["loglik"], RTOL, "configs[3] series vs reference Python",
+                          arbiter=lambda i: loglik_truth(t, y, e, th[i], p, q)[1])
+    print("configs[3] series vs the reference's Python: worst %.2e" % worst)
+    for i in (0, 3):
+        om, ma = orc.ar_roots(th[i], p), orc.ma_coefs(th[i], p, q)
+        mean, var = cpa.kfilter_carma(t, y - th[i][2], np.sqrt(th[i][1]) * e, th[i][0] ** 2 / orc.variance(om, ma), om, ma)
+        np.testing.assert_allclose(var[::stride], g["var"][i], rtol=1e-8)
+        np.testing.assert_allclose(mean[::stride], g["mean"][i], rtol=0, atol=1e-9 * np.abs(y - th[i][2]).max())
+
+
+def test_ill_conditioned_models_against_the_reference_python(cpa, golden_dir):
+    """36 parameter vectors with cond(EigenMat) 2e3 ... 3e12 whose log-likelihoods come from the reference's Python
+    (its LAPACK LU; make_golden_hard.py).  On 11 of them the REFERENCE is itself 1e-10 ... 6.5e-6 away from the exact
+    value of its formulas (tests/test_oracle_golden.py prints the table); the bar is the usual one with the reference's
+    own number in the oracle's place: within 1e-10 of it, or within 1e-10 of the exact value, or no further from the
+    exact value than the reference is."""
+    from helpers import loglik_truth
+    g = np.load(os.path.join(golden_dir, "illcond_readme.npz"))
+    t, y, e = g["t"], g["y"], g["yerr"]
+    narb = 0
+    for (p, q) in sorted({(int(a), int(b)) for a, b in zip(g["p"], g["q"])}):
+        sel = np.flatnonzero((g["p"] == p) & (g["q"] == q))
+        th = g["theta"][sel][:, : 3 + p + q]
+        ctx = cpa.Context(t, y, e, p, q)
+        ll = ctx.logdensity(th, ignore_prior=True) - np.array([ctx.logprior(x) for x in th])
+        ref = g["loglik"][sel]
+        narb += int(np.sum(np.abs(ll - ref) > RTOL * np.abs(ref)))
+        assert_parity(ll, ref, RTOL, "ill-conditioned p=%d q=%d vs reference Python" % (p, q),
+                      arbiter=lambda i: loglik_truth(t, y, e, th[i], p, q)[1], max_arbitrated=len(sel))
+    print("%d of %d ill-conditioned vectors arbitrated (the reference itself is beyond 1e-10 on 11)" % (narb, len(g["p"])))
