@@ -344,13 +344,22 @@ def main():
     if not args.no_ladder and 8 % world == 0:
         LADDER_TEXT = "MCMC iterations/s of ONE temperature ladder sharded across the ranks"
         watchdog = None
+        printed = None
         if world > 1:
             import threading
+            printed = threading.Lock()                     # whoever takes it prints the line; nobody prints twice
 
             def give_up():
-                if rank == 0:
-                    res["ladder_sharded"] = {"metric": LADDER_TEXT, "error": "no result after %d s" % args.ladder_timeout}
-                    print(json.dumps(res), flush=True)
+                # The exchange hangs: rank 0 prints the line WITH the failure in it ("ladder_leg_hung": true and the leg's
+                # error), says so on stderr, and every rank leaves.  The exit code stays 0 on purpose: the line carries the
+                # headline measurement of this N, which was complete before the leg started, and a launcher that discards
+                # the output of a failed run would lose it -- the hang is reported in the line, not hidden.
+                if rank == 0 and printed.acquire(blocking=False):
+                    out = dict(res)
+                    out["ladder_leg_hung"] = True
+                    out["ladder_sharded"] = {"metric": LADDER_TEXT, "error": "no result after %d s" % args.ladder_timeout}
+                    sys.stderr.write("bench.py: the ladder-sharded leg did not return within %d s; leaving\n" % args.ladder_timeout)
+                    print(json.dumps(out), flush=True)
                 os._exit(0)
 
             watchdog = threading.Timer(args.ladder_timeout, give_up)
@@ -362,6 +371,8 @@ def main():
             ladder = {"metric": LADDER_TEXT, "error": repr(ex)}
         if watchdog is not None:
             watchdog.cancel()
+            if rank == 0 and not printed.acquire(blocking=False):
+                time.sleep(60)                             # the watchdog fired while the leg was returning: it is leaving
 
     if rank == 0:
         if ladder is not None:
@@ -376,30 +387,57 @@ def main():
 def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):
     """N = 1: the whole ladder on one GPU.  N > 1: contiguous temperature blocks per rank, boundary chains exchanged with
     RCCL send/recv on the sampler's stream (carma_pt_iterate_sharded).  Iterations/s of the whole ladder (strong scaling:
-    the ladder is the same at every N)."""
+    the ladder is the same at every N).  At N > 1 the first ten iterations are also CHECKED: the blocks' chain states,
+    gathered on rank 0, must equal those of the same ladder run on rank 0's GPU alone (the sharded ladder walks the
+    unsharded trajectory bit for bit), and every boundary's decision checksums must have agreed."""
     from carma_pack_amd import _lib, parallel as par
     from carma_pack_amd.synth import config4_series
     t4, y4, e4, _ = config4_series(10000, seed=4)
-    TG, R4 = 8, 128
+    TG, R4, SEED4, WARM = 8, 128, 17, 10
     ctx4 = cpa.Context(t4, y4, e4, 7, 6, device=dev_index)
-    sh4 = par.LadderShard(ctx4, TG, R4, adapt_iters=10 ** 9, seed=17, dist=dist if world > 1 else None, device="cpu")
+    sh4 = par.LadderShard(ctx4, TG, R4, adapt_iters=10 ** 9, seed=SEED4, dist=dist if world > 1 else None, device="cpu")
     comm = None
     if world > 1 and not share:      # (two ranks sharing one GPU: RCCL refuses; the torch.distributed stand-in runs)
         comm = _lib.Comm.from_torch(dist, device=dev_index)
         sh4.attach_comm(comm)
     sh4.start()
     run = sh4.iterate if world > 1 else ctx4.pt_iterate
-    run(10)
+    run(WARM)
+    check = None
+    if world > 1:
+        th, lp = ctx4.pt_get_chains()
+        parts = [None] * world
+        dist.all_gather_object(parts, (th, lp, ctx4.pt_boundary_check() if comm is not None else None))
+        if dist.get_rank() == 0:
+            one = cpa.Context(t4, y4, e4, 7, 6, device=dev_index)
+            one.pt_create(TG, R4, 10 ** 9, seed=SEED4, temperatures=par.ladder_temperatures(TG))
+            one.pt_shard(TG, 0, 0)
+            one.pt_start(None)
+            one.pt_iterate(WARM)
+            uth, ulp = one.pt_get_chains()
+            check = {
+                "equals_one_gpu_run": bool(np.array_equal(np.concatenate([p_[0] for p_ in parts], axis=1), uth) and
+                                           np.array_equal(np.concatenate([p_[1] for p_ in parts], axis=1), ulp)),
+                "boundary_checksums_agree": [p_[2] for p_ in parts],
+                "iterations_checked": WARM,
+            }
+            del one
     barrier()
     tl0 = time.perf_counter()
     run(iters)
     barrier()
     tl = time.perf_counter() - tl0
+    rates = None
     if dist is not None:
         tt = torch.tensor([tl], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         tl = float(tt.item())
-    prop, acc_b = (sh4.nprop_boundary, sh4.nswap_boundary) if world > 1 else (0, 0)
+        if world > 1:
+            stats = [None] * world
+            dist.all_gather_object(stats, (sh4.nprop_boundary, sh4.nswap_boundary, ctx4.pt_boundary_check() if comm is not None else None))
+            # a boundary is counted by both of its sides; rank r's numbers cover its one or two boundaries
+            rates = [{"rank": r_, "proposed": int(s_[0]), "accepted": int(s_[1]), "rate": (s_[1] / s_[0]) if s_[0] else None,
+                      "checksums_agree": s_[2]} for r_, s_ in enumerate(stats)]
     res = {
         "metric": "MCMC iterations/s of ONE temperature ladder sharded across the ranks",
         "iters_per_s": iters / tl, "chain_evals_per_s": TG * R4 * iters / tl,
@@ -408,7 +446,9 @@ def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):
         "transport": ("rccl send/recv of %d doubles per boundary and iteration" % (R4 * 17 + 1)) if comm is not None
         else ("torch.distributed stand-in (ranks share a GPU)" if world > 1 else "none (one block)"),
         "rccl_ranks": comm.size if comm is not None else 1,
-        "boundary_swap_rate_rank0": (acc_b / prop) if prop else None,
+        "sweep": "hot -> cold over every adjacent pair every iteration, block boundaries included (the one-GPU sampler's sweep)",
+        "boundary_swaps_by_rank": rates,
+        "first_contact_check": check,
         "config": "configs[3] shape: CARMA(7,6), n=10000 (0.1+|Cauchy| steps), 8 temperatures x %d replicas" % R4,
     }
     if comm is not None:

@@ -96,9 +96,16 @@ class _CarmaBase(object):
     def SetPrior(self, max_stdev):
         self._ctx.set_prior(max_stdev)
 
-    def _run(self, sample_size, burnin, ntemps, thin, init, nreplicas, seed):
+    def _run(self, sample_size, burnin, ntemps, thin, init, nreplicas, seed, dist=None):
         init = _arr(init) if init is not None and len(init) else None
-        s, lp = self._ctx.pt_run(ntemps, nreplicas, int(sample_size), int(burnin), int(thin), init, _seed(seed))
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            # replicas split over the ranks of the process group (one process per GPU), coldest chains gathered at the end
+            from . import parallel
+            dev = "cuda:%d" % self._ctx.device if dist.get_backend() == "nccl" else "cpu"
+            s, lp = parallel.sharded_pt_run(lambda: self._ctx, ntemps, nreplicas, int(sample_size), int(burnin), int(thin),
+                                            init, _seed(seed), dist, dev)
+        else:
+            s, lp = self._ctx.pt_run(ntemps, nreplicas, int(sample_size), int(burnin), int(thin), init, _seed(seed))
         self._all_samples, self._all_logposts = s, lp
         self._samples, self._logposts = s[0], lp[0]       # the reference returns one coldest chain
         self.accept_rate, self.swap_rate = self._ctx.pt_stats()
@@ -143,19 +150,19 @@ def _pop_max_stdev(y):
 
 def run_mcmc_car1(sample_size, burnin, time, y, yerr, thin=1, init=vecD(), **kw):
     """RunCar1Sampler (src/carmcmc.cpp:30-77): one RAM chain at temperature 1 -> CAR1 object."""
-    nreplicas, seed, device = kw.pop("nreplicas", 1), kw.pop("seed", None), kw.pop("device", None)
+    nreplicas, seed, device, dist = kw.pop("nreplicas", 1), kw.pop("seed", None), kw.pop("device", None), kw.pop("dist", None)
     if kw:
         raise TypeError("unexpected arguments %r" % list(kw))
     obj = CAR1(True, "CAR(1)", time, y, yerr, device=device)
     obj.SetPrior(_pop_max_stdev(y))
-    obj._run(sample_size, burnin, 1, thin, init, nreplicas, seed)
+    obj._run(sample_size, burnin, 1, thin, init, nreplicas, seed, dist)
     return obj
 
 
 def run_mcmc_carma(sample_size, burnin, time, y, yerr, p, q, nwalkers, do_zcarma=False, thin=1, init=vecD(), **kw):
     """RunCarmaSampler (src/carmcmc.cpp:79-177): `nwalkers` tempered chains (T_i = 100^(i/(nwalkers-1))),
     RAM + exchange steps, returns the coldest chain as a CARp (q == 0) or CARMA object."""
-    nreplicas, seed, device = kw.pop("nreplicas", 1), kw.pop("seed", None), kw.pop("device", None)
+    nreplicas, seed, device, dist = kw.pop("nreplicas", 1), kw.pop("seed", None), kw.pop("device", None), kw.pop("dist", None)
     if kw:
         raise TypeError("unexpected arguments %r" % list(kw))
     if not int(p) > 1:
@@ -168,7 +175,7 @@ def run_mcmc_carma(sample_size, burnin, time, y, yerr, p, q, nwalkers, do_zcarma
     else:
         obj = CARMA(True, "CARMA(p,q) Parameters", time, y, yerr, p, q, device=device)
     obj.SetPrior(_pop_max_stdev(y))
-    obj._run(sample_size, burnin, int(nwalkers), thin, init, nreplicas, seed)
+    obj._run(sample_size, burnin, int(nwalkers), thin, init, nreplicas, seed, dist)
     return obj
 
 

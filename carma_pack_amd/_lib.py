@@ -134,6 +134,8 @@ def _load():
     L.carma_pt_iterate_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_void_p]
     L.carma_pt_sample_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, _dp, _dp]
     L.carma_pt_boundary_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.carma_pt_boundary_check.argtypes = [C.c_void_p]
+    L.carma_pt_sweep.argtypes = [C.c_void_p]
     return L
 
 
@@ -149,6 +151,7 @@ EXPORTS = [
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_sample_sharded", "carma_pt_boundary_stats",
+    "carma_pt_boundary_check", "carma_pt_sweep",
 ]
 
 
@@ -342,6 +345,14 @@ class Context:
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)
         check(lib.carma_pt_boundary_stats(self._h, C.byref(a), C.byref(b)), "carma_pt_boundary_stats")
         return a.value, b.value
+
+    def pt_boundary_check(self):
+        """1: the last sharded call's boundary self-check agreed; -1: it differed; 0: none yet."""
+        return int(lib.carma_pt_boundary_check(self._h))
+
+    def pt_sweep(self):
+        """The swap sweep inside this block for the iteration just run with do_exchange=False (carma_pt_sweep)."""
+        check(lib.carma_pt_sweep(self._h), "carma_pt_sweep")
 
 
 class Comm:

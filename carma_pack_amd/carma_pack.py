@@ -146,15 +146,28 @@ class MCMCSample(object):
     """Minimal sample container (the reference's samplers.MCMCSample holds the same `_samples` dict;
     its plotting/diagnostic methods are outside the hot path)."""
 
-    def __init__(self, logpost=None, trace=None):
+    def __init__(self, filename=None, logpost=None, trace=None):
+        # reference samplers.py:27-45: a trace wins over a file name
         self._samples = {}
         if trace is not None:
             self.generate_from_trace(trace)
+        elif filename is not None:
+            self.generate_from_file([filename])
         if logpost is not None:
             self.set_logpost(logpost)
 
     def get_samples(self, name):
         return self._samples[name].copy()
+
+    def generate_from_file(self, filename):
+        """One parameter per ascii file, its name on the first line (reference samplers.py:57-72).  `filename` is a
+        list of file names."""
+        for fname in filename:
+            with open(fname, "r") as f:
+                name = f.readline()
+            trace = np.genfromtxt(fname, skip_header=1)
+            if name not in self._samples:
+                self._samples[name] = trace
 
     def set_logpost(self, logpost):
         self._samples["logpost"] = np.asarray(logpost)
@@ -210,7 +223,9 @@ class CarmaSample(MCMCSample):
         self._sampler = sampler
         logpost = np.array(sampler.GetLogLikes())
         trace = np.array(sampler.getSamples())
-        super(CarmaSample, self).__init__(logpost=logpost, trace=trace)
+        # (as in the reference, :290, `filename` only matters when the sampler holds no trace: generate_from_file below
+        # reads the ascii file the C++ carpack wrote)
+        super(CarmaSample, self).__init__(filename=filename, logpost=logpost, trace=trace)
         self._ar_roots()
         self._ar_coefs()
         self._ma_coefs(trace)
@@ -225,6 +240,14 @@ class CarmaSample(MCMCSample):
         self.mle = {}
         if MLE is not None:
             self.add_mle(MLE)
+
+    def generate_from_file(self, filename):
+        """Samples from an ascii file written by the C++ carpack: one header line, then one row per sample holding the
+        parameter vector followed by the log-posterior (reference :427-437; `filename` is a list, its first entry is
+        read)."""
+        trace = np.atleast_2d(np.genfromtxt(filename[0], skip_header=1))
+        self.generate_from_trace(trace[:, 0:-1])
+        self.set_logpost(trace[:, -1])
 
     def generate_from_trace(self, trace):
         self.p = trace.shape[1] - 3 - self.q          # sic: p inferred from the trace width (:415)
@@ -472,9 +495,12 @@ class CarmaModel(object):
         self.p, self.q = p, q
         self.mcmc_sample = None
 
-    def run_mcmc(self, nsamples, nburnin=None, ntemperatures=None, nthin=1, init=None, nreplicas=1, seed=None):
+    def run_mcmc(self, nsamples, nburnin=None, ntemperatures=None, nthin=1, init=None, nreplicas=1, seed=None, dist=None):
         """Parallel-tempered RAM sampler on the GPU; defaults as the reference (:53-89):
-        ntemperatures = max(10, p+q), nburnin = nsamples/2."""
+        ntemperatures = max(10, p+q), nburnin = nsamples/2.  `dist`: an initialised torch.distributed module (one
+        process per GPU, every rank makes the same call): the `nreplicas` independent ladders are split over the ranks
+        and every rank returns the gathered samples of all of them (parallel.sharded_pt_run) -- the same arrays as the
+        single-process call with the same seed."""
         if ntemperatures is None:
             ntemperatures = max(10, self.p + self.q)
         if nburnin is None:
@@ -482,11 +508,11 @@ class CarmaModel(object):
         init = carmcmcLib.vecD() if init is None else _vec(init)
         if self.p == 1:
             cpp = carmcmcLib.run_mcmc_car1(nsamples, int(nburnin), self._time, self._y, self._ysig, nthin, init,
-                                           nreplicas=nreplicas, seed=seed)
+                                           nreplicas=nreplicas, seed=seed, dist=dist)
             sample = Car1Sample(self.time, self.y, self.ysig, cpp)
         else:
             cpp = carmcmcLib.run_mcmc_carma(nsamples, int(nburnin), self._time, self._y, self._ysig, self.p, self.q,
-                                            ntemperatures, False, nthin, init, nreplicas=nreplicas, seed=seed)
+                                            ntemperatures, False, nthin, init, nreplicas=nreplicas, seed=seed, dist=dist)
             sample = CarmaSample(self.time, self.y, self.ysig, cpp, q=self.q)
         self.mcmc_sample = sample
         return sample
@@ -556,8 +582,9 @@ class CarmaModel(object):
             pts[1:d + 1] += np.diag(h)
             pts[d + 1:] -= np.diag(h)
             f = -np.asarray(proc.getLogDensityBatch(pts))
-            g = (f[1:d + 1] - f[d + 1:]) / (2.0 * h)
-            g[~np.isfinite(g)] = 0.0
+            fp, fm = f[1:d + 1], f[d + 1:]
+            ok = np.isfinite(fp) & np.isfinite(fm)             # a stencil point outside the bounds is +inf: no inf - inf
+            g = np.where(ok, np.where(ok, fp, 0.0) - np.where(ok, fm, 0.0), 0.0) / (2.0 * h)
             return (f[0] if np.isfinite(f[0]) else 1e300), g
 
         results = [minimize(fun_and_grad, x0, jac=True, method="L-BFGS-B", bounds=bnds) for x0 in starts]

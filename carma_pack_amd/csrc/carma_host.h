@@ -35,6 +35,8 @@ struct PtState {
     double *d_send = nullptr, *d_recv = nullptr;       // [R][d+1] each
     unsigned* d_bnd_swaps = nullptr;                   // [1] accepted boundary swaps (this block's side)
     unsigned long long bnd_proposed = 0;
+    unsigned long long* d_checksum = nullptr;          // [4] folds of the boundary decisions: lower / upper side, the peers' reports
+    int bnd_check = 0;                                 // result of the last self-check: 1 agreed, -1 differed, 0 none yet
 };
 
 struct Ctx {

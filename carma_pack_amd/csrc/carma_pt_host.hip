@@ -40,6 +40,7 @@ void pt_state_free(Ctx* c)
     if (s->d_send) (void)hipFree(s->d_send);
     if (s->d_recv) (void)hipFree(s->d_recv);
     if (s->d_bnd_swaps) (void)hipFree(s->d_bnd_swaps);
+    if (s->d_checksum) (void)hipFree(s->d_checksum);
     delete s;
     c->pt = nullptr;
 }
@@ -455,14 +456,28 @@ int carma_pt_start(carma_ctx* h, const double* init, int ninit)
             }
         }
     }
-    std::mt19937_64 rng(s->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull + ((uint64_t)s->replica0 << 20) + s->slot0);
+    // The draws of a chain are keyed by (seed, the chain's GLOBAL slot, attempt), not by the order in which a process
+    // happens to visit its chains: a replica or a temperature gets the same starting value whichever rank holds it
+    // (carma_pt_shard), so a sharded run starts -- and, the sampler's streams being keyed the same way, continues --
+    // exactly as the single-process run does.
+    auto chain_rng = [&](size_t k, int round) {
+        const uint64_t gslot = ((uint64_t)s->replica0 + k / (size_t)s->T) * (uint64_t)s->T_global + s->slot0 + k % (size_t)s->T;
+        uint64_t z = s->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+        z ^= (gslot + 1) * 0xBF58476D1CE4E5B9ull;
+        z ^= ((uint64_t)round + 1) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return std::mt19937_64(z * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull);
+    };
     for (int round = 0; round < 4000; round++) {
         std::vector<size_t> todo;
         for (size_t k = 0; k < nchain; k++)
             if (!done[k]) todo.push_back(k);
         if (todo.empty()) break;
         std::vector<double> cand(todo.size() * d), out(todo.size());
-        for (size_t i = 0; i < todo.size(); i++) draw_start(c, rng, &cand[i * d]);
+        for (size_t i = 0; i < todo.size(); i++) {
+            std::mt19937_64 rng = chain_rng(todo[i], round);
+            draw_start(c, rng, &cand[i * d]);
+        }
         int rc = carma_logdensity_batch(h, cand.data(), (int)todo.size(), 0, out.data());
         if (rc != CARMA_OK) return rc;
         for (size_t i = 0; i < todo.size(); i++) {

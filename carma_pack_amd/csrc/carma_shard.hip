@@ -1,18 +1,30 @@
 // carma_shard.hip -- ONE temperature ladder sharded across GPUs (BASELINE config 4).
 //
-// Every rank (one process per GPU) owns a contiguous block of the ladder's temperatures for all R replicas and
-// advances it with the sampler kernel of carma_pt.hip (RAM steps + the swaps inside the block).  The only coupling
-// between ranks is the adjacent-temperature exchange across a block boundary (ExchangeStep::DoStep,
-// /root/reference/src/include/steps.hpp:318-362; wiring src/carmcmc.cpp:147-157): per iteration and active boundary
-//     k_shard_pack   gathers (theta[d], logpost) of the boundary chain of all R replicas   -> send buffer, R (d+1) doubles
-//     ncclSend / ncclRecv (RCCL, grouped) with the rank on the other side of the boundary  <= ~20 KB: latency bound
-//     k_shard_swap   draws the swap uniform and applies the exchange
-// all enqueued on the sampler's stream: no host synchronisation, no host RNG, no host<->device copy per iteration.
-// The uniform is Philox keyed by (seed, global slot of the hotter chain, iteration), so both sides compute the same
-// decision from the same bits and nothing but the chain states crosses the link.  Boundaries alternate even / odd per
-// iteration (deterministic even-odd tempering), so a rank that holds a single temperature never has both of its
-// boundaries active at once.  A process may own several consecutive blocks (`nlocal`): a boundary between two of its
-// own blocks goes through ncclSend/ncclRecv to itself, which is what lets a one-GPU box exercise the RCCL path.
+// Every rank (one process per GPU) owns a contiguous block of the ladder's temperatures for all R replicas.  The only
+// coupling between ranks is the adjacent-temperature exchange across a block boundary (ExchangeStep::DoStep,
+// /root/reference/src/include/steps.hpp:318-362; wiring src/carmcmc.cpp:147-157).
+//
+// Round 3: THE SHARDED LADDER WALKS THE UNSHARDED LADDER'S TRAJECTORY, bit for bit.  An iteration of the one-GPU kernel
+// is "every chain takes its RAM step, then ONE sweep over the adjacent pairs from the hottest to the coldest"; here
+//     every block:  sampler kernel without its sweep (RAM steps only)
+//     then, from the hottest block to the coldest:
+//         boundary with the hotter neighbour   k_shard_pack -> ncclSend / ncclRecv (grouped) -> k_shard_swap
+//         the pairs inside the block           k_shard_sweep (hot -> cold, physical swaps)
+//         boundary with the colder neighbour   (the same exchange, seen from the other side)
+// i.e. the same pairs in the same order with the same Philox uniforms (keyed by seed, global slot of the hotter chain,
+// iteration): both sides of a boundary compute the same decision from the same bits, nothing but chain states crosses
+// the link, and the chain states after any number of iterations equal those of the unsharded run
+// (tests/test_gpu_ladder_shard.py).  (Round 2 proposed a boundary pair only every other iteration -- even boundaries on
+// even iterations -- which was a valid but DIFFERENT kernel: a sharded ladder mixed more slowly across its boundaries.)
+// All of it is enqueued on the sampler's stream: no host synchronisation, no host RNG, no host<->device copy per
+// iteration.  The hot -> cold order makes the boundary exchanges of one iteration a chain through the ranks, but a rank
+// only ever waits for its two neighbours: it starts its next RAM steps as soon as its own colder boundary is done, so
+// in the steady state an iteration costs a rank its kernel + two exchanges, whatever the number of ranks.
+// A process may own several consecutive blocks (`nlocal`): a boundary between two of its own blocks goes through
+// ncclSend/ncclRecv to itself, which is what lets a one-GPU box exercise the RCCL path.
+// SELF-CHECK: every boundary side folds (iteration, replica, decision, the two log-posteriors it compared) into a
+// checksum; at the end of a call the two sides of every boundary exchange their sums and a mismatch -- a transfer that
+// delivered something else than was sent, ranks that disagree about the ladder -- fails the call loudly.
 //
 // RCCL is bound at run time (dlopen of librccl.so.1: the copy PyTorch already loaded when there is one), so the
 // library itself has no link-time dependency on it; without RCCL carma_comm_* fail loudly.
@@ -23,6 +35,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/carma_mi355.h"
@@ -48,9 +61,8 @@ struct Rccl {
 static Rccl* rccl()
 {
     static Rccl api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;                              // (choose_order drives library calls from a thread pool)
+    std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so"};
         for (const char* nm : names) {
             api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
@@ -73,7 +85,7 @@ static Rccl* rccl()
                 api.lib = nullptr;
             }
         }
-    }
+    });
     return api.lib ? &api : nullptr;
 }
 
@@ -104,13 +116,24 @@ __global__ void k_shard_pack(const double* __restrict__ theta, const double* __r
     buf[i] = j < d ? theta[((size_t)r * T + mine) * d + j] : lp[(size_t)r * T + mine];
 }
 
+// order-independent fold of one boundary decision: both sides of a boundary must arrive at the same sum
+__device__ __forceinline__ unsigned long long shard_mix(unsigned long long iter, unsigned r, bool acc, double hot, double cold)
+{
+    unsigned long long h = iter * 0x9E3779B97F4A7C15ull + (unsigned long long)r * 0xC2B2AE3D27D4EB4Full + (acc ? 0x165667B19E3779F9ull : 0ull);
+    h ^= (unsigned long long)__double_as_longlong(hot) * 0xFF51AFD7ED558CCDull;
+    h ^= (unsigned long long)__double_as_longlong(cold) * 0xC4CEB9FE1A85EC53ull;
+    h ^= h >> 29;
+    return h * 0xBF58476D1CE4E5B9ull;
+}
+
 // ExchangeStep::DoStep (steps.hpp:318-362) for the pair (hot_slot, hot_slot - 1), one thread per replica.  `upper`: this
 // block holds the COLDER chain of the pair (its hottest temperature, `mine` = T - 1), the peer the hotter one.
-// alpha = (lp_cold - lp_hot) (1/T_hot - 1/T_cold)  (steps.hpp:331-332);  accept when log u < alpha (NaN rejects, :336-338).
+// alpha = (lp_cold - lp_hot) (1/T_hot - 1/T_cold)  (steps.hpp:331-332);  accept when log u < alpha (NaN rejects, :336-338)
+// -- the expression, the uniform and the comparison of the sampler kernels' own sweep (exchange_decide, carma_pt_core.h).
 __global__ void k_shard_swap(double* __restrict__ theta, double* __restrict__ lp, int R, int T, int d, int mine,
                              const double* __restrict__ recv, int upper, double t_mine, unsigned seed0, unsigned seed1,
                              unsigned long long iter, unsigned T_global, unsigned replica0, unsigned hot_slot,
-                             unsigned* __restrict__ nswap)
+                             unsigned* __restrict__ nswap_bnd, unsigned* __restrict__ nswap, unsigned long long* __restrict__ checksum)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
@@ -121,10 +144,44 @@ __global__ void k_shard_swap(double* __restrict__ theta, double* __restrict__ lp
     const double a = (cold - hot) * (1.0 / t_hot - 1.0 / t_cold);
     RngKey key{seed0, seed1, (replica0 + (unsigned)r) * T_global + hot_slot};
     const double logu = log(rng_uniform(key, iter, RNG_SWAP, 0));
-    if (logu < a) {
+    const bool acc = logu < a;
+    if (acc) {
         for (int j = 0; j < d; j++) theta[((size_t)r * T + mine) * d + j] = recv[(size_t)r * (d + 1) + j];
         lp[(size_t)r * T + mine] = ot_lp;
-        atomicAdd(nswap, 1u);
+        atomicAdd(nswap_bnd, 1u);
+        if (!upper) nswap[(size_t)r * T] += 1u;            // entry i of the statistics = swaps between temperature i and i - 1
+    }
+    atomicAdd(checksum, shard_mix(iter, (unsigned)r, acc, hot, cold));
+}
+
+// The pairs INSIDE a block, hottest first (the part of the sweep the sampler kernel was told to leave out): one thread
+// per replica walks hot -> cold and swaps the two chains' parameter vectors and stored log-posteriors in place
+// (exchange_sweep of carma_pt_core.h with the kernels' decision rule: log u < (lp_{i-1} - lp_i) (1/T_i - 1/T_{i-1})).
+__global__ void k_shard_sweep(double* __restrict__ theta, double* __restrict__ lp, int R, int T, int d,
+                              const double* __restrict__ temps, unsigned seed0, unsigned seed1, unsigned long long iter,
+                              unsigned T_global, unsigned replica0, unsigned slot0, unsigned* __restrict__ nswap)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double* th = theta + (size_t)r * T * d;
+    double* l = lp + (size_t)r * T;
+    const unsigned chain_base = (replica0 + (unsigned)r) * T_global + slot0;
+    for (int i = T - 1; i > 0; i--) {
+        const double hot = l[i], cold = l[i - 1];
+        const double dbeta = 1.0 / temps[i] - 1.0 / temps[i - 1];
+        const double a = (cold - hot) * dbeta;
+        RngKey key{seed0, seed1, chain_base + (unsigned)i};
+        const double logu = log(rng_uniform(key, iter, RNG_SWAP, 0));
+        if (logu < a) {
+            for (int j = 0; j < d; j++) {
+                const double tmp = th[(size_t)i * d + j];
+                th[(size_t)i * d + j] = th[(size_t)(i - 1) * d + j];
+                th[(size_t)(i - 1) * d + j] = tmp;
+            }
+            l[i] = cold;
+            l[i - 1] = hot;
+            nswap[(size_t)r * T + i] += 1u;
+        }
     }
 }
 
@@ -263,6 +320,8 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
             if (e == hipSuccess) e = hipMalloc(&s->d_recv, sizeof(double) * nbuf);
             if (e == hipSuccess) e = hipMalloc(&s->d_bnd_swaps, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(s->d_bnd_swaps, 0, sizeof(unsigned));
+            if (e == hipSuccess) e = hipMalloc(&s->d_checksum, 4 * sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipMemset(s->d_checksum, 0, 4 * sizeof(unsigned long long));
             if (e != hipSuccess) return hip_fail(e, "carma_pt_iterate_sharded: boundary buffers");
         }
     }
@@ -273,67 +332,31 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
         if (e != hipSuccess) return hip_fail(e, "carma_pt_iterate_sharded");
     }
     const unsigned tpb = 64;
-    for (long it = 0; it < niter; it++) {
-        const unsigned long long iter = s0->iter;     // index of the iteration about to run (== every block's)
-        for (int i = 0; i < nlocal; i++) {
-            int rc = pt_enqueue(cs[i], 1, 1, 0, nullptr, st);
-            if (rc != CARMA_OK) return rc;
-        }
-        const bool save_now = save_thin > 0 && d_samples && s0->slot0 == 0 && ((it + 1) % save_thin) == 0;
-        auto save = [&]() {
-            if (!save_now) return;
-            const long sidx = (it + 1) / save_thin - 1;
-            if (sidx < sample_cap)
-                hipLaunchKernelGGL(k_shard_save, dim3((unsigned)((R * (d + 1) + tpb - 1) / tpb)), dim3(tpb), 0, st, s0->d_theta, s0->d_lp,
-                                   R, s0->T, d, sidx, sample_cap, d_samples, d_slp);
-        };
-        if (nblocks == 1) {
-            save();
-            continue;
-        }
-        const int parity = (int)(iter & 1ull);
-        // boundary k sits between block k and block k + 1; active when k has the iteration's parity.  A block has at
-        // most one active boundary per iteration, so one send and one receive buffer per block are enough.
-        struct Side {
-            int local;      // index of the local block
-            int mine;       // its boundary temperature (local index)
-            int upper;      // 1: the peer block is the hotter one
-            int peer;       // rank that owns the block on the other side
-            int k;          // boundary
-        };
-        std::vector<Side> sides;
-        for (int i = 0; i < nlocal; i++) {
-            const int gb = rank * nlocal + i;
-            if (gb + 1 < nblocks && (gb & 1) == parity) sides.push_back({i, cs[i]->pt->T - 1, 1, (gb + 1) / nlocal, gb});
-            if (gb > 0 && ((gb - 1) & 1) == parity) sides.push_back({i, 0, 0, (gb - 1) / nlocal, gb - 1});
-        }
-        if (sides.empty()) {
-            save();
-            continue;
-        }
-        for (const Side& sd : sides) {
-            PtState* s = cs[sd.local]->pt;
+    struct Side {
+        int local;      // index of the local block
+        int mine;       // its boundary temperature (local index)
+        int upper;      // 1: the peer block is the hotter one
+        int peer;       // rank that owns the block on the other side
+    };
+    // one boundary, as seen from this process: one side (the peer is another rank) or both (lower block first)
+    auto exchange = [&](const Side* sides, int nsides, unsigned long long iter) -> int {
+        for (int a = 0; a < nsides; a++) {
+            PtState* s = cs[sides[a].local]->pt;
             hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((nbuf + tpb - 1) / tpb)), dim3(tpb), 0, st, s->d_theta, s->d_lp, R,
-                               s->T, d, sd.mine, s->temps[sd.mine], s->d_send);
+                               s->T, d, sides[a].mine, s->temps[sides[a].mine], s->d_send);
         }
-        e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "k_shard_pack");
+        hipError_t el = hipGetLastError();
+        if (el != hipSuccess) return hip_fail(el, "k_shard_pack");
         // Sends and receives between one pair of ranks are matched in issue order; the only pair with two transfers in
-        // flight is this rank with itself (a boundary between two of its own blocks), where the lower block's data has
-        // to land in the upper block's buffer and vice versa -- so every side issues its send, then the receive INTO THE
-        // OTHER SIDE'S BUFFER when the peer is this rank (sides of one boundary are adjacent in `sides`: lower first).
+        // flight is this rank with itself, where the lower block's data has to land in the upper block's buffer and vice
+        // versa -- so every side issues its send, then the receive INTO THE OTHER SIDE'S BUFFER when the peer is this rank.
         ncclResult_t nr = api->GroupStart();
         if (nr != ncclSuccess) return rccl_fail(nr, "ncclGroupStart");
-        for (size_t a = 0; a < sides.size(); a++) {
-            const Side& sd = sides[a];
-            PtState* s = cs[sd.local]->pt;
-            double* recv_into = s->d_recv;
-            if (sd.peer == rank) {
-                const size_t other = (sd.upper ? a + 1 : a - 1);      // the other side of the same boundary
-                recv_into = cs[sides[other].local]->pt->d_recv;
-            }
-            nr = api->Send(s->d_send, nbuf, ncclDouble, sd.peer, cm->nccl, st);
-            if (nr == ncclSuccess) nr = api->Recv(recv_into, nbuf, ncclDouble, sd.peer, cm->nccl, st);
+        for (int a = 0; a < nsides; a++) {
+            PtState* s = cs[sides[a].local]->pt;
+            double* recv_into = nsides == 2 ? cs[sides[1 - a].local]->pt->d_recv : s->d_recv;
+            nr = api->Send(s->d_send, nbuf, ncclDouble, sides[a].peer, cm->nccl, st);
+            if (nr == ncclSuccess) nr = api->Recv(recv_into, nbuf, ncclDouble, sides[a].peer, cm->nccl, st);
             if (nr != ncclSuccess) {
                 (void)api->GroupEnd();
                 return rccl_fail(nr, "ncclSend/ncclRecv");
@@ -341,30 +364,137 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
         }
         nr = api->GroupEnd();
         if (nr != ncclSuccess) return rccl_fail(nr, "ncclGroupEnd");
-        for (const Side& sd : sides) {
-            PtState* s = cs[sd.local]->pt;
-            const unsigned hot_slot = sd.upper ? s->slot0 + (unsigned)s->T : s->slot0;      // global slot of the hotter chain
+        for (int a = 0; a < nsides; a++) {
+            PtState* s = cs[sides[a].local]->pt;
+            const unsigned hot_slot = sides[a].upper ? s->slot0 + (unsigned)s->T : s->slot0;      // global slot of the hotter chain
             hipLaunchKernelGGL(k_shard_swap, dim3((unsigned)((R + tpb - 1) / tpb)), dim3(tpb), 0, st, s->d_theta, s->d_lp, R, s->T, d,
-                               sd.mine, s->d_recv, sd.upper, s->temps[sd.mine], (unsigned)(s->seed & 0xffffffffu),
-                               (unsigned)(s->seed >> 32), iter, s->T_global, s->replica0, hot_slot, s->d_bnd_swaps);
+                               sides[a].mine, s->d_recv, sides[a].upper, s->temps[sides[a].mine], (unsigned)(s->seed & 0xffffffffu),
+                               (unsigned)(s->seed >> 32), iter, s->T_global, s->replica0, hot_slot, s->d_bnd_swaps, s->d_nswap,
+                               s->d_checksum + (sides[a].upper ? 1 : 0));
             s->bnd_proposed += (unsigned long long)R;
         }
-        save();
-        e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "k_shard_swap");
-    }
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return hip_fail(e, "carma_pt_iterate_sharded");
-    for (int i = 0; i < nlocal; i++) {
-        bool aborted = false;
-        int rc = pt_check_abort(cs[i], &aborted);
-        if (rc != CARMA_OK) return rc;
-        if (aborted) {
-            set_error("carma_pt_iterate_sharded: a cross-workgroup swap barrier of the sampler kernel timed out");
-            return CARMA_EHIP;
+        el = hipGetLastError();
+        if (el != hipSuccess) return hip_fail(el, "k_shard_swap");
+        return CARMA_OK;
+    };
+    int rc_loop = CARMA_OK;
+    for (long it = 0; it < niter && rc_loop == CARMA_OK; it++) {
+        const unsigned long long iter = s0->iter;     // index of the iteration about to run (== every block's)
+        // one block: the sampler kernel with its own sweep; several: RAM steps only, the sweep follows piece by piece
+        for (int i = 0; i < nlocal && rc_loop == CARMA_OK; i++) rc_loop = pt_enqueue(cs[i], 1, nblocks == 1 ? 1 : 0, 0, nullptr, st);
+        if (rc_loop != CARMA_OK) break;
+        if (nblocks > 1) {
+            // the sweep of the whole ladder, hottest pair first, as far as this process holds a side of it
+            for (int i = nlocal - 1; i >= 0 && rc_loop == CARMA_OK; i--) {
+                const int gb = rank * nlocal + i;
+                PtState* s = cs[i]->pt;
+                if (i == nlocal - 1 && gb + 1 < nblocks) {             // the hotter neighbour is another rank's block
+                    const Side sd{i, s->T - 1, 1, rank + 1};
+                    rc_loop = exchange(&sd, 1, iter);
+                    if (rc_loop != CARMA_OK) break;
+                }
+                if (s->T > 1) {
+                    hipLaunchKernelGGL(k_shard_sweep, dim3((unsigned)((R + tpb - 1) / tpb)), dim3(tpb), 0, st, s->d_theta, s->d_lp, R, s->T,
+                                       d, s->d_temps, (unsigned)(s->seed & 0xffffffffu), (unsigned)(s->seed >> 32), iter, s->T_global,
+                                       s->replica0, s->slot0, s->d_nswap);
+                    e = hipGetLastError();
+                    if (e != hipSuccess) {
+                        rc_loop = hip_fail(e, "k_shard_sweep");
+                        break;
+                    }
+                }
+                if (gb > 0) {
+                    if (i > 0) {                                        // the colder neighbour is this process's block i - 1
+                        const Side both[2] = {{i - 1, cs[i - 1]->pt->T - 1, 1, rank}, {i, 0, 0, rank}};
+                        rc_loop = exchange(both, 2, iter);
+                    } else {
+                        const Side sd{i, 0, 0, rank - 1};
+                        rc_loop = exchange(&sd, 1, iter);
+                    }
+                }
+            }
+            if (rc_loop != CARMA_OK) break;
+        }
+        if (save_thin > 0 && d_samples && s0->slot0 == 0 && ((it + 1) % save_thin) == 0) {
+            const long sidx = (it + 1) / save_thin - 1;
+            if (sidx < sample_cap)
+                hipLaunchKernelGGL(k_shard_save, dim3((unsigned)((R * (d + 1) + tpb - 1) / tpb)), dim3(tpb), 0, st, s0->d_theta, s0->d_lp,
+                                   R, s0->T, d, sidx, sample_cap, d_samples, d_slp);
         }
     }
-    return CARMA_OK;
+    // SELF-CHECK: the two sides of every boundary must have folded the same decisions on the same log-posteriors.  One
+    // more (8-byte) exchange per boundary and CALL, in the sweep's order.
+    std::vector<unsigned long long> mine_sum, peer_sum;
+    if (rc_loop == CARMA_OK && nblocks > 1) {
+        ncclResult_t nr = ncclSuccess;
+        for (int i = nlocal - 1; i >= 0 && nr == ncclSuccess; i--) {
+            const int gb = rank * nlocal + i;
+            PtState* s = cs[i]->pt;
+            // d_checksum: [0] lower side, [1] upper side of this block, [2] / [3] what the peers of those sides report
+            if (i == nlocal - 1 && gb + 1 < nblocks) {
+                nr = api->GroupStart();
+                if (nr == ncclSuccess) nr = api->Send(s->d_checksum + 1, 1, ncclUint64, rank + 1, cm->nccl, st);
+                if (nr == ncclSuccess) nr = api->Recv(s->d_checksum + 3, 1, ncclUint64, rank + 1, cm->nccl, st);
+                if (nr == ncclSuccess) nr = api->GroupEnd();
+            }
+            if (gb > 0 && nr == ncclSuccess) {
+                nr = api->GroupStart();
+                if (i > 0) {
+                    PtState* sl = cs[i - 1]->pt;
+                    if (nr == ncclSuccess) nr = api->Send(sl->d_checksum + 1, 1, ncclUint64, rank, cm->nccl, st);
+                    if (nr == ncclSuccess) nr = api->Recv(s->d_checksum + 2, 1, ncclUint64, rank, cm->nccl, st);
+                    if (nr == ncclSuccess) nr = api->Send(s->d_checksum, 1, ncclUint64, rank, cm->nccl, st);
+                    if (nr == ncclSuccess) nr = api->Recv(sl->d_checksum + 3, 1, ncclUint64, rank, cm->nccl, st);
+                } else {
+                    if (nr == ncclSuccess) nr = api->Send(s->d_checksum, 1, ncclUint64, rank - 1, cm->nccl, st);
+                    if (nr == ncclSuccess) nr = api->Recv(s->d_checksum + 2, 1, ncclUint64, rank - 1, cm->nccl, st);
+                }
+                if (nr == ncclSuccess) nr = api->GroupEnd();
+            }
+        }
+        if (nr != ncclSuccess) rc_loop = rccl_fail(nr, "boundary self-check exchange");
+    }
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc_loop == CARMA_OK) rc_loop = hip_fail(e, "carma_pt_iterate_sharded");
+    bool any_abort = false;
+    for (int i = 0; i < nlocal; i++) {
+        bool aborted = false;
+        (void)pt_check_abort(cs[i], &aborted);
+        if (aborted) {
+            any_abort = true;
+            if (cs[i]->pt->d_abort) (void)hipMemset(cs[i]->pt->d_abort, 0, sizeof(unsigned));
+        }
+    }
+    if (any_abort && rc_loop == CARMA_OK) {
+        set_error("carma_pt_iterate_sharded: a cross-workgroup swap barrier of the sampler kernel timed out");
+        rc_loop = CARMA_EHIP;
+    }
+    if (rc_loop == CARMA_OK && nblocks > 1) {
+        for (int i = 0; i < nlocal && rc_loop == CARMA_OK; i++) {
+            const int gb = rank * nlocal + i;
+            unsigned long long h[4] = {0, 0, 0, 0};
+            e = hipMemcpy(h, cs[i]->pt->d_checksum, sizeof h, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                rc_loop = hip_fail(e, "boundary self-check");
+                break;
+            }
+            const bool lower_ok = gb == 0 || h[0] == h[2], upper_ok = gb + 1 >= nblocks || h[1] == h[3];
+            cs[i]->pt->bnd_check = (lower_ok && upper_ok) ? 1 : -1;
+            if (!lower_ok || !upper_ok) {
+                set_error("carma_pt_iterate_sharded: rank %d block %d and its %s neighbour took different swap decisions (checksums %016llx vs "
+                          "%016llx): the boundary exchange is broken", rank, gb, lower_ok ? "hotter" : "colder",
+                          lower_ok ? h[1] : h[0], lower_ok ? h[3] : h[2]);
+                rc_loop = CARMA_EHIP;
+            }
+        }
+    }
+    if (rc_loop != CARMA_OK) {
+        // A failure somewhere inside the loop leaves the blocks at different points of an iteration: the chain states
+        // are not a sample of anything any more.  Refuse to continue from them (carma_pt_start / carma_pt_set_chains
+        // re-arm the sampler); peers of a failed rank are left waiting in their receive -- tear the communicator down.
+        for (int i = 0; i < nlocal; i++) cs[i]->pt->started = false;
+    }
+    return rc_loop;
 }
 
 extern "C" {
@@ -408,6 +538,33 @@ int carma_pt_sample_sharded(carma_ctx* const* shards, int nlocal, int nsamples, 
         if (e != hipSuccess) rc = hip_fail(e, "carma_pt_sample_sharded: D2H");
     }
     return rc;
+}
+
+int carma_pt_boundary_check(carma_ctx* h)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt) return CARMA_EINVAL;
+    return reinterpret_cast<Ctx*>(h)->pt->bnd_check;
+}
+
+int carma_pt_sweep(carma_ctx* h)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || !reinterpret_cast<Ctx*>(h)->pt->started || reinterpret_cast<Ctx*>(h)->pt->iter == 0) {
+        set_error("carma_pt_sweep: no iteration to sweep after");
+        return CARMA_EINVAL;
+    }
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (s->T > 1) {
+        hipLaunchKernelGGL(k_shard_sweep, dim3((unsigned)((s->R + 63) / 64)), dim3(64), 0, c->stream, s->d_theta, s->d_lp, s->R, s->T, c->d,
+                           s->d_temps, (unsigned)(s->seed & 0xffffffffu), (unsigned)(s->seed >> 32), s->iter - 1, s->T_global,
+                           s->replica0, s->slot0, s->d_nswap);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(e, "carma_pt_sweep");
+    }
+    return CARMA_OK;
 }
 
 int carma_pt_boundary_stats(carma_ctx* h, unsigned long long* proposed, unsigned long long* accepted)

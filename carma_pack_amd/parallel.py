@@ -14,8 +14,12 @@ adjacent-temperature exchange (ExchangeStep, /root/reference/src/include/steps.h
     doubles each way (<= 20 KB: latency bound, never link bound).  Both sides compute the SAME
     Metropolis decision from a counter-based uniform keyed by the hotter chain's global slot
     (``philox_uniform`` reproduces carma_rng.h bit for bit), so no decision is communicated.
-    Boundaries alternate even/odd per iteration so a rank that holds a single temperature never has
-    both of its boundaries active at once (deterministic even-odd parallel tempering).
+    An iteration is the one-GPU sampler's: RAM steps everywhere, then ONE sweep over all adjacent pairs
+    from the hottest to the coldest -- boundary with the hotter rank, the pairs inside the block,
+    boundary with the colder rank -- so the sharded ladder walks the unsharded ladder's trajectory.
+  * ``sharded_pt_run`` -- independent replicas (whole ladders) split by rank, no data-path collective
+    during sampling; the coldest chains are gathered to rank 0 at the end (the reference's driver
+    returns the coldest chain, src/carmcmc.cpp:164-176, src/samplers.cpp:118-124).
 """
 import numpy as np
 
@@ -157,10 +161,9 @@ class LadderShard(object):
             other = self._swap_with(peer, torch.cat([th[:, mine, :], lp[:, mine, None]], dim=1).contiguous())
             my_lp, ot_lp = lp[:, mine].clone(), other[:, d]
             hot_lp, cold_lp = (ot_lp, my_lp) if upper else (my_lp, ot_lp)
-            # ExchangeStep::DoStep (steps.hpp:331-339); both ranks evaluate the same expression on the same bits
-            alpha = torch.exp((cold_lp - hot_lp) / t_hot + (hot_lp - cold_lp) / t_cold).clamp(max=1.0)
-            alpha = torch.where(torch.isfinite(alpha), alpha, torch.zeros_like(alpha))
-            acc = torch.from_numpy(u).to(th.device) < alpha
+            # ExchangeStep::DoStep (steps.hpp:331-339) in the kernels' form, log u < (lp_cold - lp_hot) (1/T_hot - 1/T_cold)
+            # (a NaN rejects); both ranks evaluate the same expression on the same bits
+            acc = torch.from_numpy(np.log(u)).to(th.device) < (cold_lp - hot_lp) * (1.0 / t_hot - 1.0 / t_cold)
             th[:, mine, :] = torch.where(acc[:, None], other[:, :d], th[:, mine, :])
             lp[:, mine] = torch.where(acc, ot_lp, my_lp)
             self.nswap_boundary += int(acc.sum())
@@ -172,10 +175,8 @@ class LadderShard(object):
         other = self._swap_with(peer, send).cpu().numpy()
         my_lp, ot_lp = lp[:, mine], other[:, d]
         hot_lp, cold_lp = (ot_lp, my_lp) if upper else (my_lp, ot_lp)
-        with np.errstate(over="ignore", invalid="ignore"):
-            alpha = np.minimum(np.exp((cold_lp - hot_lp) / t_hot + (hot_lp - cold_lp) / t_cold), 1.0)
-        alpha = np.where(np.isfinite(alpha), alpha, 0.0)
-        acc = u < alpha
+        with np.errstate(invalid="ignore"):
+            acc = np.log(u) < (cold_lp - hot_lp) * (1.0 / t_hot - 1.0 / t_cold)
         if acc.any():
             th[acc, mine, :] = other[acc, :d]
             lp[acc, mine] = other[acc, d]
@@ -193,8 +194,28 @@ class LadderShard(object):
             raise ValueError("communicator does not span the ladder's ranks")
         self._comm = comm
 
+    def _sweep_inside(self):
+        """The adjacent pairs inside this block, hottest first (the kernels' exchange sweep, carma_pt_core.h)."""
+        if self.T_local < 2:
+            return
+        if hasattr(self.b, "pt_sweep"):
+            self.b.pt_sweep()
+            return
+        th, lp = self.b.pt_get_chains()
+        for i in range(self.T_local - 1, 0, -1):
+            slot = self.slot0 + i
+            u = philox_uniform_chains(self.seed, np.arange(self.R) * self.T_global + slot, self.iteration, RNG_SWAP)
+            dbeta = 1.0 / float(self.temps[slot]) - 1.0 / float(self.temps[slot - 1])
+            with np.errstate(invalid="ignore"):
+                acc = np.log(u) < (lp[:, i - 1] - lp[:, i]) * dbeta
+            if acc.any():
+                th[acc, i, :], th[acc, i - 1, :] = th[acc, i - 1, :].copy(), th[acc, i, :].copy()
+                lp[acc, i], lp[acc, i - 1] = lp[acc, i - 1].copy(), lp[acc, i].copy()
+        self.b.pt_set_chains(th, lp)
+
     def iterate(self, niter):
-        """niter x (local RAM steps + local swap sweep, then alternating even/odd boundary swaps)."""
+        """niter x (RAM steps, then the ladder's sweep hot -> cold: boundary with the hotter rank, the pairs inside the
+        block, boundary with the colder rank)."""
         if getattr(self, "_comm", None) is not None:
             from . import _lib
             _lib.pt_iterate_sharded([self.b], niter, self._comm)
@@ -202,13 +223,14 @@ class LadderShard(object):
             self.nprop_boundary, self.nswap_boundary = self.b.pt_boundary_stats()
             return
         for _ in range(int(niter)):
-            self.b.pt_iterate(1, do_exchange=True)
-            if self.world > 1:
-                parity = self.iteration & 1
-                # boundary k sits between rank k and rank k+1; even boundaries on even iterations
-                if self.rank + 1 < self.world and (self.rank & 1) == parity:
+            if self.world == 1:
+                self.b.pt_iterate(1, do_exchange=True)
+            else:
+                self.b.pt_iterate(1, do_exchange=False)
+                if self.rank + 1 < self.world:
                     self._exchange_boundary(upper=True)
-                if self.rank > 0 and ((self.rank - 1) & 1) == parity:
+                self._sweep_inside()
+                if self.rank > 0:
                     self._exchange_boundary(upper=False)
             self.iteration += 1
 
@@ -218,3 +240,47 @@ class LadderShard(object):
             return self._th[:, 0, :].cpu().numpy(), self._lp[:, 0].cpu().numpy()
         th, lp = self.b.pt_get_chains()
         return th[:, 0, :], lp[:, 0]
+
+
+def sharded_pt_run(make_sampler, ntemps, nreplicas_total, sample_size, burnin, thin=1, init=None, seed=0, dist=None,
+                   device="cpu"):
+    """Independent replicas of the parallel-tempering sampler split by rank (mode 2).
+
+    `make_sampler()` returns this rank's backend (a ``carma_pack_amd.Context``; the CPU tests plug in a stand-in with the
+    same pt_* interface).  Rank r runs replicas [lo, hi) = ``shard_slice(nreplicas_total, r, world)`` with their GLOBAL
+    indices (``pt_shard(ntemps, 0, lo)``: the Philox streams are keyed by the global chain slot, so the result does
+    not depend on how the replicas are split), no collective while sampling; at the end the coldest-chain samples are
+    gathered on every rank (``all_gather`` -- RCCL on device tensors with backend "nccl", gloo in the CPU suite) and
+    returned as (samples[R_total][sample_size][d], logposts[R_total][sample_size]) -- the array a single process
+    running all replicas returns (the reference returns the coldest chain: src/carmcmc.cpp:164-176,
+    src/samplers.cpp:118-124)."""
+    import torch
+    b = make_sampler()
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if nreplicas_total < world:
+        raise ValueError("need at least one replica per rank")
+    sl = shard_slice(nreplicas_total, rank, world)
+    R = sl.stop - sl.start
+    b.pt_create(ntemps, R, burnin, seed=seed)
+    b.pt_shard(ntemps, 0, sl.start)
+    b.pt_start(init)
+    b.pt_iterate(burnin, do_exchange=True)
+    samples, logposts = b.pt_sample(sample_size, thin)
+    samples, logposts = np.ascontiguousarray(samples), np.ascontiguousarray(logposts)
+    if world == 1:
+        return samples, logposts
+    d = samples.shape[2]
+    width = (nreplicas_total + world - 1) // world           # all_gather wants equal shapes: pad the short ranks
+    buf = torch.full((width, sample_size, d + 1), float("nan"), dtype=torch.float64, device=device)
+    buf[:R, :, :d] = torch.from_numpy(samples).to(device)
+    buf[:R, :, d] = torch.from_numpy(logposts).to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out_s = np.empty((nreplicas_total, sample_size, d))
+    out_l = np.empty((nreplicas_total, sample_size))
+    for r in range(world):
+        s_ = shard_slice(nreplicas_total, r, world)
+        part = parts[r][: s_.stop - s_.start].cpu().numpy()
+        out_s[s_], out_l[s_] = part[:, :, :d], part[:, :, d]
+    return out_s, out_l

@@ -213,11 +213,14 @@ long carma_pt_iterations_done(const carma_ctx* h);
  * carma_pt_iterate_sharded: `shards` = the nlocal (normally 1) contexts of this process, each created with
  * carma_pt_create + carma_pt_shard for a contiguous block of temperature slots, consecutive blocks in ascending order;
  * the blocks of all ranks tile the ladder in rank order with the same nlocal everywhere.  Per iteration: the sampler
- * kernel advances every block (RAM steps + swaps inside the block), then the chains on either side of every ACTIVE
- * block boundary (even boundaries on even iterations, odd on odd) are exchanged for all replicas: pack kernel ->
- * ncclSend/ncclRecv of R (d+1) + 1 doubles -> swap kernel, all on the sampler's stream with no host synchronisation;
- * both sides draw the same Philox uniform (seed, hotter chain's global slot, iteration) and take the same decision.
- * Returns after the last iteration has completed.  comm may be NULL when the process owns the whole ladder as one block.
+ * kernel advances every block (RAM steps only), then the ladder's sweep runs hot -> cold over ALL adjacent pairs --
+ * inside a block by a sweep kernel, across a block boundary by pack kernel -> ncclSend/ncclRecv of R (d+1) + 1 doubles ->
+ * swap kernel -- all on the sampler's stream with no host synchronisation; both sides of a boundary draw the same Philox
+ * uniform (seed, hotter chain's global slot, iteration) and take the same decision.  Same pairs, same order, same
+ * uniforms as the one-GPU sampler: the chain states equal those of the unsharded run bit for bit.
+ * Returns after the last iteration has completed, and after the two sides of every boundary have compared a checksum of
+ * their decisions (a mismatch fails the call).  After a failed call the blocks refuse to continue (carma_pt_start /
+ * carma_pt_set_chains re-arm them).  comm may be NULL when the process owns the whole ladder as one block.
  */
 int carma_comm_unique_id(void* out128);
 carma_comm* carma_comm_create(const void* id128, int nranks, int rank, int device);
@@ -230,8 +233,15 @@ int carma_pt_iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, c
  * owns temperature 0 receives samples = [R][nsamples][d], logposts = [R][nsamples] (host), the others pass NULL. */
 int carma_pt_sample_sharded(carma_ctx* const* shards, int nlocal, int nsamples, int thin, carma_comm* comm,
                             double* samples, double* logposts);
-/* boundary swaps this block took part in: proposed = R per active boundary and iteration; accepted */
+/* boundary swaps this block took part in: proposed = R per boundary and iteration; accepted */
 int carma_pt_boundary_stats(carma_ctx* h, unsigned long long* proposed, unsigned long long* accepted);
+/* result of the last call's boundary self-check for this block: 1 = both sides of its boundaries folded the same
+ * decisions, -1 = they differed (the call failed), 0 = no sharded call yet */
+int carma_pt_boundary_check(carma_ctx* h);
+/* The sweep over the adjacent pairs INSIDE this block for the iteration just run with do_exchange = 0 (hot -> cold,
+ * ExchangeStep, src/include/steps.hpp:318-362): the building block of a sharded iteration for host programs that move
+ * the boundary chains themselves (carma_pack_amd/parallel.py over torch.distributed). */
+int carma_pt_sweep(carma_ctx* h);
 
 #ifdef __cplusplus
 }

@@ -79,13 +79,31 @@ def _run(resident):
     return res
 
 
+def _unsharded():
+    """The same ladder on ONE context (the one-GPU sampler kernel with its own sweep): what every sharded run must equal."""
+    import carma_pack_amd as cpa
+    from carma_pack_amd import parallel as par
+    t, y, e = _series()
+    ctx = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std())
+    ctx.pt_create(TG, R, NITER, seed=SEED, temperatures=par.ladder_temperatures(TG))
+    ctx.pt_shard(TG, 0, 0)
+    ctx.pt_start(None)
+    ctx.pt_iterate(NITER)
+    th, lp = ctx.pt_get_chains()
+    return th, lp, ctx.pt_stats()
+
+
 def test_ladder_sharded_over_two_ranks():
     import oracle as orc
     res = _run(resident=True)
     (r0, sw0, pr0, s0, th0, lp0), (r1, sw1, pr1, s1, th1, lp1) = res
     assert (s0, th0.shape[1], s1, th1.shape[1]) == (0, 3, 3, 2)
-    assert sw0 == sw1 and pr0 == pr1 == R * (NITER // 2)          # the single boundary is even: active every other iteration
+    assert sw0 == sw1 and pr0 == pr1 == R * NITER                # the boundary pair is proposed every iteration
     assert 0 < sw0 < pr0
+    # THE SHARDED LADDER IS THE UNSHARDED ONE: same starting values (keyed by the global chain slot), same RAM steps,
+    # same sweep order, same uniforms -> the same chain states bit for bit
+    uth, ulp, _ = _unsharded()
+    assert np.array_equal(np.concatenate([th0, th1], axis=1), uth) and np.array_equal(np.concatenate([lp0, lp1], axis=1), ulp)
     # stored log-posterior == LogDensity(theta) for every chain on both ranks, swapped ones included
     t, y, e = _series()
     ms = 10.0 * y.std()
@@ -104,6 +122,7 @@ def test_ladder_sharded_over_two_ranks():
 
 
 def _native_worker(q, nblocks_T, rccl, nsample=0):
+    # (every block's self-check must have agreed)
     """One process owning the whole ladder as consecutive blocks; boundaries go through carma_pt_iterate_sharded."""
     import carma_pack_amd as cpa
     from carma_pack_amd import _lib, parallel as par
@@ -124,6 +143,7 @@ def _native_worker(q, nblocks_T, rccl, nsample=0):
     out = []
     for c in ctxs:
         th, lp = c.pt_get_chains()
+        assert c.pt_boundary_check() == (1 if len(nblocks_T) > 1 else 0)
         out.append((th, lp, c.pt_boundary_stats(), c.pt_iterations_done()))
     q.put(out + ([samples] if nsample else []))
     if comm is not None:
@@ -157,8 +177,17 @@ def test_native_rccl_exchange_walks_the_same_trajectory():
     assert np.array_equal(nth0, th0) and np.array_equal(nlp0, lp0)
     assert np.array_equal(nth1, th1) and np.array_equal(nlp1, lp1)
     assert (npr0, nsw0) == (pr0, sw0) and (npr1, nsw1) == (pr1, sw1)
-    # one block per temperature (BASELINE config 4's layout: 5 blocks of 1): both kinds of boundary, every iteration
+    # ... and both are the unsharded ladder, whatever the partition: one block per temperature (BASELINE config 4's
+    # layout: 5 blocks of 1), 2 + 2 + 1, and without RCCL one block of 5
+    uth, ulp, (uacc, uswp) = _unsharded()
+    assert np.array_equal(np.concatenate([nth0, nth1], axis=1), uth) and np.array_equal(np.concatenate([nlp0, nlp1], axis=1), ulp)
+    for blocks in ([2, 2, 1], [5]):
+        out = _run_native(blocks, rccl=len(blocks) > 1)
+        assert np.array_equal(np.concatenate([o[0] for o in out], axis=1), uth), blocks
+        assert np.array_equal(np.concatenate([o[1] for o in out], axis=1), ulp), blocks
     one = _run_native([1, 1, 1, 1, 1])
+    assert np.array_equal(np.concatenate([o[0] for o in one], axis=1), uth)
+    assert np.array_equal(np.concatenate([o[1] for o in one], axis=1), ulp)
     import oracle as orc
     t, y, e = _series()
     m = orc.OracleModel(t, y, e, P, Q, max_stdev=10.0 * y.std())
@@ -170,7 +199,7 @@ def test_native_rccl_exchange_walks_the_same_trajectory():
                   arbiter=lambda i: loglik_truth(t, y, e, th[i], P, Q)[0])
     prop = [o[2][0] for o in one]
     acc = [o[2][1] for o in one]
-    assert prop == [R * NITER // 2, R * NITER, R * NITER, R * NITER, R * NITER // 2]     # inner blocks: a boundary every iteration
+    assert prop == [R * NITER, 2 * R * NITER, 2 * R * NITER, 2 * R * NITER, R * NITER]     # every boundary, every iteration
     assert all(0 < a < p_ for a, p_ in zip(acc, prop))
     # boundary k is counted once by either side: blocks 0 and 4 see one boundary, the inner blocks two
     assert acc[0] + acc[2] + acc[4] == acc[1] + acc[3]

@@ -46,8 +46,10 @@ def test_shard_slice_covers_everything():
 
 
 class ToyBackend(object):
-    """pt_* interface on the CPU: random-walk Metropolis on a tempered standard normal; the last
-    component of theta is an immutable chain tag so that swaps can be audited."""
+    """pt_* interface on the CPU: random-walk Metropolis on a tempered standard normal; the last component of theta is
+    an immutable chain tag so that swaps can be audited.  Like the device sampler, every draw is a counter-based
+    function of (seed, GLOBAL chain slot, iteration) -- so a ladder or a set of replicas walks the same trajectory
+    however it is split over ranks, which is what the tests below pin."""
 
     def __init__(self, d):
         self.d = d
@@ -57,17 +59,26 @@ class ToyBackend(object):
         return -0.5 * np.sum(th[..., :-1] ** 2, axis=-1)
 
     def pt_create(self, T, R, adapt_iters, seed=0, temperatures=None):
-        self.T, self.R, self.temps = T, R, np.asarray(temperatures, dtype=float)
-        self.rng = np.random.default_rng(seed + 17)
+        self.T, self.R, self.seed, self.it = T, R, int(seed), 0
+        self.temps = np.asarray(temperatures, dtype=float) if temperatures is not None else par.ladder_temperatures(T)
+        self.T_global, self.slot0, self.replica0 = T, 0, 0
+        self.nswap = np.zeros((R, T), dtype=int)
 
     def pt_shard(self, T_global, slot0, replica0):
-        self.T_global, self.slot0 = T_global, slot0
+        self.T_global, self.slot0, self.replica0 = T_global, slot0, replica0
+
+    def _slots(self):
+        return ((self.replica0 + np.arange(self.R))[:, None] * self.T_global + self.slot0 + np.arange(self.T)[None, :]).ravel()
+
+    def _normal(self, it, j):
+        g = self._slots()
+        u1 = par.philox_uniform_chains(self.seed, g, it, par.RNG_PROPOSAL, 2 * j)
+        u2 = par.philox_uniform_chains(self.seed, g, it, par.RNG_PROPOSAL, 2 * j + 1)
+        return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).reshape(self.R, self.T)
 
     def pt_start(self, init=None):
-        self.th = self.rng.standard_normal((self.R, self.T, self.d))
-        for r in range(self.R):
-            for c in range(self.T):
-                self.th[r, c, -1] = 1000 * r + self.slot0 + c      # tag
+        self.th = np.stack([self._normal(2 ** 40, j) for j in range(self.d)], axis=-1)
+        self.th[..., -1] = 1000 * (self.replica0 + np.arange(self.R))[:, None] + self.slot0 + np.arange(self.T)[None, :]   # tag
         self.lp = self.target(self.th)
 
     def pt_get_chains(self):
@@ -79,10 +90,28 @@ class ToyBackend(object):
     def pt_iterate(self, n, do_exchange=True):
         for _ in range(n):
             prop = self.th.copy()
-            prop[..., :-1] += 0.5 * self.rng.standard_normal(prop[..., :-1].shape)
+            for j in range(self.d - 1):
+                prop[..., j] += 0.5 * self._normal(self.it, j)
             lpn = self.target(prop)
-            acc = np.log(self.rng.uniform(size=lpn.shape)) < (lpn - self.lp) / self.temps[None, :]
+            u = par.philox_uniform_chains(self.seed, self._slots(), self.it, par.RNG_ACCEPT).reshape(self.R, self.T)
+            acc = np.log(u) < (lpn - self.lp) / self.temps[None, :]
             self.th[acc], self.lp[acc] = prop[acc], lpn[acc]
+            if do_exchange:                                   # the kernels' sweep: hot -> cold over all adjacent pairs
+                for i in range(self.T - 1, 0, -1):
+                    g = (self.replica0 + np.arange(self.R)) * self.T_global + self.slot0 + i
+                    lu = np.log(par.philox_uniform_chains(self.seed, g, self.it, par.RNG_SWAP))
+                    sw = lu < (self.lp[:, i - 1] - self.lp[:, i]) * (1.0 / self.temps[i] - 1.0 / self.temps[i - 1])
+                    self.th[sw, i], self.th[sw, i - 1] = self.th[sw, i - 1].copy(), self.th[sw, i].copy()
+                    self.lp[sw, i], self.lp[sw, i - 1] = self.lp[sw, i - 1].copy(), self.lp[sw, i].copy()
+                    self.nswap[sw, i] += 1
+            self.it += 1
+
+    def pt_sample(self, nsamples, thin=1):
+        s, l = np.empty((self.R, nsamples, self.d)), np.empty((self.R, nsamples))
+        for k in range(nsamples):
+            self.pt_iterate(thin, do_exchange=True)
+            s[:, k], l[:, k] = self.th[:, 0], self.lp[:, 0]
+        return s, l
 
 
 def _worker(rank, world, port, q):
@@ -100,17 +129,31 @@ def _worker(rank, world, port, q):
         sh = par.LadderShard(ToyBackend(d), Tg, R, adapt_iters=0, seed=99, dist=dist)
         assert sh.T_local == (3 if rank == 0 else 2) and sh.slot0 == (0 if rank == 0 else 3)
         sh.start()
+        # the same ladder in ONE process (every rank runs its own copy): the sharded ladder must walk its trajectory
+        one = ToyBackend(d)
+        one.pt_create(Tg, R, 0, seed=99, temperatures=par.ladder_temperatures(Tg))
+        one.pt_start()
         for _ in range(60):
             sh.iterate(1)
+            one.pt_iterate(1, do_exchange=True)
             th, lp = sh.b.pt_get_chains()
             assert np.allclose(lp, ToyBackend.target(th))              # swapped log-posteriors travel with theta
-            tags = torch.from_numpy(th[:, :, -1].copy())
-            allt = [torch.empty((R, 3 if r == 0 else 2), dtype=torch.float64) for r in range(world)]
-            dist.all_gather_object(obj := [None] * world, tags.numpy())
+            sl = slice(sh.slot0, sh.slot0 + sh.T_local)
+            assert np.array_equal(th, one.th[:, sl]) and np.array_equal(lp, one.lp[:, sl]), "sharded != unsharded"
+            dist.all_gather_object(obj := [None] * world, th[:, :, -1].copy())
             tagsets = np.concatenate(obj, axis=1)                      # [R][Tg]
             for r in range(R):
                 assert sorted(tagsets[r].tolist()) == [1000 * r + c for c in range(Tg)], "chain lost or duplicated"
         moved = int(np.sum(th[:, :, -1] != (1000 * np.arange(R)[:, None] + sh.slot0 + np.arange(sh.T_local)[None, :])))
+        # ---- replica sharding: independent ladders split by rank, coldest chains gathered -------------------------
+        Rt, S = 7, 11
+        gs, gl = par.sharded_pt_run(lambda: ToyBackend(d), Tg, Rt, S, burnin=20, thin=2, seed=5, dist=dist)
+        ref = ToyBackend(d)
+        ref.pt_create(Tg, Rt, 20, seed=5)
+        ref.pt_start()
+        ref.pt_iterate(20)
+        rs, rl = ref.pt_sample(S, 2)
+        assert gs.shape == (Rt, S, d) and np.array_equal(gs, rs) and np.array_equal(gl, rl), "gathered != single process"
         q.put((rank, sh.nswap_boundary, sh.nprop_boundary, moved))
     finally:
         dist.destroy_process_group()
@@ -129,4 +172,4 @@ def test_world_size_2_gloo():
     res = sorted(q.get() for _ in range(world))
     # both sides of the single boundary took the same decisions
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
-    assert res[0][1] > 0 and res[0][2] == 6 * 30      # even boundary active on even iterations only
+    assert res[0][1] > 0 and res[0][2] == 6 * 60      # the boundary pair is proposed every iteration, like every other pair

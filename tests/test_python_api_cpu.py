@@ -91,6 +91,32 @@ def test_carma_sample_dictionary(golden_dir):
     assert np.isfinite(s.DIC())
 
 
+def test_samples_from_a_carpack_ascii_file(golden_dir, tmp_path):
+    """generate_from_file (reference carma_pack.py:427-437, samplers.py:57-72): the ascii output of the C++ carpack --
+    a header line, then parameter vector + log-posterior per row -- fills the same dictionary as a trace does."""
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    fake = _FakeSampler(t, y, yerr, 5, 3, g["theta"][:16])
+    s = cp.CarmaSample(t, y, yerr, fake, q=3)
+    fname = str(tmp_path / "carpack_samples.dat")
+    lp = np.array(fake.GetLogLikes())
+    np.savetxt(fname, np.c_[g["theta"][:16], lp], header="sigma measerr_scale mu ar... ma... logpost", fmt="%.17g")
+    s2 = cp.CarmaSample.__new__(cp.CarmaSample)
+    s2.q, s2._samples = 3, {}
+    s2.generate_from_file([fname])
+    assert s2.p == 5
+    for key in ("var", "measerr_scale", "mu", "quad_coefs"):
+        np.testing.assert_array_equal(np.squeeze(s2._samples[key]), np.squeeze(s._samples[key]))
+    np.testing.assert_array_equal(s2._samples["logpost"], lp)
+    # the generic container: one parameter per file, its name on the first line
+    one = str(tmp_path / "mu.dat")
+    with open(one, "w") as f:
+        f.write("mu\n")
+        np.savetxt(f, g["theta"][:16, 2])
+    m = cp.MCMCSample(filename=one)
+    np.testing.assert_allclose(m.get_samples("mu\n"), g["theta"][:16, 2])
+
+
 def test_carma_process_moments():
     rng = np.random.RandomState(3)
     roots = cm.get_ar_roots(np.array([0.05, 0.02]), np.array([0.1]))
