@@ -261,27 +261,16 @@ def main():
         # (gfx950 FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound.)
         kernel_name = ctx.kernel_name(B)
         traffic_gbs_bytes, traffic_src, pmc_extra = None, None, None
-        import glob
-        import re
-        # newest = highest (round, version) in the path (profiles/r02/pmc_v5.json); file times mean nothing after a checkout
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")),
-                       key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.relpath(f, ROOT))], reverse=True)
-        for pmc in cands:
-            try:
-                pj = json.load(open(pmc))
-            except ValueError:
-                continue
-            disp = (pj.get("_dispatch") or {}).get("Kernel_Name", "")
-            grid = (pj.get("_dispatch") or {}).get("Grid_Size", "")
-            if kernel_name not in disp.replace(" ", "") or "FETCH_SIZE" not in pj or "WRITE_SIZE" not in pj:
-                continue
-            if str(grid) != str(((B + 3) // 4) * 256):            # same launch shape (workgroups x 256 threads)
-                continue
+        pj, pmc_path = committed_pmc(kernel_name, ((B + 3) // 4) * 256)       # same kernel, same launch shape
+        if pj is not None and "FETCH_SIZE" in pj and "WRITE_SIZE" in pj:
             traffic_gbs_bytes = (2.0 * pj["FETCH_SIZE"]["mean"] + pj["WRITE_SIZE"]["mean"]) * 1024.0
             pmc_extra = {k: pj[k]["mean"] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
                                                      "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if k in pj}
-            traffic_src = "%s (rocprofv3 --pmc of this command, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch" % os.path.relpath(pmc, ROOT)
-            break
+            traffic_src = "%s (rocprofv3 --pmc of this command, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch" % pmc_path
+        if mcmc is not None:
+            mcmc["pmc_per_iteration"] = pmc_digest(*committed_pmc("k_pt_row<%d," % p))
+        if tput is not None:
+            tput["pmc_per_launch"] = pmc_digest(*committed_pmc(tput["kernel"]))
         fp64_tflops = flops_per_eval * B / (kernel_ms * 1e-3) / 1e12
         res = {
             "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
@@ -382,6 +371,41 @@ def main():
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def committed_pmc(kernel_substr, grid=None):
+    """Counters of `kernel_substr` from the newest committed rocprofv3 PMC summary (profiles/r*/pmc_*.json, written by
+    tools/profile_round.sh + tools/summarize_prof.py from separate --pmc passes of this command) whose dispatch record
+    names that kernel (and launch grid); (None, None) when there is none -- never a stale or foreign figure."""
+    import glob
+    import re
+    # newest = highest (round, version) in the path (profiles/r03/pmc_v2.json); file times mean nothing after a checkout
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.relpath(f, ROOT))], reverse=True)
+    for pmc in cands:
+        try:
+            pj = json.load(open(pmc))
+        except ValueError:
+            continue
+        disp = pj.get("_dispatch") or {}
+        if kernel_substr.replace(" ", "") not in disp.get("Kernel_Name", "").replace(" ", ""):
+            continue
+        if grid is not None and str(disp.get("Grid_Size", "")) != str(grid):
+            continue
+        return pj, os.path.relpath(pmc, ROOT)
+    return None, None
+
+
+def pmc_digest(pj, src):
+    if pj is None:
+        return None
+    out = {k: pj[k]["mean"] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+                                      "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE") if k in pj}
+    out["per"] = pj.get("_per", "launch")
+    out["kernel"] = (pj.get("_dispatch") or {}).get("Kernel_Name", "").split("(")[0].replace("void carma::", "")
+    out["vgprs"] = (pj.get("_dispatch") or {}).get("VGPR_Count")
+    out["source"] = "%s (rocprofv3 --pmc of this command, not live; FETCH/WRITE in KiB)" % src
+    return out
 
 
 def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):

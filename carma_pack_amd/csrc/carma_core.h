@@ -172,8 +172,8 @@ CARMA_DEV void model_kappa(const GrpT& g, Model<P>& m, const Cx bm)
 // PART selects what is evaluated -- the wave pipeline splits the set-up between its two recursion waves:
 //   MODEL_ALL     everything
 //   MODEL_CONSTS  roots, b, kappa, sigma^2, s0 (what the covariance wave needs); valid = true, sing as computed
-//   MODEL_FLAGS   roots, mu, scale, the prior bounds and the repeated-root flag (what the mean wave needs); b, kappa,
-//                 sigma^2 and s0 are NOT set
+//   MODEL_FLAGS   roots, mu, scale and the prior bounds (what the mean wave needs); b, kappa, sigma^2, s0 and the
+//                 repeated-root flag are NOT set (the flag reaches the mean wave through the pipeline, carma_pipe3l.h)
 constexpr int MODEL_ALL = 0, MODEL_CONSTS = 1, MODEL_FLAGS = 2;
 template <int P, int G, int PART = MODEL_ALL, class GrpT>
 CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const Prior& pr, int ignore_prior,
@@ -229,12 +229,7 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
     m.sigsqr = theta[0] * theta[0] / var1;
     m.s0 = theta[0] * theta[0];                  // = sigma^2 Variance(1): var_0 = sigma_y^2 + yerr_0^2 (kfilter.cpp:180-182)
     } else {
-        // repeated-root flag without the products: two roots with the same bits
-        bool same = false;
-#pragma unroll
-        for (int j = 0; j < P; j++)
-            if (j != rr && m.w.re == m.wall[j].re && m.w.im == m.wall[j].im) same = true;
-        m.sing = g.sum((r < P && same) ? 1.0 : 0.0) != 0.0;
+        m.sing = false;      // the repeated-root flag is the covariance wave's (model_kappa): handed over by the pipeline
     }
     // --- prior bounds (carpack.cpp:314-374, unique_roots :709-732)
     m.valid = true;

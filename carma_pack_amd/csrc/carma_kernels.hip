@@ -143,11 +143,12 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, theta[e * d], m.scale, series[n - npad - 1].y, m.mu);
     asm volatile("" : "+v"(lpri));
     CARMA_MARK(2);
-    double ll = pipe3l_mean<P>(g, m.mu, series, n, npad, ring);
+    bool sing;
+    double ll = pipe3l_mean<P>(g, m.mu, series, n, npad, ring, &sing);
     CARMA_MARK(3);
     ll += lpri;
     const double ninf = -1.0 / 0.0;
-    if (m.sing || !m.valid) ll = ninf;
+    if (sing || !m.valid) ll = ninf;
     if (live && g.lane() == 0) out[e] = ll;
     CARMA_MARK(4);
     CARMA_MARK_DUMP("mean", 0);

@@ -75,7 +75,7 @@ struct Pipe3LGeom {
     static constexpr int LINK_OFF = 3 * C * SLOT;               // double2 {k~_r, var}[2][C][SLOT]
     static constexpr int CONST_OFF = LINK_OFF + 2 * C * SLOT;   // double2 {h_r, c_r}[SLOT]
     static constexpr int CONST2_OFF = CONST_OFF + SLOT;         // double2 {g_r h_r, c_r / g_r}[SLOT]: (h~, c~) at a re-base datum
-    static constexpr int FLAG_OFF = CONST2_OFF + SLOT;          // u64[3] (+ pad): re-base data of a chunk, bit 16 row + slot
+    static constexpr int FLAG_OFF = CONST2_OFF + SLOT;          // u64[3]: re-base data of a chunk, bit 16 row + slot; u64[3]: rows with a repeated AR root
     static constexpr int TAIL_OFF = FLAG_OFF + 2;               // double[2][C]: yerr^2 (wave A) and y (wave B) of the last, partial chunk
     static constexpr int ENTRIES = TAIL_OFF + C;
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(Cx);   // 41.8 KiB
@@ -292,6 +292,12 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     const bool act = (lane & 15) < P;
     const double h_row = act ? rc.h_own : 0.0, c_row = act ? rc.c_own : 0.0;     // idle lanes carry exact zeros
     reinterpret_cast<double2*>(ring + Geo::CONST_OFF)[Geo::entry(lane)] = make_double2(h_row, c_row);
+    {
+        // ONE definition of "repeated AR root" for the whole launch shape: this wave's (alpha'(omega_r) == 0, model_kappa --
+        // the test of the other kernels), handed to the mean wave, which forms the result, through the spare flag word
+        const unsigned long long sing_rows = __ballot(m.sing);
+        if (lane == 0) reinterpret_cast<unsigned long long*>(ring + Geo::FLAG_OFF)[3] = sing_rows;
+    }
     __syncthreads();                                          // the producers finish chunk 0 with these constants
     const double one = 1.0;
     double S[P];
@@ -406,7 +412,7 @@ __device__ __forceinline__ double pipe3l_pad_correction(int npad, double sigma_y
 // part of the set-up (model_from_theta<MODEL_FLAGS>).
 template <int P>
 __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const double4* __restrict__ series, int n,
-                                              int npad, const Cx* __restrict__ ring)
+                                              int npad, const Cx* __restrict__ ring, bool* sing)
 {
     const double* __restrict__ y_arr = reinterpret_cast<const double*>(series + (n - npad + P3L_PAD_RECORDS)) +
                                        (n - npad + P3L_PAD_RECORDS);                                              // y[]
@@ -452,6 +458,7 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
     __syncthreads();                                          // (h_r, c_r) published
     __syncthreads();                                          // barrier 0
     h_own = reinterpret_cast<const double2*>(ring + Geo::CONST2_OFF)[Geo::entry(lane)].x;    // g_r h_r: h~ at a re-base datum
+    *sing = ((flag_b[3] >> (16 * (lane >> 4))) & 1ull) != 0ull;     // the covariance wave's repeated-root flag of this row
     for (int c = 0; c < nc; c++) {
         __syncthreads();                                      // barrier c + 1: wave A has finished chunk c
         // y_j: two wide scalar loads, requested first (as yerr_j^2 in the covariance wave)

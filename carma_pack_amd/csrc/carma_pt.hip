@@ -345,9 +345,10 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 // before the recursion: off the critical path
                 double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], m.scale, series[L.n - 1].y, m.mu);
                 asm volatile("" : "+v"(lpri));
-                double ll = pipe3l_mean<P>(g, m.mu, series, L.n + npad, npad, ring);
+                bool sing;
+                double ll = pipe3l_mean<P>(g, m.mu, series, L.n + npad, npad, ring, &sing);
                 ll += lpri;
-                if (m.sing || !m.valid) ll = -1.0 / 0.0;
+                if (sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;
             }
             __syncthreads();                               // log-densities visible to the chain wave

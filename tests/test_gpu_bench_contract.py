@@ -63,7 +63,12 @@ def test_two_ranks_sharing_the_gpu():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["finite_in_last_batch"] == 1024
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 2 * 1024) < 1e-6 * 2048          # whole-job aggregate
     ld = j["ladder_sharded"]                                                 # one ladder of 8 temperatures, 4 per rank
-    assert ld["temperatures_per_rank"] == 4 and ld["scaling"] == "strong" and 0.0 < ld["boundary_swap_rate_rank0"] < 1.0
+    assert ld["temperatures_per_rank"] == 4 and ld["scaling"] == "strong", ld
+    rates = ld["boundary_swaps_by_rank"]
+    assert len(rates) == 2 and rates[0]["proposed"] == rates[1]["proposed"] == 128 * 16 and rates[0]["accepted"] == rates[1]["accepted"]
+    assert 0.0 < rates[0]["rate"] < 1.0
+    # first contact: the two blocks' chains after ten iterations ARE the one-GPU ladder's
+    assert ld["first_contact_check"]["equals_one_gpu_run"] is True, ld["first_contact_check"]
 
 
 def test_ladder_leg_cannot_hold_the_line_back():
@@ -77,4 +82,4 @@ def test_ladder_leg_cannot_hold_the_line_back():
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
-    assert j["n_gpus"] == 2 and j["value"] > 1e6 and "no result after" in j["ladder_sharded"]["error"]
+    assert j["n_gpus"] == 2 and j["value"] > 1e6 and "no result after" in j["ladder_sharded"]["error"] and j["ladder_leg_hung"] is True

@@ -107,8 +107,13 @@ def test_config3_long_series_ladder(cpa):
     th, lp = ctx.pt_get_chains()
     flat = th.reshape(-1, 16)
     from helpers import loglik_truth
+    # The chains are a few hundred iterations away from prior-like CARMA(7,6) starts: roots spread over five decades of
+    # frequency, cond(EigenMat) 1e7 ... 1e12 for a good part of them -- where the ORACLE's LU and sums are 1e-10 ... 1e-4
+    # off the exact value of the reference's formulas (tests/test_oracle_golden.py prints such a table).  Measured: 37-44 of
+    # the 1024 chain states differ from the oracle by more than 1e-10 (worst 1e-3), every one of them with the GPU the
+    # closer of the two to the quad-precision value; 8 % may go to the arbiter here (1 % is the default).
     assert_parity(lp.reshape(-1), m.logdensity_batch(flat, nthreads=os.cpu_count() or 8), 1e-10, "config 3 chain states",
-                  arbiter=lambda i: loglik_truth(t, y, e, flat[i], 7, 6)[0])
+                  arbiter=lambda i: loglik_truth(t, y, e, flat[i], 7, 6)[0], max_arb_frac=0.08)
     acc, swp = ctx.pt_stats()
     assert acc.mean() > 0.02 and swp[:, 1:].mean() > 0.01
     assert np.median(lp[:, 0]) > np.median(lp0[:, 0])                   # the cold chains climbed
@@ -160,7 +165,7 @@ def test_config3_ladder_sharded_over_rccl():
         th = np.concatenate([o[0][0] for o in out], axis=1).reshape(-1, 16)
         lp = np.concatenate([o[0][1] for o in out], axis=1).reshape(-1)
         assert_parity(lp, m.logdensity_batch(th, nthreads=os.cpu_count() or 8), 1e-10, "sharded %s" % blocks,
-                      arbiter=lambda i: loglik_truth(t, y, e, th[i], 7, 6)[0])
+                      arbiter=lambda i: loglik_truth(t, y, e, th[i], 7, 6)[0], max_arb_frac=0.08)   # (see test_config3_long_series_ladder)
         prop = [o[1][0] for o in out]
         acc = [o[1][1] for o in out]
         assert all(p_ > 0 for p_ in prop) and all(a > 0 for a in acc), (prop, acc)

@@ -208,6 +208,63 @@ def test_gpu_sampler_matches_literal_cpu_sampler(cpa):
     assert 0.15 < acc[:, 0].mean() < 0.40
 
 
+def test_headline_order_sampler_matches_literal_cpu_sampler(cpa, golden_dir):
+    """The same distributional comparison at the HEADLINE order: README CARMA(5,3), n = 270, a ladder of 10 temperatures
+    (the reference's default max(10, p+q), carma_pack.py:67) -- the GPU's 64 replicas against the oracle's literal
+    restatement of RunCarmaSampler (serial hot -> cold sweep RAM(i), swap(i, i-1), RAM(i-1) ..., src/carmcmc.cpp:147-157;
+    its own RNG) run from 8 seeds in parallel on the host.  Posterior means of theta_0 ... theta_7 (sigma_y, error scale,
+    mu, the five AR parameters) within Monte-Carlo error (z from the replica-to-replica and seed-to-seed scatter),
+    posterior standard deviations within 15 %.  (The three MA parameters are unidentified on this series -- flat over tens
+    of e-folds, test_config2_full_pt_mcmc -- and a mean / sd criterion says nothing about them.  A ladder sharded through
+    carma_pt_iterate_sharded needs no statistical test any more: it reproduces the unsharded chains bit for bit,
+    test_gpu_ladder_shard.py.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from helpers import prior_like_theta
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, yerr = g["t"], g["y"], g["yerr"]
+    p, q, T, nseeds = 5, 3, 10, 8
+    ms = _pop_stdev(y)
+    nb, ns = 15000, 30000
+    rng = np.random.default_rng(81)
+    m0 = orc.OracleModel(t, y, yerr, p, q, max_stdev=ms)
+    starts = []
+    for _ in range(nseeds):
+        st = []
+        while len(st) < T:
+            x = prior_like_theta(rng, p, q, t, y)
+            if np.isfinite(m0.logdensity(x)):
+                st.append(x)
+        starts.append(np.array(st))
+
+    def cpu_run(k):                                       # (the C call releases the interpreter lock: threads run in parallel)
+        m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ms)
+        return m.sampler_run(T, ns, nb, 1, 500 + k, starts[k])
+
+    with ThreadPoolExecutor(max_workers=nseeds) as pool:
+        fut = [pool.submit(cpu_run, k) for k in range(nseeds)]
+        ctx = cpa.Context(t, y, yerr, p, q, max_stdev=ms)          # the GPU runs meanwhile
+        samples, lp = ctx.pt_run(T, 64, ns, nb, 1, seed=4321)
+        outs = [f.result() for f in fut]
+    sel = list(range(8))
+    # a chain that has not found the mode by the end of the burn-in would only add scatter: both sides must have
+    best = m0.logdensity(g["theta"][0])
+    assert min(o["logpost"][-2000:].max() for o in outs) > best - 15.0 and lp[:, -2000:].max(axis=1).min() > best - 15.0
+    cpu_means = np.array([o["samples"][:, sel].mean(0) for o in outs])
+    cpu_sd = np.array([o["samples"][:, sel].std(0) for o in outs])
+    gpu_means, gpu_sd = samples[:, :, sel].mean(1), samples[:, :, sel].std(1)
+    mg, mc = gpu_means.mean(0), cpu_means.mean(0)
+    se = np.sqrt(gpu_means.var(0, ddof=1) / 64 + cpu_means.var(0, ddof=1) / nseeds)
+    zscore = np.abs(mg - mc) / se
+    ratio = gpu_sd.mean(0) / cpu_sd.mean(0)
+    print("headline-order sampler parity: z", np.round(zscore, 2), " sd ratio", np.round(ratio, 3))
+    assert np.all(zscore < 5.0), (mg, mc, zscore)
+    assert np.all(np.abs(ratio - 1.0) < 0.15), ratio
+    for o in outs:
+        assert 0.12 < o["accept_rate"][0] < 0.45
+    acc, swp = ctx.pt_stats()
+    assert 0.12 < acc[:, 0].mean() < 0.45
+
+
 @pytest.mark.parametrize("p,q", [(5, 3), (4, 0), (1, 0)])
 def test_starting_values_follow_the_reference_distribution(cpa, golden_dir, p, q):
     """A12: 10^4 starting values through carma_pt_start (CARMA::StartingValue / CARp::StartingAR / StartingMA /

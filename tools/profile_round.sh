@@ -1,9 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel stats + PMC passes of the bench command.
-#   tools/profile_round.sh <tag>        -> gpurun_out/prof_<tag>/...; summaries via tools/summarize_prof.py
+#   tools/profile_round.sh <tag>        -> gpurun_out/prof_<tag>/...; summaries via tools/summarize_prof.py <tag> <outdir>
 # Counters are collected in their own runs (only --kernel-trace next to --pmc), the program itself
 # follows "--" (no env/bash -c hop: the profiler's preloaded library has already initialised the GPU).
-TAG=${1:-r02}
+# The PMC passes keep the sampler leg (300 iterations of k_pt_row in two dispatches) and the throughput leg
+# (k_logdens_carma<5,8,4>, 65 536 evaluations per launch) next to the headline kernel: one summary per kernel.
+TAG=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 REPO=$PWD
 export TMPDIR=/tmp
@@ -12,10 +14,11 @@ mkdir -p $OUT
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --no-cpu --no-pipelined > $OUT/stats.log 2>&1
 echo "stats rc=$?"
+PMC_ARGS="--steps 50 --warmup 5 --no-cpu --no-pipelined --no-ladder --mcmc-iters 200"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o $TAG -- python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu --no-mcmc --no-pipelined --no-throughput --no-ladder > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o $TAG -- python3 $REPO/bench.py $PMC_ARGS > $OUT/pmc_$c.log 2>&1
   echo "pmc $c rc=$?"
 done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -o $TAG -- python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu --no-mcmc --no-pipelined --no-throughput --no-ladder > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -o $TAG -- python3 $REPO/bench.py $PMC_ARGS > $OUT/pmc_SQ.log 2>&1
 echo "pmc SQ rc=$?"
 find $OUT -name "*.csv" | head -20
