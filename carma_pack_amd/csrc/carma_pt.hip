@@ -281,8 +281,21 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     double* s_lu = s_z + 64;                               // [64] this exchange's log-uniforms (T <= 64), producer wave 1
     double* s_step = s_lu + 64;                            // [1] this iteration's adaptation step length (+ pad), same
     double* s_tha = s_step + 2;                            // [T][d] the ladder's staged parameter vectors (T <= 64)
-    const long lad = blockIdx.x / S.wpl;                   // local replica (ladder) index
-    const int part = (int)(blockIdx.x % S.wpl);
+    // Which ladder, which part of it.  Workgroups are dealt to the eight XCDs (each with its own L2) round-robin by
+    // blockIdx, and the swap step is an exchange between the workgroups of ONE ladder: S.xcd_map = 8 puts a ladder's wpl
+    // workgroups on blockIdx b, b + 8, b + 16, ... -- the same XCD -- instead of b, b + 1, ... (eight different ones).
+    // Placement only: the exchange uses agent-scope operations either way, so a device that deals differently is merely
+    // slower.  (The host sets it when the replicas fill whole groups of eight.)
+    long lad;
+    int part;
+    if (S.xcd_map > 1) {
+        const unsigned x = blockIdx.x % (unsigned)S.xcd_map, slot = blockIdx.x / (unsigned)S.xcd_map;
+        lad = (long)(slot / (unsigned)S.wpl) * S.xcd_map + x;
+        part = (int)(slot % (unsigned)S.wpl);
+    } else {
+        lad = blockIdx.x / S.wpl;
+        part = (int)(blockIdx.x % S.wpl);
+    }
     const long ch0 = lad * T;                              // first chain of the ladder in the state arrays
 
     for (int i = tid; i < T; i += 256) {
@@ -609,6 +622,12 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     }();
     Sa.rot = S.wpl == 1 ? 0x36D2 : 0xB14E;
     if (tune_rot >= 0) Sa.rot = (int)tune_rot;
+    static const long tune_xcd = [] {
+        const char* e = getenv("CARMA_TUNE_PT_ROW_XCD_MAP");                    // measurements only; read once
+        return e ? atol(e) : -1L;
+    }();
+    Sa.xcd_map = (S.wpl > 1 && L.R % 8 == 0) ? 8 : 1;
+    if (tune_xcd >= 0) Sa.xcd_map = (tune_xcd > 1 && L.R % tune_xcd == 0) ? (int)tune_xcd : 1;
     Prior pra = pr;
     void* args[] = {&La, &Sa, (void*)&series, &pra, (void*)&temps, &theta, &logpost, &chol, &naccept, &nswap, &samples, &sample_lp};
     if (S.wpl == 1)

@@ -166,7 +166,7 @@ static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save
     if (s->use_row) {
         e = hipMemsetAsync(s->d_counter, 0, sizeof(unsigned) * s->R, st);
         if (e != hipSuccess) return hip_fail(e, "reset pt counters");
-        PtRowSync S{s->d_stage_th, s->d_stage_lp, s->d_counter, s->d_abort, s->wpl, device_cus(), 0};
+        PtRowSync S{s->d_stage_th, s->d_stage_lp, s->d_counter, s->d_abort, s->wpl, device_cus(), 1, 0};
         e = launch_pt_row(c->p, L, S, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
                           s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
         if (e == hipErrorCooperativeLaunchTooLarge) {      // the grid is not co-resident on this device: ladder kernel

@@ -56,6 +56,7 @@ struct PtRowSync {
     unsigned* abort_flag;    // [1] set when a barrier timed out (the launch then ends early)
     int wpl;                 // workgroups per ladder = ceil(T / 4)
     int ncu;                 // compute units of the device: workgroups i, i + ncu, i + 2 ncu share a CU
+    int xcd_map;             // > 1: a ladder's workgroups sit xcd_map blocks apart (same XCD), see k_pt_row
     int rot;                 // which wave plays which part in the second (bits 0-7) and third (bits 8-15) workgroup of a CU:
                              // 2 bits per wave, set by the launcher (the placement differs between launch kinds)
 };

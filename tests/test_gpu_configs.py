@@ -234,11 +234,13 @@ def test_config4_choose_order_vs_scipy(cpa, golden_dir):
         # low orders: at least as good as scipy's best.  (Not "equal": CARMA(2,1) on this series has a second mode, error
         # scale at its lower bound and two real roots, 2.4 units of -log L BELOW the one every scipy start ends in; the
         # lock-step optimiser reaches it from one of the 24 starts.  The value there is exact: quad-precision arbiter.)
-        assert fb[ok].min() <= fs[ok].min() + (0.05 if p <= 3 else 6.0), (p, q)
+        # (p > 3: the surface is rugged and 24 starts are few; measured gaps between the two optimisers' best of 24: +0.08,
+        # -0.04, +0.03, +0.26 units of -log L for (4,2), (5,3), (6,1), (7,6) -- 1.0 is the allowance, round 2 had 6.0)
+        assert fb[ok].min() <= fs[ok].min() + (0.05 if p <= 3 else 1.0), (p, q)
         # (the 100 starts of choose_order are drawn independently of these 24, so on a rugged surface either set can hold
         # the lucky start: bounded here, counted below)
-        assert fun_100 <= fs[ok].min() + (0.05 if p <= 3 else 6.0), (p, q, fun_100, fb[ok].min(), fs[ok].min())
-        assert fun_100 <= min(fb[ok].min(), fs[ok].min()) + 6.0, (p, q, fun_100, fb[ok].min(), fs[ok].min())
+        assert fun_100 <= fs[ok].min() + (0.05 if p <= 3 else 1.0), (p, q, fun_100, fb[ok].min(), fs[ok].min())
+        assert fun_100 <= min(fb[ok].min(), fs[ok].min()) + 1.0, (p, q, fun_100, fb[ok].min(), fs[ok].min())
         unlucky += fun_100 > min(fb[ok].min(), fs[ok].min()) + 0.5
         # the objective is the oracle's: -LogDensity(x) with the bounds ignored (SetMLE(true), carma_pack.py:242)
         best = mle[int(np.argmin(np.where(ok, fb, np.inf)))]
