@@ -388,7 +388,8 @@ def committed_pmc(kernel_substr, grid=None):
         except ValueError:
             continue
         disp = pj.get("_dispatch") or {}
-        if kernel_substr.replace(" ", "") not in disp.get("Kernel_Name", "").replace(" ", ""):
+        # (rocprofv3 prints defaulted template arguments too: "k_logdens_carma<5, 8, 4, false>" for "k_logdens_carma<5,8,4>")
+        if kernel_substr.replace(" ", "").rstrip(">") not in disp.get("Kernel_Name", "").replace(" ", ""):
             continue
         if grid is not None and str(disp.get("Grid_Size", "")) != str(grid):
             continue
