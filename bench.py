@@ -246,7 +246,9 @@ def main():
             "kernel_avg_us": k_us,
             "fp64_valu": {"achieved_tflops": flops_per_eval_ * BT / (k_us * 1e-6) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "frac": flops_per_eval_ * BT / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          "note": "algorithmic flop count of the reference's complex recursion (SURVEY.md 8d)"},
+                          "note": "algorithmic flop count of the reference's COMPLEX recursion (SURVEY.md 8d): the kernels work in real "
+                                  "modal coordinates on the symmetric half of the matrix, about a third of those flops -- a fraction "
+                                  "above 1 is this count's artefact, not a measurement error"},
         }
 
     res = None

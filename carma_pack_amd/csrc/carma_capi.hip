@@ -483,7 +483,12 @@ static int kf_filter(Kf* k, double* mean, double* var)
     if (e == hipSuccess) e = hipMemcpyAsync(var, k->d_io + m, sizeof(double) * m, hipMemcpyDeviceToHost, k->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&sing, k->d_sing, sizeof(int), hipMemcpyDeviceToHost, k->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
-    if (e != hipSuccess) return hip_fail(e, "carma_kfilter");
+    if (e != hipSuccess) {
+        // copies enqueued before the failure may still be writing into the caller's buffers (and into `sing` on this
+        // stack frame): drain the stream before anybody frees or leaves them
+        (void)hipStreamSynchronize(k->stream);
+        return hip_fail(e, "carma_kfilter");
+    }
     return sing ? 1 : CARMA_OK;
 }
 
@@ -516,7 +521,10 @@ static int kf_predict(Kf* k, const double* tpred, int M, double* pmean, double* 
     if (e == hipSuccess) e = hipMemcpyAsync(pvar, d_io + 2 * (size_t)M, sizeof(double) * M, hipMemcpyDeviceToHost, k->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&sing, k->d_sing, sizeof(int), hipMemcpyDeviceToHost, k->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
-    if (e != hipSuccess) return hip_fail(e, "carma_predict");
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(k->stream);               // see kf_filter
+        return hip_fail(e, "carma_predict");
+    }
     return sing ? 1 : CARMA_OK;
 }
 

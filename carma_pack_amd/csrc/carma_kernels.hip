@@ -24,6 +24,7 @@
 #include "carma_predict.h"
 #include "carma_simulate.h"
 #include "carma_pipe3l.h"
+#include "carma_lane.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -154,6 +155,20 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     CARMA_MARK_DUMP("mean", 0);
 }
 
+// Throughput regime proper (tens of thousands of evaluations): ONE EVALUATION PER LANE (carma_lane.h) -- nothing crosses
+// lanes, all 64 lanes work; a wave per 64 evaluations.
+template <int P>
+__global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restrict__ theta, int B, int d, int q,
+                                                          const double4* __restrict__ series, int n, Prior pr,
+                                                          int ignore_prior, double* __restrict__ out)
+{
+    long e = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    const double ll = logdensity_lane<P>(theta + e * d, q, series, n, pr, ignore_prior);
+    if (live) out[e] = ll;
+}
+
 __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ theta, int B,
                                                      const double4* __restrict__ series, int n, Prior pr,
                                                      double* __restrict__ out)
@@ -278,7 +293,16 @@ static long p3l_max_rows()
 }
 
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
-enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4 };
+enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE };
+// smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
+static long lane_min_evals()
+{
+    static const long tune = [] {
+        const char* e = getenv("CARMA_TUNE_LANE_MIN");
+        return e ? atol(e) : -1L;
+    }();
+    return tune >= 0 ? tune : 64L * 4 * device_cus() / 2;      // half a wave per SIMD
+}
 template <int P>
 static LdShape logdens_shape(long B, int n)
 {
@@ -286,6 +310,7 @@ static LdShape logdens_shape(long B, int n)
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
+    if (B >= lane_min_evals()) return LdShape::LANE;
     // few evaluations in flight: one wave's instruction stream is the run time, so split it (consumer + rho producer,
     // carma_ring.h).  Beyond 512 waves (two rounds of workgroups) the plain kernel with pair-shared exp/sincos is
     // ahead: 104 vs 111 us at 6144 evaluations (tools/midrange_probe.py)
@@ -329,6 +354,10 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
                 hipLaunchKernelGGL((k_logdens_carma<P, G, 1>), dim3((unsigned)waves), dim3(64), 0, st, theta, B, d, q, series, n,
                                    pr, ignore_prior, out);
             return hipGetLastError();
+        case LdShape::LANE:
+            hipLaunchKernelGGL((k_logdens_carma_lane<P>), dim3((unsigned)(((long)B + 63) / 64)), dim3(64), 0, st, theta, B, d, q, series,
+                               n, pr, ignore_prior, out);
+            return hipGetLastError();
         case LdShape::PLAIN4:
             if (repeated_dt)
                 hipLaunchKernelGGL((k_logdens_carma<P, G, 4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, theta, B,
@@ -352,6 +381,7 @@ static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
         case LdShape::PC2: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,2>", P, G);
         case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1%s>", P, G, dtc);
         case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4%s>", P, G, dtc);
+        case LdShape::LANE: return snprintf(buf, len, "k_logdens_carma_lane<%d>", P);
     }
     return -1;
 }

@@ -1,0 +1,297 @@
+// carma_lane.h -- the CARMA(p,q) Kalman log-density with ONE EVALUATION PER LANE (round 3): the throughput regime.
+//
+// The lane-group kernels of carma_core.h give an evaluation G = 8 lanes (p = 5..7) of which p work, and every step pays
+// for talking between them: two 3-stage DPP butterflies (var, mean), an LDS all-gather of the gain, DPP moves of the
+// pair partner's row in the rotation -- 127.6 VALU instructions per wave-step for EIGHT evaluations (16 per
+// evaluation-step, profiles/r03/pmc_v1_tput.json).  With tens of thousands of evaluations in flight none of that is
+// needed: here a lane holds the whole p x p matrix D of its evaluation (symmetric: p (p + 1) / 2 registers), nothing
+// crosses lanes, all 64 lanes work, and a wave-step of ~330 instructions serves SIXTY-FOUR evaluations (~5 per
+// evaluation-step).  The series record of a step is still wave-uniform (scalar loads), and so is the time step: a step
+// that repeats its predecessor's dt re-uses the transition factors (the regular-cadence variant of the other kernels
+// is a wave-uniform branch here, always on).
+//
+// Same model, same recursion as filter_loop_real (REAL modal coordinates; reference: KalmanFilterp::Reset / Update,
+// src/kfilter.cpp:138-215; CARMA_Base::LogDensity, src/include/carpack.hpp:131-176; set-up closed forms: struct Model
+// in carma_core.h) -- only the distribution of the work over lanes differs:
+//     coordinates     z_{2k} = Re x_{2k}, z_{2k+1} = Im x_{2k} for a complex pair, z_r = x_r for a real root
+//     h_{2k} = 2 Re b_{2k}, h_{2k+1} = -2 Im b_{2k} (real root: b_r);   c_{2k} = Re (V b^H)_{2k}, c_{2k+1} = Im (V b^H)_{2k}
+//     var  = s0 + h.w + e,  mean = h.z,  k = w + c,  w = D h
+//     z   <- Phi (z + k innov / var),   D <- Phi (D - k k^T / var) Phi^T
+//     Phi : rotation-scaling [[c,-s],[s,c]] per complex pair (c + i s = exp(omega_{2k} dt)), a scalar per real root;
+//           stored per coordinate as (c_r, s_r) with s_{2k+1} = -s_{2k}, so that
+//           (d Phi^T)_{ij} = d_ij c_j - d_{i,j^1} s_j   and   (Phi m)_{ij} = c_i m_ij - s_i m_{i^1,j}
+//           hold for every coordinate (s = 0 for a real root, whose partner index is never dereferenced).
+// Plain C++ over doubles: compiled for the host by the test harness as well (tests/emu).
+#pragma once
+#include "carma_core.h"
+
+namespace carma {
+
+template <int P>
+struct LaneModel {
+    double h[P], c[P];         // observation row and gain offset in real coordinates
+    double wre[P], wim[P];     // AR roots
+    double s0, scale, mu;
+    bool valid, sing;
+    bool realpair[(P + 1) / 2];   // quadratic factor i has two REAL roots (its members then rotate separately)
+};
+
+// theta -> everything the recursion needs (ARRoots, ExtractMA, ExtractSigsqr, CheckPriorBounds; closed forms of struct Model)
+template <int P>
+CARMA_DEV void lane_model_from_theta(const double* theta, int q, const Prior& pr, int ignore_prior, LaneModel<P>& m)
+{
+    constexpr int NMA = P > 1 ? P - 1 : 1;
+    Cx w[P], mu[NMA];
+#pragma unroll
+    for (int j = 0; j < P; j++) w[j] = poly_root(theta + 3, P, j);
+#pragma unroll
+    for (int k = 0; k < NMA; k++) mu[k] = k < q ? poly_root(theta + 3 + P, q, k) : Cx{-1.0, 0.0};
+    // prod_k mu_k is real (conjugate pairs and real roots)
+    Cx pmu = {1.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NMA; k++)
+        if (k < q) pmu = cmul(pmu, mu[k]);
+    const double rmu = 1.0 / pmu.re;
+    Cx b[P], kap[P];
+    bool sing = false;
+    double var1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        // b_r = beta(omega_r) = prod_k (mu_k - omega_r) / mu_k,  beta(-omega_r) = prod_k (mu_k + omega_r) / mu_k
+        Cx pb = {1.0, 0.0}, pm = {1.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NMA; k++) {
+            if (k < q) {
+                pb = cmul(pb, csub(mu[k], w[r]));
+                pm = cmul(pm, cadd(mu[k], w[r]));
+            }
+        }
+        b[r] = cscale(pb, rmu);
+        // kappa_r = beta(-omega_r) / (alpha'(omega_r) alpha(-omega_r))
+        Cx ap = {1.0, 0.0}, am = {1.0, 0.0};
+#pragma unroll
+        for (int l = 0; l < P; l++) {
+            const Cx dl = csub(w[r], w[l]);
+            const Cx sl = {-(w[r].re + w[l].re), -(w[r].im + w[l].im)};
+            if (l != r) ap = cmul(ap, dl);
+            am = cmul(am, sl);
+        }
+        if (ap.re == 0.0 && ap.im == 0.0) sing = true;      // repeated AR root (arma::solve throws, carpack.hpp:154-164)
+        kap[r] = cdiv(cscale(pm, rmu), cmul(ap, am));
+        var1 += b[r].re * kap[r].re - b[r].im * kap[r].im;
+    }
+    // sigma^2 = theta0^2 / Variance(omega, beta, 1)   (carpack.cpp:377-409, carpack.hpp:316-319, 391-395)
+    const double sigsqr = theta[0] * theta[0] / var1;
+    m.s0 = theta[0] * theta[0];
+    m.scale = theta[1];
+    m.mu = theta[2];
+    m.sing = sing;
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        m.wre[r] = w[r].re;
+        m.wim[r] = w[r].im;
+        const bool cpx = (w[r].im != 0.0) && (r < (P & ~1));
+        const int ev = r & ~1;                               // the even member of r's pair
+        if (cpx) {
+            // (the odd member is the conjugate of the even one: h = 2 Im b_odd = -2 Im b_even, c = Im (V b^H)_even)
+            m.h[r] = (r & 1) ? 2.0 * b[r].im : 2.0 * b[r].re;
+            m.c[r] = sigsqr * ((r & 1) ? kap[ev].im : kap[r].re);
+        } else {
+            m.h[r] = b[r].re;
+            m.c[r] = sigsqr * kap[r].re;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (P + 1) / 2; i++) m.realpair[i] = (2 * i + 1 < P) && (w[2 * i].im == 0.0);
+    // --- prior bounds (carpack.cpp:314-374, unique_roots :709-732)
+    m.valid = true;
+    if (!ignore_prior) {
+        bool viol = false;
+        double cent_prev = 0.0;
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            const double cent = fabs(w[r].im) / 2.0 / (TWO_PI / 2.0);
+            const double width = -w[r].re / 2.0 / (TWO_PI / 2.0);
+            if (!(cent < pr.max_freq) || !(width < pr.max_freq) || !(width > pr.min_freq)) viol = true;
+            if (r >= 1 && (cent - cent_prev) > 1e-8) viol = true;
+            cent_prev = cent;
+#pragma unroll
+            for (int j = r + 1; j < P; j++) {
+                // |(w - w_j) / (w + w_j)| <= 1e-4 (carpack.cpp:709-732), compared as squared moduli
+                const Cx dn = csub(w[r], w[j]), sm = cadd(w[r], w[j]);
+                const double n2 = dn.re * dn.re + dn.im * dn.im, d2 = sm.re * sm.re + sm.im * sm.im;
+                if (n2 <= 1e-8 * d2) viol = true;
+            }
+        }
+        const double ysigma = theta[0], ms = theta[1];
+        if (viol || (ysigma > pr.max_stdev) || (ysigma < 0) || (ms < 0.5) || (ms > 2.0)) m.valid = false;
+    }
+}
+
+// index of (i, j), i <= j, in the packed upper triangle
+template <int P>
+CARMA_DEV constexpr int tri(int i, int j)
+{
+    return i <= j ? i * P - i * (i - 1) / 2 + (j - i) : j * P - j * (j - 1) / 2 + (i - j);
+}
+
+// wave-uniform "does any lane need it" (the host build runs one evaluation at a time)
+CARMA_DEV bool lane_any(bool b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(b) != 0;
+#else
+    return b;
+#endif
+}
+
+// Reset + n - 1 Updates -> log-likelihood sum (no prior)
+template <int P>
+CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ series, int n)
+{
+    constexpr int NT = P * (P + 1) / 2;
+    constexpr int PE = P & ~1;                               // coordinates that belong to pairs
+    double D[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) D[i] = 0.0;
+    double z[P], k[P], w[P];
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        z[r] = 0.0;
+        w[r] = 0.0;
+        k[r] = m.c[r];
+    }
+    double cr[P], sr[P];                                     // transition factors per coordinate
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        cr[r] = 1.0;
+        sr[r] = 0.0;
+    }
+    bool anyreal = false;
+#pragma unroll
+    for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
+    anyreal = lane_any(anyreal);
+    LogLikAcc acc;
+    acc.init();
+    double4 rprev = series[0];
+    double dt_prev = -1.0;                                   // (a time step is never negative)
+    for (int kk = 1; kk < n; kk++) {
+        const double4 rec = series[kk];
+        // --- transition factors of this step: one exp/sincos per PAIR (the members are conjugates), one exp per real
+        // root; a repeated time step (wave-uniform: the series is shared) re-uses them
+        if (rec.x != dt_prev) {
+            dt_prev = rec.x;
+#pragma unroll
+            for (int i = 0; i < P / 2; i++) {
+                double c, s;
+                cexp_step(m.wre[2 * i], m.wim[2 * i], rec.x, &c, &s);
+                cr[2 * i] = c;
+                sr[2 * i] = s;
+                cr[2 * i + 1] = c;
+                sr[2 * i + 1] = -s;
+            }
+            if (anyreal) {
+                // a quadratic factor with two real roots: the second member has its own modulus (and no phase: s = 0)
+#pragma unroll
+                for (int i = 0; i < P / 2; i++) {
+                    const double e1 = exp_neg(m.wre[2 * i + 1] * rec.x);
+                    if (m.realpair[i]) cr[2 * i + 1] = e1;
+                }
+            }
+            if (P & 1) cr[P - 1] = exp_neg(m.wre[P - 1] * rec.x);
+        }
+        // --- var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z   (kfilter.cpp:180-184, 207-213)
+        double pv = 0.0, pm = 0.0;
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            pv = fma(m.h[r], w[r], pv);
+            pm = fma(m.h[r], z[r], pm);
+        }
+        const double var = m.s0 + pv + rprev.z * m.scale;
+        const double innov = (rprev.y - m.mu) - pm;
+        acc.add_var(var);
+        const double s = recip(var);
+        const double si = s * innov;
+        acc.chi2 += innov * si;
+        // --- state (kfilter.cpp:191-194, 200-201)
+        double zu[P];
+#pragma unroll
+        for (int r = 0; r < P; r++) zu[r] = fma(k[r], si, z[r]);
+#pragma unroll
+        for (int r = 0; r < P; r++) z[r] = (r < PE) ? cr[r] * zu[r] - sr[r] * zu[r ^ 1] : cr[r] * zu[r];
+        // --- covariance (kfilter.cpp:197, 204): d = D - k k^T / var (upper triangle), mm = d Phi^T, D = Phi mm
+        double d[NT];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const double t = k[i] * s;
+#pragma unroll
+            for (int j = i; j < P; j++) d[tri<P>(i, j)] = fma(-t, k[j], D[tri<P>(i, j)]);
+        }
+        // mm_ij for j >= i, and below the diagonal the one entry a pair's even row needs from its partner: (i + 1, i)
+        double mm[P][P];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                const bool need = (j >= i) || (j == i - 1 && (i & 1) && i < PE);
+                if (need) {
+                    if (j < PE)
+                        mm[i][j] = d[tri<P>(i, j)] * cr[j] - d[tri<P>(i, j ^ 1)] * sr[j];
+                    else
+                        mm[i][j] = d[tri<P>(i, j)] * cr[j];
+                } else {
+                    mm[i][j] = 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+#pragma unroll
+            for (int j = i; j < P; j++) {
+                if (i < PE)
+                    D[tri<P>(i, j)] = cr[i] * mm[i][j] - sr[i] * mm[i ^ 1][j];
+                else
+                    D[tri<P>(i, j)] = cr[i] * mm[i][j];
+            }
+        }
+        // --- w = D h, gain of the next step k = w + c   (kfilter.cpp:191 of the next Update)
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; j++) a = fma(D[tri<P>(i, j)], m.h[j], a);
+            w[i] = a;
+            k[i] = a + m.c[i];
+        }
+        rprev = rec;
+    }
+    {   // last point: var_{n-1}, mean_{n-1}
+        double pv = 0.0, pm = 0.0;
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            pv = fma(m.h[r], w[r], pv);
+            pm = fma(m.h[r], z[r], pm);
+        }
+        const double var = m.s0 + pv + rprev.z * m.scale;
+        const double innov = (rprev.y - m.mu) - pm;
+        acc.add_var(var);
+        acc.chi2 += innov * (recip(var) * innov);
+    }
+    return acc.total();
+}
+
+// CARMA_Base::LogDensity (carpack.hpp:131-176): -inf outside the prior bounds or on a repeated root, else
+// log-likelihood + log prior
+template <int P>
+CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __restrict__ series, int n, const Prior& pr,
+                                 int ignore_prior)
+{
+    LaneModel<P> m;
+    lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
+    double ll = lane_filter<P>(m, series, n);
+    ll += log_prior(m.scale, pr.measerr_dof);
+    if (m.sing || !m.valid) ll = -1.0 / 0.0;
+    return ll;
+}
+
+}  // namespace carma

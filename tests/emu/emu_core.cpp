@@ -5,6 +5,7 @@
 #include <vector>
 #include "grp_emu.h"
 #include "../../carma_pack_amd/csrc/carma_core.h"
+#include "../../carma_pack_amd/csrc/carma_lane.h"
 
 using namespace carma;
 
@@ -55,6 +56,28 @@ static void kfilter_one(const double* om_re, const double* om_im, const double* 
             *sing = s;
         }
     });
+}
+
+extern "C" int emu_logdensity_carma_lane(int p, int q, const double* theta, int B, const double* series, int n, const double* prior,
+                                         int ignore_prior, double* out)
+{
+    // one evaluation per lane (carma_lane.h): plain scalar code, run once per parameter vector
+    Prior pr{prior[0], prior[1], prior[2], prior[3]};
+    const double4* s4 = reinterpret_cast<const double4*>(series);
+    const int d = 3 + p + q;
+    for (int b = 0; b < B; b++) {
+        const double* th = theta + (size_t)b * d;
+        switch (p) {
+            case 2: out[b] = logdensity_lane<2>(th, q, s4, n, pr, ignore_prior); break;
+            case 3: out[b] = logdensity_lane<3>(th, q, s4, n, pr, ignore_prior); break;
+            case 4: out[b] = logdensity_lane<4>(th, q, s4, n, pr, ignore_prior); break;
+            case 5: out[b] = logdensity_lane<5>(th, q, s4, n, pr, ignore_prior); break;
+            case 6: out[b] = logdensity_lane<6>(th, q, s4, n, pr, ignore_prior); break;
+            case 7: out[b] = logdensity_lane<7>(th, q, s4, n, pr, ignore_prior); break;
+            default: return -1;
+        }
+    }
+    return 0;
 }
 
 extern "C" {

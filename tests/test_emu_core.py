@@ -130,3 +130,52 @@ def test_emu_predict_orders(p, q):
     b = orc.predict_carma(t, y - th[2], yerr, sig, om, ma, times)
     np.testing.assert_allclose(a[0], b[0], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(a[1], b[1], rtol=1e-8)
+
+
+@pytest.mark.parametrize("p,q", [(2, 0), (2, 1), (3, 2), (4, 1), (4, 3), (5, 3), (6, 2), (6, 5), (7, 3), (7, 6)])
+def test_lane_code_matches_oracle(p, q, golden_dir):
+    """carma_lane.h -- one evaluation per lane, the throughput regime's kernel body (plain scalar code, so the host runs
+    the very functions the GPU compiles) -- against the oracle on prior-like and golden parameter vectors, with the bounds
+    on and off, real root pairs included, and against the lane-group loop it must agree with to rounding."""
+    from helpers import loglik_truth
+    if (p, q) == (5, 3):
+        g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+        t, y, yerr, th = g["t"], g["y"], g["yerr"], g["theta"]
+    else:
+        t, y, yerr = irregular_series(130, seed=p * 13 + q)
+        rng = np.random.default_rng(p * 57 + q)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(24)])
+        # quadratic factors with two REAL roots (b^2 > 4 a): first factor, then every factor
+        th[-1, 3:5] = [np.log(0.02), np.log(0.5)]
+        for i in range(p // 2):                               # well separated real roots r1 = -0.02 3^i, r2 = -0.5 1.7^i
+            r1, r2 = 0.02 * 3.0 ** i, 0.5 * 1.7 ** i
+            th[-2, 3 + 2 * i:5 + 2 * i] = [np.log(r1 * r2), np.log(r1 + r2)]
+    m = orc.OracleModel(t, y, yerr, p, q)
+    pr = (m.max_stdev, m.max_freq, m.min_freq)
+    for ign in (False, True):
+        got = emu.logdensity_carma_lane(t, y, yerr, p, q, th, pr, ignore_prior=ign)
+        want = m.logdensity_batch(th, ignore_prior=ign)
+        assert_parity(got, want, 1e-10, "lane p=%d q=%d" % (p, q), arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0],
+                      max_arb_frac=0.1)
+        ref = emu.logdensity_carma(t, y, yerr, p, q, th, pr, ignore_prior=ign)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(got), fin)
+        # (the constructed all-real-roots vectors are ill-conditioned: there the two layouts' roundings are amplified to 1e-8,
+        # each closer to the exact value than the oracle -- the arbiter above has seen them)
+        rel = np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])
+        assert np.all(rel <= 1e-6) and np.sum(rel > 1e-9) <= 2, rel
+
+
+def test_lane_code_regular_cadence():
+    """A series with a constant time step (and gaps): the lane code re-uses the transition factors of a repeated step."""
+    rng = np.random.default_rng(3)
+    t = np.concatenate([np.arange(60) * 1.5, 200.0 + np.arange(70) * 1.5])
+    y = 17.0 + np.sin(t / 9.0) + 0.4 * rng.standard_normal(t.size)
+    yerr = np.full(t.size, 0.4)
+    for p, q in ((5, 3), (3, 1)):
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(10)])
+        m = orc.OracleModel(t, y, yerr, p, q)
+        pr = (m.max_stdev, m.max_freq, m.min_freq)
+        from helpers import loglik_truth
+        assert_parity(emu.logdensity_carma_lane(t, y, yerr, p, q, th, pr), m.logdensity_batch(th), 1e-10, "lane regular cadence",
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.2)

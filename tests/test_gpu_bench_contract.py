@@ -47,7 +47,7 @@ def test_single_gpu_line():
     assert rf["traffic"] is None or (rf["traffic_source"] and rf["traffic"] < rf["algorithmic_bytes_per_launch"])
     assert 0.0 < rf["fp64_valu"]["frac"] < 1.0
     tp, ld = j["throughput"], j["ladder_sharded"]
-    assert tp["batch_per_gpu"] == 65536 and tp["kernel"] == "k_logdens_carma<5,8,4>" and tp["evals_per_s"] > j["value"]
+    assert tp["batch_per_gpu"] == 65536 and tp["kernel"] == "k_logdens_carma_lane<5>" and tp["evals_per_s"] > j["value"]
     assert ld["temperatures"] == 8 and ld["replicas"] == 128 and ld["rccl_ranks"] == 1 and ld["iters_per_s"] > 0
 
 

@@ -490,7 +490,8 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
     ctx = cpa.Context(t, y, yerr, p, q)
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     from helpers import loglik_truth
-    B = 20000                                                   # throughput kernel
+    B = 20000                                                   # lane-group throughput kernel
+    assert ctx.kernel_name(B).startswith("k_logdens_carma<") and ctx.kernel_name(40000).startswith("k_logdens_carma_lane<")
     res = {}
     for name, pool in (("complex", cplx), ("real", real), ("mixed", np.concatenate([cplx, real])[rng.permutation(64)])):
         want = m.logdensity_batch(pool, ignore_prior=True, nthreads=8)
@@ -500,6 +501,12 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
         assert_parity(got[:pool.shape[0]], want, RTOL, "%s p=%d q=%d" % (name, p, q),
                       arbiter=lambda i, pool=pool: loglik_truth(t, y, yerr, pool[i], p, q)[0])
         res[name] = dict(zip(map(bytes, pool), got[:pool.shape[0]]))
+        # one evaluation per lane (40 000 evaluations): the second exponential of a real pair is a wave-uniform branch there
+        big = np.tile(pool, (40000 // pool.shape[0] + 1, 1))[:40000]
+        gl = ctx.logdensity(big, ignore_prior=True)
+        assert np.array_equal(gl, np.tile(gl[:pool.shape[0]], 40000 // pool.shape[0] + 1)[:40000], equal_nan=True), name
+        assert_parity(gl[:pool.shape[0]], want, RTOL, "lane kernel, %s p=%d q=%d" % (name, p, q),
+                      arbiter=lambda i, pool=pool: loglik_truth(t, y, yerr, pool[i], p, q)[0])
     # the same theta in an all-complex wave (pair-shared factors) and in a mixed wave (one evaluation per lane)
     for key, v in res["complex"].items():
         w = res["mixed"][key]
@@ -569,7 +576,7 @@ def test_sampler_states_with_extreme_ma_parameters(cpa, readme):
     assert np.isfinite(want[:5]).all() and np.isnan(want[5])          # (c): the reference's own NaN
     arb = lambda i: loglik_truth(t, y, yerr, th[i % 6], 5, 3)[0]   # noqa: E731
     assert abs(want[3] - arb(3)) > 1e-4 * abs(want[3])                # (b): the reference's arithmetic is that far off
-    for B in (6, 6 * 600, 6 * 12000):                                 # wave pipeline, G-lane producer/consumer, throughput
+    for B in (6, 6 * 600, 6 * 4000, 6 * 12000):                     # wave pipeline, G-lane producer/consumer, throughput, one per lane
         got = ctx.logdensity(np.tile(th, (B // 6, 1)))
         assert np.array_equal(got, np.tile(got[:6], B // 6), equal_nan=True), ctx.kernel_name(B)
         assert np.isnan(got[5])
@@ -593,20 +600,20 @@ def test_regular_cadence_series(cpa, p, q):
     y = 5.0 + np.sin(t / 9.0) + 0.3 * rng.standard_normal(n)
     yerr = np.full(n, 0.3) * rng.uniform(0.8, 1.2, n)
     ctx = cpa.Context(t, y, yerr, p, q)
-    assert ctx.kernel_name(70000).endswith(",true>")
+    assert ctx.kernel_name(20000).endswith(",true>") and ctx.kernel_name(70016).startswith("k_logdens_carma_lane<")
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(32)])
     r1 = 10.0 ** rng.uniform(-2.0, -0.5, 8)
     th[:8, 3], th[:8, 4] = np.log(r1 * r1 * 7.0), np.log(r1 * 8.0)  # one quadratic factor with two real roots
     want = m.logdensity_batch(th, ignore_prior=True)
-    for B in (32, 3200, 9600, 70016):
+    for B in (32, 3200, 9600, 20000, 70016):                      # (70 016: one evaluation per lane, which always re-uses)
         got = ctx.logdensity(np.tile(th, (B // 32, 1)), ignore_prior=True)
         assert np.array_equal(got, np.tile(got[:32], B // 32), equal_nan=True), ctx.kernel_name(B)
         assert_parity(got[:32], want, RTOL, "regular cadence p=%d q=%d %s" % (p, q, ctx.kernel_name(B)),
                       arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
     # an irregular series keeps the plain variant
     ti = np.cumsum(rng.uniform(1.0, 3.0, n))
-    assert not cpa.Context(ti, y, yerr, p, q).kernel_name(70000).endswith(",true>")
+    assert not cpa.Context(ti, y, yerr, p, q).kernel_name(20000).endswith(",true>")
 
 
 @pytest.mark.parametrize("unit", [1e-60, 1e-7, 1e9, 1e45])
@@ -631,7 +638,7 @@ def test_units_of_the_data_do_not_matter(cpa, unit):
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     want = m.logdensity_batch(th, ignore_prior=True)
     assert np.isfinite(want).sum() >= 20
-    for B in (24, 3600, 72000):
+    for B in (24, 3600, 24000, 72000):
         got = ctx.logdensity(np.tile(th, (B // 24, 1)), ignore_prior=True)[:24]
         assert_parity(got, want, RTOL, "unit %g %s" % (unit, ctx.kernel_name(B)),
                       arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
@@ -705,3 +712,27 @@ def test_ill_conditioned_models_against_the_reference_python(cpa, golden_dir):
         assert_parity(ll, ref, RTOL, "ill-conditioned p=%d q=%d vs reference Python" % (p, q),
                       arbiter=lambda i: loglik_truth(t, y, e, th[i], p, q)[1], max_arbitrated=len(sel))
     print("%d of %d ill-conditioned vectors arbitrated (the reference itself is beyond 1e-10 on 11)" % (narb, len(g["p"])))
+
+
+@pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
+def test_lane_kernel_prior_like_sweep(cpa, p):
+    """k_logdens_carma_lane<P> -- one evaluation per lane, what launches of 32 768 evaluations and more take (round 3) --
+    for every order (p, q < p): 160 prior-like parameter vectors, tiled to 33 000 evaluations, bounds on and off, against the
+    oracle with the usual bar (1e-10, or no further from the quad-precision value than the oracle); every copy of a
+    vector gives the same bits wherever it sits in the launch."""
+    from helpers import loglik_truth
+    for q in range(p):
+        t, y, yerr = irregular_series(150, seed=300 * p + q)
+        rng = np.random.default_rng(9000 + 10 * p + q)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(160)])
+        ctx = cpa.Context(t, y, yerr, p, q)
+        B = 33000
+        assert ctx.kernel_name(B) == "k_logdens_carma_lane<%d>" % p
+        m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+        big = np.tile(th, (B // 160 + 1, 1))[:B]
+        for ign in (False, True):
+            want = m.logdensity_batch(th, ignore_prior=ign, nthreads=os.cpu_count() or 8)
+            got = ctx.logdensity(big, ignore_prior=ign)
+            assert np.array_equal(got, np.tile(got[:160], B // 160 + 1)[:B], equal_nan=True)
+            assert_parity(got[:160], want, RTOL, "lane kernel p=%d q=%d" % (p, q),
+                          arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.04)

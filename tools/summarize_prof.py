@@ -4,7 +4,7 @@
    pmc_<tag>.json               headline kernel k_logdens_carma_p3l<5>: per-LAUNCH mean/min/max of each counter
    pmc_<tag>_ptrow.json         sampler kernel k_pt_row<5,...>: counters summed over its dispatches / iterations run
                                 (the bench's sampler leg under --mcmc-iters 200: 100 warm-up + 200 timed = 300) -> per ITERATION
-   pmc_<tag>_tput.json          throughput kernel k_logdens_carma<5,8,4>: per launch of 65 536 evaluations
+   pmc_<tag>_tput.json          throughput kernel k_logdens_carma_lane<5> (one evaluation per lane): per launch of 65 536 evaluations
 usage: summarize_prof.py <tag> [outdir] [sampler-iterations-in-the-pmc-run (300)]"""
 import csv, glob, json, os, shutil, sys
 
@@ -48,7 +48,7 @@ def collect(kern, grid=None, per_iteration=0):
 
 
 for name, kern, grid, it in (("", "k_logdens_carma_p3l<5>", 65536, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),
-                             ("_tput", "k_logdens_carma<5,8,4", None, 0)):
+                             ("_tput", "k_logdens_carma_lane<5>", None, 0)):
     r = collect(kern, grid, it)
     if r["_dispatch"] is None:
         print("no dispatches of", kern)
