@@ -276,3 +276,44 @@ def test_rccl_exchange_between_two_gpus():
     assert np.array_equal(nth0, th0) and np.array_equal(nlp0, lp0)
     assert np.array_equal(nth1, th1) and np.array_equal(nlp1, lp1)
     assert (npr0, nsw0) == (pr0, sw0) and (npr1, nsw1) == (pr1, sw1)
+
+
+def _replica_worker(rank, world, port, q):
+    """CarmaModel.run_mcmc(dist=): independent ladders split over the ranks, coldest chains gathered on every rank."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import carmcmc as cm
+        t, y, e = _series()
+        model = cm.CarmaModel(t, y + 3.0, e, p=P, q=Q)
+        s = model.run_mcmc(60, nburnin=40, ntemperatures=4, nreplicas=5, seed=99, dist=dist)
+        q.put((rank, np.asarray(s._sampler._all_samples), np.asarray(s._sampler._all_logposts)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_mcmc_with_replicas_split_over_ranks():
+    """SURVEY 8(e) mode 2 through the Python API: run_mcmc(nreplicas=5, dist=) on two ranks (3 + 2 ladders; gloo, both on
+    the one GPU) returns, on EVERY rank, the samples and log-posteriors of all five ladders -- the very arrays the
+    single-process call with the same seed returns (starting values and sampler streams are keyed by the global chain
+    slot, so the split does not enter)."""
+    import torch.multiprocessing as mp
+    from helpers import queue_get
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted((queue_get(q, procs, 300) for _ in range(2)), key=lambda r: r[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    import carmcmc as cm
+    t, y, e = _series()
+    one = cm.CarmaModel(t, y + 3.0, e, p=P, q=Q).run_mcmc(60, nburnin=40, ntemperatures=4, nreplicas=5, seed=99)
+    ref_s, ref_l = np.asarray(one._sampler._all_samples), np.asarray(one._sampler._all_logposts)
+    assert ref_s.shape == (5, 60, 3 + P + Q)
+    for _, s, l in res:
+        assert np.array_equal(s, ref_s) and np.array_equal(l, ref_l)
