@@ -17,7 +17,7 @@ m = orc.OracleModel(t, y, yerr, P, Q, max_stdev=ctx.prior()[0])
 want = m.logdensity_batch(base[:512], nthreads=8)
 dev = torch.device('cuda'); st = torch.cuda.current_stream().cuda_stream
 print("CARMA_TUNE_LANE_MIN=%s  CARMA(%d,%d)" % (os.environ.get("CARMA_TUNE_LANE_MIN", "(default)"), P, Q))
-for B in (4096, 8192, 16384, 32768, 65536, 131072, 262144, 1048576):
+for B in (16384, 24576, 32768, 65536, 131072, 1048576):
     th = torch.from_numpy(np.tile(base, (B // 4096 + 1, 1))[:B].copy()).to(dev)
     out = torch.empty(B, dtype=torch.float64, device=dev)
     for _ in range(3): ctx.logdensity_dev(th.data_ptr(), B, out.data_ptr(), stream=st)
