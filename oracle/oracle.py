@@ -247,42 +247,46 @@ class OracleModel:
 
 
 class NativeComparator:
-    """The SAME restatement built `-O3 -march=native` (no fast-math) on the machine that runs it: the CPU comparator of
-    SURVEY.md 8(d), used by bench.py's cpu_baseline leg only.  Never the parity oracle (FMA contraction is on here)."""
+    """The SAME restatement built with -march=native (no fast-math) on the machine that runs it: the CPU comparator of
+    SURVEY.md 8(d), used by bench.py's cpu_baseline leg only.  Never the parity oracle (FMA contraction is on here).
+    variant "O3": -O3 -march=native as 8(d) words it; "O2": -O2 -march=native, which is 3x FASTER on this code (gcc's -O3
+    vectoriser pessimises its short complex loops)."""
 
-    _so = os.path.join(_HERE, "libcarma_oracle_native.so")
-    _L = None
+    _libs = {}
+    FLAGS = {"O3": "-O3 -march=native", "O2": "-O2 -march=native"}
 
     @classmethod
-    def _lib(cls):
-        if cls._L is None:
-            subprocess.check_call(["make", "-C", _HERE, "-B", "libcarma_oracle_native.so"], stdout=subprocess.DEVNULL)
-            L = C.CDLL(cls._so)
+    def _lib(cls, variant):
+        if variant not in cls._libs:
+            name = "libcarma_oracle_native.so" if variant == "O3" else "libcarma_oracle_native_o2.so"
+            subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
+            L = C.CDLL(os.path.join(_HERE, name))
             L.orc_model_create.restype = C.c_void_p
             L.orc_model_create.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double]
             L.orc_model_destroy.argtypes = [C.c_void_p]
             L.orc_logdensity_batch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, _dp]
             L.orc_max_threads.restype = C.c_int
-            cls._L = L
-        return cls._L
+            cls._libs[variant] = L
+        return cls._libs[variant]
 
-    def __init__(self, t, y, yerr, p, q, max_stdev):
+    def __init__(self, t, y, yerr, p, q, max_stdev, variant="O3"):
         t, y, yerr = _a(t), _a(y), _a(yerr)
+        self.variant = variant
         self.p, self.q = int(p), int(q)
         self.d = 4 if self.p == 1 else 3 + self.p + self.q
-        self._h = C.c_void_p(self._lib().orc_model_create(_p(t), _p(y), _p(yerr), t.size, self.p, self.q, float(max_stdev)))
+        self._h = C.c_void_p(self._lib(variant).orc_model_create(_p(t), _p(y), _p(yerr), t.size, self.p, self.q, float(max_stdev)))
 
     def __del__(self):
         try:
-            self._lib().orc_model_destroy(self._h)
+            self._lib(self.variant).orc_model_destroy(self._h)
         except Exception:
             pass
 
     def max_threads(self):
-        return self._lib().orc_max_threads()
+        return self._lib(self.variant).orc_max_threads()
 
     def logdensity_batch(self, thetas, ignore_prior=False, nthreads=1):
         thetas = _a(thetas).reshape(-1, self.d)
         out = np.empty(thetas.shape[0])
-        self._lib().orc_logdensity_batch(self._h, _p(thetas), thetas.shape[0], int(ignore_prior), int(nthreads), _p(out))
+        self._lib(self.variant).orc_logdensity_batch(self._h, _p(thetas), thetas.shape[0], int(ignore_prior), int(nthreads), _p(out))
         return out
