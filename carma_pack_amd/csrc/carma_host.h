@@ -28,8 +28,9 @@ struct PtState {
     // row-variant kernel (k_pt_row): ladders spread over wpl workgroups, swap through global staging
     bool use_row = false;
     int wpl = 0;
-    double *d_stage_th = nullptr, *d_stage_lp = nullptr;
-    unsigned *d_counter = nullptr, *d_abort = nullptr;
+    unsigned long long* d_stage = nullptr;      // tagged staging words of the swap step (PtRowSync::stage)
+    unsigned long long epoch = 0;               // launches so far (PtRowSync::epoch)
+    unsigned* d_abort = nullptr;
     double* d_backup = nullptr;         // chain state before the chunk in flight (theta, logpost, chol): abort recovery
     // ladder sharded across ranks (carma_shard.hip): boundary staging and statistics
     double *d_send = nullptr, *d_recv = nullptr;       // [R][d+1] each

@@ -250,6 +250,23 @@ static hipError_t launch_pt_p(const PtLaunch& L, const double4* series, const Pr
 // once it has handed the log-density over -- waits for the ladder at the rendezvous, fetches the staged log-posteriors
 // and parameter vectors and replays the sweep.  The two meet at a barrier, the chain wave picks up what the sweep
 // assigned to its rows, adds R^T z and the next filter starts.
+// TAGGED STAGING (round 3).  The chains a ladder's workgroups exchange in the swap step travel as self-validating words:
+// every 64-bit value v is stored twice, as v ^ tag1 and v ^ tag2 with tags derived from (iteration, launch counter), by
+// relaxed agent-scope stores with nothing to wait for; a reader loads both words and takes the value when
+// (a ^ tag1) == (b ^ tag2) -- a word left over from an earlier iteration (the buffers alternate) or never written fails
+// that test (for a wrong pair to pass, two independent 64-bit hashes would have to collide).  Every 8-byte access is
+// atomic by itself, so no ordering between the words is needed: the reader simply polls the ladder's (T (d + 1)) pairs
+// until all of them validate -- ONE round trip after the last store has landed, instead of round 2's "stores, wait for
+// their acknowledgement, bump an arrival counter | poll the counter, then fetch" (two waits on the publishing side, two
+// round trips on the reading side): 34.1 -> 33.0 us per iteration at 16 x 64.
+__device__ __forceinline__ unsigned long long pt_tag(unsigned long long iter, unsigned long long epoch, unsigned long long salt)
+{
+    unsigned long long z = (iter + 1) * 0x9E3779B97F4A7C15ull + epoch * 0xD1B54A32D192ED03ull + salt;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 // MINW = workgroups of this kernel a CU is to hold (waves per SIMD): 2 -> up to 256 registers, nothing spilled; 3 -> 168
 // registers, where the cold code of the swap step and of the random-number tails spills a few values around itself (the
 // recursion loops do not).  The host takes MINW = 3 only for grids of more than two workgroups per CU.
@@ -271,7 +288,8 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3l.h rings
     double* s_thn = reinterpret_cast<double*>(ring + Pipe3LGeom<P>::ENTRIES);  // [CPW][16] proposals
     double* s_ll = s_thn + CPW * PT_DMAX;                  // [CPW] log-density of the proposals (mean wave -> chain wave)
-    double* s_lp = s_ll + CPW;                             // [T] the ladder's log-posteriors after the sweep
+    double* s_ua = s_ll + CPW;                             // [CPW] acceptance uniforms of this iteration (producer wave 1)
+    double* s_lp = s_ua + CPW;                             // [T] the ladder's log-posteriors after the sweep
     double* s_dbeta = s_lp + T;
     double* s_logu = s_dbeta + T;
     unsigned* s_nswap = reinterpret_cast<unsigned*>(s_logu + T);
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     double* s_z = reinterpret_cast<double*>(s_flag + 2);   // [64] next iteration's t8 variates, drawn by producer wave 0
     double* s_lu = s_z + 64;                               // [64] this exchange's log-uniforms (T <= 64), producer wave 1
     double* s_step = s_lu + 64;                            // [1] this iteration's adaptation step length (+ pad), same
-    double* s_tha = s_step + 2;                            // [T][d] the ladder's staged parameter vectors (T <= 64)
+    double* s_tha = s_step + 2;                            // [T][d + 1] the ladder's staged (theta, log-posterior), validated copy
     // Which ladder, which part of it.  Workgroups are dealt to the eight XCDs (each with its own L2) round-robin by
     // blockIdx, and the swap step is an exchange between the workgroups of ONE ladder: S.xcd_map = 8 puts a ladder's wpl
     // workgroups on blockIdx b, b + 8, b + 16, ... -- the same XCD -- instead of b, b + 1, ... (eight different ones).
@@ -333,10 +351,14 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             if (wave == 2) {
                 s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
                 if (lane64 == 0) *s_step = ram_adapt_step(d, iter);
-            } else if (exch && T <= 64) {
-                const int i = lane64 < T ? lane64 : T - 1;
-                RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
-                s_lu[lane64] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+            } else {
+                if (exch && T <= 64) {
+                    const int i = lane64 < T ? lane64 : T - 1;
+                    RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
+                    s_lu[lane64] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
+                }
+                const double ua = rng_uniform(key, iter, RNG_ACCEPT, 0);     // the rows' Metropolis uniforms
+                if (j == 0) s_ua[row] = ua;
             }
             __syncthreads();                               // log-densities (and these draws) visible
             __syncthreads();                               // sweep done
@@ -347,7 +369,6 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
 
     if (wave == 1) {
         // ---- mean recursion of the four proposals, then the ladder's swap sweep (steps.hpp:318-362)
-        unsigned nexch = 0;
         int buf = 0;
         for (int it = 0; it < L.niter; it++) {
             const uint64_t iter = L.iter0 + (uint64_t)it;
@@ -371,39 +392,42 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             CARMA_STAMP(b0);
 #endif
             if (exch) {
-                const double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
-                const double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
-                // wait for the ladder: every workgroup's chain wave bumps the counter once its chains are staged
+                // the ladder's staged chains: poll the tagged words until every pair validates (see "tagged staging")
+                const size_t nval = nchain_all * (size_t)(d + 1);
+                const unsigned long long* st_a = S.stage + (size_t)buf * 2 * nval + (size_t)ch0 * (d + 1);
+                const unsigned long long* st_b = st_a + nval;
+                const unsigned long long tg1 = pt_tag(iter, S.epoch, 1), tg2 = pt_tag(iter, S.epoch, 2);
+                const int NV = T * (d + 1);
                 int aborted = 0;
-                if (lane64 == 0) {
-                    const unsigned target = (unsigned)S.wpl * (nexch + 1);
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(&S.counter[lad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                        if (__hip_atomic_load(S.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                            ++spins > 20000000u) {
-                            __hip_atomic_store(S.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            *s_flag = 1;
-                            aborted = 1;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(4);
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+                    for (int v = lane64; v < NV; v += 64) {
+                        const unsigned long long a = __hip_atomic_load(&st_a[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ tg1;
+                        const unsigned long long b = __hip_atomic_load(&st_b[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ tg2;
+                        ok = ok && (a == b);
+                        s_tha[v] = __longlong_as_double((long long)a);
                     }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                    if (lane64 == 0 && (__hip_atomic_load(S.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > 5000000u)) {
+                        __hip_atomic_store(S.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *s_flag = 1;
+                        aborted = 1;
+                    }
+                    aborted = __builtin_amdgcn_readfirstlane(aborted);
+                    if (aborted) break;
+                    __builtin_amdgcn_s_sleep(2);
                 }
-                aborted = __builtin_amdgcn_readfirstlane(aborted);
 #if defined(CARMA_STAMPS)
                 CARMA_STAMP(b1);
 #endif
                 if (!aborted) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    g.sync();                              // this wave's LDS writes above, read back below
                     if (T <= 64) {
-                        // the ladder's staged parameter vectors into LDS, requested TOGETHER with the log-posteriors
-                        // (which vector a chain picks up is known only after the sweep; a load after it was one more
-                        // trip to L2).  Lane i owns temperature i, the sweep runs through v_readlane.
-                        for (int i = lane64; i < T * d; i += 64)
-                            s_tha[i] = __hip_atomic_load(&st_th[ch0 * d + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // lane i owns temperature i, the sweep runs through v_readlane
                         const int i = lane64 < T ? lane64 : T - 1;
-                        double lp_i = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const double logu_i = s_lu[lane64];           // drawn by producer wave 1 during the filter
+                        double lp_i = s_tha[i * (d + 1) + d];
+                        const double logu_i = s_lu[lane64];           // drawn by producer wave 1 behind the pipeline
                         int src_i = i;
                         bool sw;
                         exchange_decide_wave(T, lane64, lp_i, s_dbeta[i], logu_i, src_i, &sw);
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                         }
                     } else {
                         for (int i = lane64; i < T; i += 64) {
-                            s_lp[i] = __hip_atomic_load(&st_lp[ch0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_lp[i] = s_tha[i * (d + 1) + d];
                             s_src[i] = i;
                             RngKey k2{L.seed0, L.seed1, chain_base + (uint32_t)i};
                             s_logu[i] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
@@ -424,7 +448,6 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                     }
                 }
                 buf ^= 1;
-                nexch++;
             }
 #if defined(CARMA_STAMPS)
             CARMA_STAMP(b2);
@@ -477,22 +500,25 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
         __syncthreads();                                   // log-densities visible
         CARMA_STAMP(st3);
         double alpha;
-        if (ram_accept_row(ch, temperature, iter, key, s_ll[row], &lp, &alpha)) nacc++;
+        if (ram_accept_row(ch, temperature, iter, key, s_ll[row], &lp, &alpha, s_ua + row)) nacc++;
         if (exch) {
-            // publish this workgroup's chains and ARRIVE at the ladder's rendezvous.  Agent-scope (write-through)
-            // stores and loads for the staged values instead of a device-wide fence: a release/acquire fence at
-            // agent scope writes back and invalidates the whole L2 of the XCD, and with 256 workgroups doing that
-            // every iteration the swap cost grew from 4 to 20 us (the L2-resident series had to be re-fetched each
-            // time).  The stores are complete (vmcnt) before the arrival counter is bumped; both by this wave.
-            double* st_th = S.stage_th + (size_t)buf * nchain_all * d;
-            double* st_lp = S.stage_lp + (size_t)buf * nchain_all;
+            // publish this workgroup's chains as tagged words (see "tagged staging"): fire and forget
+            const size_t nval = nchain_all * (size_t)(d + 1);
+            unsigned long long* st_a = S.stage + (size_t)buf * 2 * nval + (size_t)(ch0 + c) * (d + 1);
+            unsigned long long* st_b = st_a + nval;
+            const unsigned long long tg1 = pt_tag(iter, S.epoch, 1), tg2 = pt_tag(iter, S.epoch, 2);
             if (active) {
-                if (j < d) __hip_atomic_store(&st_th[(ch0 + c) * d + j], ch.th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (j == 0) __hip_atomic_store(&st_lp[ch0 + c], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j < d) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(ch.th);
+                    __hip_atomic_store(&st_a[j], bits ^ tg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&st_b[j], bits ^ tg2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (j == 0) {                              // (d may be 16: the log-posterior has no lane of its own)
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(lp);
+                    __hip_atomic_store(&st_a[d], bits ^ tg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&st_b[d], bits ^ tg2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0);
-            if (lane64 == 0) __hip_atomic_fetch_add(&S.counter[lad], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             buf ^= 1;
         }
         CARMA_STAMP(st4);
@@ -508,13 +534,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
         if (exch) {
             const int from = s_src[cc];
             lp = s_lp[cc];
-            if (from != cc && j < d) {
-                if (T <= 64)
-                    ch.th = s_tha[from * d + j];
-                else
-                    ch.th = __hip_atomic_load(&S.stage_th[(size_t)(buf ^ 1) * nchain_all * d + (ch0 + from) * d + j], __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (from != cc && j < d) ch.th = s_tha[from * (d + 1) + j];
         }
         CARMA_STAMP(st7);
 #if defined(CARMA_STAMPS)
@@ -549,9 +569,9 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
 static size_t pt_row_lds(int d, int T)
 {
     (void)d;
-    // rings, proposals [4][16], s_ll [4], s_lp / s_dbeta / s_logu [T], s_nswap + s_src [T] (4 B each), flag, s_z / s_lu [64], step, s_tha
-    return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 4 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16 + 128 * 8 + 16 +
-           (size_t)(T <= 64 ? T : 0) * PT_DMAX * 8;
+    // rings, proposals [4][16], s_ll [4], s_ua [4], s_lp / s_dbeta / s_logu [T], s_nswap + s_src [T] (4 B each), flag, s_z / s_lu [64], step, s_tha
+    return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 8 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16 + 128 * 8 + 16 +
+           (size_t)T * (PT_DMAX + 1) * 8;
 }
 
 template <int P>

@@ -32,9 +32,7 @@ void pt_state_free(Ctx* c)
     if (s->d_nswap) (void)hipFree(s->d_nswap);
     if (s->d_samples) (void)hipFree(s->d_samples);
     if (s->d_slp) (void)hipFree(s->d_slp);
-    if (s->d_stage_th) (void)hipFree(s->d_stage_th);
-    if (s->d_stage_lp) (void)hipFree(s->d_stage_lp);
-    if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->d_stage) (void)hipFree(s->d_stage);
     if (s->d_abort) (void)hipFree(s->d_abort);
     if (s->d_backup) (void)hipFree(s->d_backup);
     if (s->d_send) (void)hipFree(s->d_send);
@@ -164,9 +162,7 @@ static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save
     const PtLaunch L = pt_launch_args(c, ch, do_exchange, thin, save_offset ? *save_offset : 0);
     hipError_t e;
     if (s->use_row) {
-        e = hipMemsetAsync(s->d_counter, 0, sizeof(unsigned) * s->R, st);
-        if (e != hipSuccess) return hip_fail(e, "reset pt counters");
-        PtRowSync S{s->d_stage_th, s->d_stage_lp, s->d_counter, s->d_abort, s->wpl, device_cus(), 1, 0};
+        PtRowSync S{s->d_stage, s->d_abort, ++s->epoch, s->wpl, device_cus(), 1, 0};
         e = launch_pt_row(c->p, L, S, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
                           s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
         if (e == hipErrorCooperativeLaunchTooLarge) {      // the grid is not co-resident on this device: ladder kernel
@@ -348,9 +344,10 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
         if (want && cap >= (long)nreplicas * wpl) {
             s->use_row = true;
             s->wpl = wpl;
-            e = hipMalloc(&s->d_stage_th, sizeof(double) * 2 * nchain * d);
-            if (e == hipSuccess) e = hipMalloc(&s->d_stage_lp, sizeof(double) * 2 * nchain);
-            if (e == hipSuccess) e = hipMalloc(&s->d_counter, sizeof(unsigned) * nreplicas);
+            // tagged staging: two buffers x two copies of (theta[d], log-posterior) per chain; zeroed once (an all-zero
+            // pair of words never validates)
+            e = hipMalloc(&s->d_stage, sizeof(unsigned long long) * 4 * nchain * (d + 1));
+            if (e == hipSuccess) e = hipMemset(s->d_stage, 0, sizeof(unsigned long long) * 4 * nchain * (d + 1));
             if (e == hipSuccess) e = hipMalloc(&s->d_abort, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(s->d_abort, 0, sizeof(unsigned));
             if (e == hipSuccess) e = hipMalloc(&s->d_backup, sizeof(double) * nchain * (d + 1 + (size_t)d * d));

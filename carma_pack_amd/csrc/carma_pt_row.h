@@ -44,19 +44,43 @@ __device__ __forceinline__ double ram_draw_row(const Grp<16>& g, RowChain& ch, i
     return znorm2;
 }
 
-// CholUpdateR1 (steps.cpp:111-131) on the register-resident factor.
+// 1 / sqrt(x) to double precision: v_rsq_f64 (2^-24) + two Newton steps.  (The rank-1 update below needs sqrt(x) AND 1 / sqrt(x);
+// the library sqrt is the same sequence plus a scaling for denormal inputs, which a Cholesky diagonal never is.)
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
+// CholUpdateR1 (steps.cpp:111-131) on the register-resident factor.  Step k turns on (R_kk, v_k): with rs = 1 / sqrt(R_kk^2 +-
+// v_k^2) the reference's c = rr / R_kk, s = v_k / R_kk and the division by c become rr = x rs, c = rr / R_kk, s = v_k / R_kk,
+// 1 / c = R_kk rs.  The diagonal entries are not touched before their own step, so every lane forms 1 / R_jj ONCE in front of
+// the loop; what is left on the dependent chain v_k -> rs -> row update -> v_{k+1} is one reciprocal square root instead of a
+// square root and two reciprocals (round 3: the adaptation is no longer hidden behind the swap rendezvous -- the tagged
+// staging made that shorter than this loop).
 __device__ __forceinline__ void chol_update_row(const Grp<16>& g, int d, RowChain& ch, bool downdate)
 {
     const int j = g.lane();
     const double sign = downdate ? -1.0 : 1.0;
+    double diag = 1.0;
+    static_for<0, PT_DMAX>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (j == k) diag = ch.Rc[k];
+    });
+    const double idiag = recip(diag);                       // 1 / R_jj of this lane's own diagonal entry
     static_for<0, PT_DMAX>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if (k < d) {
             const double Rkk = Grp<16>::bcast_c<k>(ch.Rc[k]);
+            const double iR = Grp<16>::bcast_c<k>(idiag);
             const double vk = Grp<16>::bcast_c<k>(ch.v);
-            const double rr = sqrt(Rkk * Rkk + sign * vk * vk);
-            const double iR = recip(Rkk);
-            const double c = rr * iR, s = vk * iR, ic = Rkk * recip(rr);
+            const double x = fma(sign * vk, vk, Rkk * Rkk);
+            const double rs = rsqrt_nr(x);
+            const double rr = x * rs;
+            const double c = rr * iR, s = vk * iR, ic = Rkk * rs;
             const double Rkj = (ch.Rc[k] + sign * s * ch.v) * ic;
             const double vj = c * ch.v - s * Rkj;
             ch.Rc[k] = (j == k) ? rr : (j > k ? Rkj : ch.Rc[k]);
@@ -66,8 +90,9 @@ __device__ __forceinline__ void chol_update_row(const Grp<16>& g, int d, RowChai
 }
 
 // Metropolis accept with the tempered ratio (steps.cpp:36-56); *alpha is the acceptance probability the adaptation uses.
+// `upre` (may be null): the acceptance uniform drawn ahead of time by a producer wave (same key, iteration, purpose)
 __device__ __forceinline__ bool ram_accept_row(RowChain& ch, double temperature, uint64_t iter, const RngKey& key, double ll,
-                                               double* lp, double* alpha_out)
+                                               double* lp, double* alpha_out, const double* upre = nullptr)
 {
     double alpha = (ll - *lp) / temperature;
     bool accept = false;
@@ -75,7 +100,7 @@ __device__ __forceinline__ bool ram_accept_row(RowChain& ch, double temperature,
     if (!fin) {
         alpha = 0.0;                                    // steps.cpp:41-46
     } else {
-        const double u = rng_uniform(key, iter, RNG_ACCEPT, 0);
+        const double u = upre ? *upre : rng_uniform(key, iter, RNG_ACCEPT, 0);
         alpha = fmin(exp(alpha), 1.0);
         accept = u < alpha;
     }
@@ -101,7 +126,7 @@ __device__ __forceinline__ void ram_adapt_row(const Grp<16>& g, RowChain& ch, in
                                               double znorm2, double step)
 {
     if ((long)iter < (long)maxiter) {
-        const double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(znorm2);
+        const double fac = sqrt(step * fabs(alpha - 0.25) * recip(znorm2));
         ch.v *= fac;
         chol_update_row(g, d, ch, alpha < 0.25);
     }

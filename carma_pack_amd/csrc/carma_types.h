@@ -47,13 +47,12 @@ struct PtLaunch {
     unsigned replica0;           // global index of local replica 0            (replica sharding)
 };
 
-// Cross-workgroup exchange state of the row-variant PT kernel (k_pt_row): a ladder is spread over
-// `wpl` workgroups, which meet once per iteration through global memory.
+// Cross-workgroup exchange state of the row-variant PT kernel (k_pt_row): a ladder is spread over `wpl` workgroups, which
+// exchange their chains once per iteration through global memory -- as SELF-VALIDATING words (k_pt_row, "tagged staging").
 struct PtRowSync {
-    double* stage_th;        // [2][R*T*d] current values published for the swap
-    double* stage_lp;        // [2][R*T]
-    unsigned* counter;       // [R] arrivals of the ladder's workgroups (zeroed before every launch)
-    unsigned* abort_flag;    // [1] set when a barrier timed out (the launch then ends early)
+    unsigned long long* stage;   // [2 buffers][2 copies][R*T*(d+1)] tagged 64-bit words: theta[d] and the log-posterior of every chain
+    unsigned* abort_flag;    // [1] set when a rendezvous timed out (the launch then ends early)
+    unsigned long long epoch;    // launch counter of this sampler (never repeats): part of the tags
     int wpl;                 // workgroups per ladder = ceil(T / 4)
     int ncu;                 // compute units of the device: workgroups i, i + ncu, i + 2 ncu share a CU
     int xcd_map;             // > 1: a ladder's workgroups sit xcd_map blocks apart (same XCD), see k_pt_row
