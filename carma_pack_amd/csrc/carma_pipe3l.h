@@ -63,6 +63,17 @@ __device__ __forceinline__ void row_consts(const Grp<16>& g, const Model<P>& m, 
     rc.s0 = fc.s0;
 }
 
+// wave priorities when workgroups share a CU (A/B builds may override; measured: profiles/r03/priorities_ab_v*.txt)
+#ifndef CARMA_PRIO_A
+#define CARMA_PRIO_A 3
+#endif
+#ifndef CARMA_PRIO_B
+#define CARMA_PRIO_B 1
+#endif
+#ifndef CARMA_PRIO_P
+#define CARMA_PRIO_P 1
+#endif
+
 template <int P>
 struct Pipe3LGeom {
     static constexpr int C = 16;
@@ -120,6 +131,7 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
     // n counts the npad neutral pad data at the end (carma_types.h, p3l_pad): their entries are exact zeros
     using Geo = Pipe3LGeom<P>;
     constexpr int C = Geo::C;
+    if (CARMA_PRIO_P != 0) __builtin_amdgcn_s_setprio(CARMA_PRIO_P);
     // a lane works on a conjugate PAIR of roots (2 pr, 2 pr + 1): both share |E|, cos and sin, so one exp/sincos
     // evaluation serves two ring entries; an odd order's last lane holds the single real root
     constexpr int NPAIR = (P + 1) / 2, PPL = 16 / NPAIR;
@@ -286,9 +298,10 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
     const int lane = g.lane64;
     const int nc = (n + C - 1) / C;
     // When workgroups share a CU this wave's instruction stream is the one the launch waits for: it issues ahead of the
-    // mean waves (priority 1) and the producers (0) of the other workgroups on its SIMD (2048 evaluations 39.0 -> 36.7 us,
+    // mean waves and the producers (priority 1 both: 3 / 1 / 0 was 4 % slower) of the other workgroups on its SIMD (2048
+    // evaluations 39.0 -> 35.2 us, 3072: 51.5 -> 47.4 us,
     // 16 x 128 ladders 20.6k -> 22.3k iterations/s; nothing to arbitrate with one workgroup per CU)
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(CARMA_PRIO_A);
     const bool act = (lane & 15) < P;
     const double h_row = act ? rc.h_own : 0.0, c_row = act ? rc.c_own : 0.0;     // idle lanes carry exact zeros
     reinterpret_cast<double2*>(ring + Geo::CONST_OFF)[Geo::entry(lane)] = make_double2(h_row, c_row);
@@ -425,7 +438,7 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
     double z = 0.0, h_own = 0.0;                              // h_own: read from LDS once the covariance wave has published it
     LogLikAcc acc;
     acc.init();
-    __builtin_amdgcn_s_setprio(1);                            // see pipe3l_cov
+    __builtin_amdgcn_s_setprio(CARMA_PRIO_B);                 // see pipe3l_cov
     const double2* ring_b = nullptr;
     const double2* link_b = nullptr;
     double2 hc_n = make_double2(0.0, 0.0), lk_n = make_double2(0.0, 1.0);
