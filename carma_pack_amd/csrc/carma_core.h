@@ -72,7 +72,16 @@ CARMA_DEV Cx csel(bool m, Cx a, Cx b) { return {m ? a.re : b.re, m ? a.im : b.im
 CARMA_DEV Cx quad_root(double lq1, double lq2, int which)
 {
     double q1 = exp(lq1), q2 = exp(lq2);
-    double disc = q2 * q2 - 4.0 * q1;
+    // The discriminant as the reference rounds it: the product q2 q2 rounded BEFORE the subtraction, no fused multiply-add.
+    // It matters in one place: where 4 q1 / q2^2 lies between 2^-53 and 2^-52 the reference's q2 - sqrt(disc) is exactly
+    // zero or one ulp depending on that rounding -- and with a zero root its MA polynomial, and the log-density, is NaN (kept,
+    // see below).  A fused discriminant put the sampler's stored log-posterior on the other side of that coin for about one
+    // state in 1500 of the configs[2] run.  (What is left is the last bit of exp(): the two libraries agree on most arguments.)
+    double q22 = q2 * q2;
+#ifdef __HIPCC__
+    asm volatile("" : "+v"(q22));                    // (keeps the compiler from contracting the next line into an FMA)
+#endif
+    double disc = q22 - 4.0 * q1;
     const double sq = sqrt(fabs(disc));              // one sqrt for both signs of the discriminant
     Cx r;
     if (disc > 0) {

@@ -60,6 +60,41 @@ def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=N
     return float(rel.max())
 
 
+def in_zero_root_band(theta, p, q):
+    """True when a quadratic factor of theta (AR or MA; log coefficients lq1, lq2 -> q1 = e^lq1, q2 = e^lq2) has two real roots
+    with 4 q1 / q2^2 between 2^-54 and 2^-51: the band in which the reference's smaller root -(q2 - sqrt(q2^2 - 4 q1)) / 2 is
+    exactly zero or not depending on the last bit of exp() and of the discriminant's rounding -- and with a zero MA root
+    the reference's log-density is NaN (carpack.cpp:522-580 divides by it).  Two correct implementations can land on
+    different sides; the sampler's unconstrained MA parameters drift through this band."""
+    th = np.asarray(theta, dtype=float)
+    for lo, m in ((3, p), (3 + p, q)):
+        for i in range(m // 2):
+            lq1, lq2 = th[lo + 2 * i], th[lo + 2 * i + 1]
+            r = np.log2(4.0) + (lq1 - 2.0 * lq2) / np.log(2.0)         # log2(4 q1 / q2^2)
+            if -54.0 < r < -51.0:
+                return True
+    return False
+
+
+def assert_parity_states(got, want, thetas, p, q, rtol=1e-10, what="", arbiter=None, **kw):
+    """assert_parity for sampler states: entries whose FINITE PATTERN differs are excused when the state sits in the
+    zero-root band (in_zero_root_band) and the finite side agrees with the exact (quad-precision) value to rtol -- at most
+    0.5 % of the entries, each printed; everything else goes through assert_parity."""
+    got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
+    diff = np.flatnonzero(np.isfinite(got) != np.isfinite(want))
+    assert diff.size <= max(2, int(0.005 * got.size)), "%s: %d entries with a different finite pattern" % (what, diff.size)
+    keep = np.ones(got.size, dtype=bool)
+    for i in diff:
+        assert in_zero_root_band(thetas[i], p, q), "%s: finite pattern differs at %d outside the zero-root band" % (what, i)
+        v = got[i] if np.isfinite(got[i]) else want[i]
+        truth = arbiter(int(i))
+        assert abs(v - truth) <= rtol * abs(truth), (what, i, v, truth)
+        print("%s: entry %d sits in the zero-root band (device %r, oracle %r, exact %r): excused" % (what, i, got[i], want[i], truth))
+        keep[i] = False
+    idx = np.flatnonzero(keep)
+    return assert_parity(got[keep], want[keep], rtol, what, arbiter=(lambda k: arbiter(int(idx[k]))) if arbiter else None, **kw)
+
+
 def queue_get(q, procs, timeout=600.0):
     """q.get() that notices a dead worker at once instead of after the whole time-out."""
     import queue

@@ -60,9 +60,11 @@ def test_config2_full_pt_mcmc(cpa, golden_dir):
     print("config 2: %d iterations x %d chains in %.2f s = %.0f it/s" % (nb + ns, T * R, dt, (nb + ns) / dt))
     m = orc.OracleModel(t, y, yerr, 5, 3, max_stdev=ms)
     sub = samples[:, ::2503].reshape(-1, 11)                           # 64 x 20 samples
-    from helpers import loglik_truth
-    assert_parity(lp[:, ::2503].reshape(-1), m.logdensity_batch(sub, nthreads=os.cpu_count() or 8), 1e-10, "stored logpost",
-                  arbiter=lambda i: loglik_truth(t, y, yerr, sub[i], 5, 3)[0])
+    from helpers import assert_parity_states, loglik_truth
+    # (the MA parameters of this fit are unidentified and drift to extremes: about one state in 1500 sits where the
+    # reference's smaller MA root is exactly zero or not by the last bit of exp() -- helpers.in_zero_root_band)
+    assert_parity_states(lp[:, ::2503].reshape(-1), m.logdensity_batch(sub, nthreads=os.cpu_count() or 8), sub, 5, 3, 1e-10,
+                         "stored logpost", arbiter=lambda i: loglik_truth(t, y, yerr, sub[i], 5, 3)[0])
     truth = g["theta"][0]
     pooled = samples[:, ::5].reshape(-1, 11)
     zs = {"log sigma_y": (np.log(pooled[:, 0]).mean() - np.log(truth[0])) / np.log(pooled[:, 0]).std(),

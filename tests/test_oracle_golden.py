@@ -366,3 +366,29 @@ def test_distance_of_the_oracle_from_the_reference_on_ill_conditioned_models(gol
             worst = (d_or, float(g["cond"][i]))
     assert n_above >= 20
     print("worst oracle-reference distance %.1e at cond %.1e" % worst)
+
+
+def test_zero_root_band_states(golden_dir):
+    """Two states the GPU sampler stored in the configs[2] run (round 3) on which the REFERENCE's arithmetic gives NaN by a
+    rounding accident: an MA quadratic factor with two real roots and 4 q1 / q2^2 = 2^-52.25 / 2^-52.07, where the
+    reference's smaller root -(q2 - sqrt(q2^2 - 4 q1)) / 2 comes out as exactly zero and its MA polynomial divides by it
+    (carpack.cpp:522-580).  The exact value of the formulas is finite (quad precision), the device reproduced it to 1e-15
+    -- with the last bit of exp() the coin can land either way, which is what helpers.in_zero_root_band excuses."""
+    from helpers import in_zero_root_band
+    g = _load(golden_dir, "carma53_readme.npz")
+    t, y, e = g["t"], g["y"], g["yerr"]
+    ms = 10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)
+    m = orc.OracleModel(t, y, e, 5, 3, max_stdev=ms)
+    states = [
+        ([2.3521415749979684, 1.1353751202125038, 16.346713997289932, -2.6070758477523803, -3.4086607253064884, -3.7678557418618164,
+          1.01437543843715, -3.4723410470074025, 23.141959232799465, 30.37101444163148, 108.3259598958267], -117.74892595616718),
+        ([1.729609217076725, 1.548875058116524, 16.159812169772717, -2.6234816883436123, -2.798166309693116, -7.57636705521334,
+          -2.833068476446049, 0.6623614004138593, -3.4957159671186826, 16.992497163911835, 231.87726605878635], -122.07286251511061),
+    ]
+    for th, device_value in states:
+        th = np.array(th)
+        assert in_zero_root_band(th, 5, 3) and m.check_prior_bounds(th)
+        assert np.isnan(m.logdensity(th))                                  # the reference's own NaN
+        truth = orc.truth_logdensity(t, y, e, th, 5, 3)[0]
+        assert np.isfinite(truth) and abs(device_value - truth) <= 1e-13 * abs(truth)
+    assert not in_zero_root_band(g["theta"][0], 5, 3)
