@@ -135,6 +135,7 @@ def _load():
     L.carma_pt_sample_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, _dp, _dp]
     L.carma_pt_boundary_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.carma_pt_boundary_check.argtypes = [C.c_void_p]
+    L.carma_pt_kernel_in_use.argtypes = [C.c_void_p]
     L.carma_pt_sweep.argtypes = [C.c_void_p]
     return L
 
@@ -151,7 +152,7 @@ EXPORTS = [
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_sample_sharded", "carma_pt_boundary_stats",
-    "carma_pt_boundary_check", "carma_pt_sweep",
+    "carma_pt_boundary_check", "carma_pt_sweep", "carma_pt_kernel_in_use",
 ]
 
 
@@ -336,6 +337,10 @@ class Context:
         acc, swp = np.empty((R, T)), np.empty((R, T))
         check(lib.carma_pt_stats(self._h, ptr(acc), ptr(swp), int(bool(reset))), "carma_pt_stats")
         return acc, swp
+
+    def pt_kernel(self):
+        """"row" (k_pt_row) or "ladder" (k_pt): the sampler kernel this context is on (carma_pt_kernel_in_use)."""
+        return "row" if lib.carma_pt_kernel_in_use(self._h) == 1 else "ladder"
 
     def pt_iterations_done(self):
         return lib.carma_pt_iterations_done(self._h)

@@ -567,6 +567,12 @@ int carma_pt_stats(carma_ctx* h, double* accept_rate, double* swap_rate, int res
     return CARMA_OK;
 }
 
+int carma_pt_kernel_in_use(const carma_ctx* h)
+{
+    if (!h || !reinterpret_cast<const Ctx*>(h)->pt) return CARMA_EINVAL;
+    return reinterpret_cast<const Ctx*>(h)->pt->use_row ? 1 : 0;
+}
+
 long carma_pt_iterations_done(const carma_ctx* h)
 {
     if (!h || !reinterpret_cast<const Ctx*>(h)->pt) return CARMA_EINVAL;

@@ -200,6 +200,10 @@ int carma_pt_sample(carma_ctx* h, int nsamples, int thin, double* samples, doubl
 /* acceptance rate per chain [R][T]; swap_rate[r][i] = accepted swaps between temperatures i and i-1 */
 int carma_pt_stats(carma_ctx* h, double* accept_rate, double* swap_rate, int reset);
 long carma_pt_iterations_done(const carma_ctx* h);
+/* which sampler kernel the context is on: 1 = k_pt_row (one chain per DPP row, ladders spread over workgroups), 0 = k_pt
+ * (one workgroup per ladder).  A context created on k_pt_row drops to k_pt -- silently, the results are the same chains --
+ * when a cooperative launch is refused or a cross-workgroup exchange times out; tests assert that it did not. */
+int carma_pt_kernel_in_use(const carma_ctx* h);
 
 /*
  * ONE temperature ladder sharded across the GPUs of a node (one process per GPU): the reference has no counterpart --

@@ -76,11 +76,37 @@ def in_zero_root_band(theta, p, q):
     return False
 
 
-def assert_parity_states(got, want, thetas, p, q, rtol=1e-10, what="", arbiter=None, **kw):
+def in_overflow_region(theta, p, q):
+    """True when the reference's MA coefficients (carpack.cpp:522-580: the polynomial of the MA roots divided by its
+    constant term, i.e. by the product of the roots) exceed 1e150.  CARp::Variance (carpack.cpp:377-409) multiplies two sums
+    of them: the products leave the double range, the variance comes out +-inf or NaN depending on the signs of the
+    infinities, sigma^2 = ysigma^2 / variance is 0 or NaN, and the log-density the reference returns is an artefact --
+    finite values up to 20x away from the exact (quad-precision) one, measured by tools/debug/overflow_probe.py, or NaN.
+    The device (which never forms the coefficients: beta(omega_r) = prod (mu_k - omega_r) / mu_k) overflows in the same
+    region, to other artefacts.  There is nothing to be identical with: such states are left out of a comparison, counted.
+    The MA parameters are unbounded and the likelihood is flat in that direction, so the hottest chains of a long run drift
+    there (tools/soak_pt_row.py: 1-2 of 600 states after 1e5 iterations)."""
+    if q == 0:
+        return False
+    import oracle as orc
+    with np.errstate(all="ignore"):
+        ma = np.abs(orc.ma_coefs(np.asarray(theta, dtype=float), p, q))
+    return bool(np.all(np.isfinite(ma)) and ma.max() > 1e150)
+
+
+def assert_parity_states(got, want, thetas, p, q, rtol=1e-10, what="", arbiter=None, max_overflow_frac=0.01, **kw):
     """assert_parity for sampler states: entries whose FINITE PATTERN differs are excused when the state sits in the
     zero-root band (in_zero_root_band) and the finite side agrees with the exact (quad-precision) value to rtol -- at most
-    0.5 % of the entries, each printed; everything else goes through assert_parity."""
+    0.5 % of the entries, each printed; states in the overflow region (in_overflow_region; at most max_overflow_frac) are left out;
+    everything else goes through assert_parity."""
     got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
+    over = np.array([in_overflow_region(th, p, q) for th in thetas], dtype=bool)
+    if over.any():
+        assert over.sum() <= max(2, int(max_overflow_frac * got.size)), "%s: %d of %d states in the overflow region" % (what, over.sum(), got.size)
+        print("%s: %d of %d states sit in the overflow region of the reference's MA coefficients: left out" % (what, over.sum(), got.size))
+        keep = np.flatnonzero(~over)
+        return assert_parity_states(got[keep], want[keep], np.asarray(thetas)[keep], p, q, rtol, what,
+                                    arbiter=(lambda k: arbiter(int(keep[k]))) if arbiter else None, **kw)
     diff = np.flatnonzero(np.isfinite(got) != np.isfinite(want))
     assert diff.size <= max(2, int(0.005 * got.size)), "%s: %d entries with a different finite pattern" % (what, diff.size)
     keep = np.ones(got.size, dtype=bool)

@@ -57,6 +57,7 @@ def test_config2_full_pt_mcmc(cpa, golden_dir):
     samples, lp = ctx.pt_run(T, R, ns, nb, 1, seed=2024)
     dt = time.perf_counter() - t0
     assert samples.shape == (R, ns, 11) and ctx.pt_iterations_done() == nb + ns and np.all(np.isfinite(lp))
+    assert ctx.pt_kernel() == "row"                          # 75 000 exchanges across workgroups, none timed out
     print("config 2: %d iterations x %d chains in %.2f s = %.0f it/s" % (nb + ns, T * R, dt, (nb + ns) / dt))
     m = orc.OracleModel(t, y, yerr, 5, 3, max_stdev=ms)
     sub = samples[:, ::2503].reshape(-1, 11)                           # 64 x 20 samples

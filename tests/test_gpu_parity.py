@@ -585,6 +585,45 @@ def test_sampler_states_with_extreme_ma_parameters(cpa, readme):
         assert np.max(np.abs(got[:5] - tr) / np.abs(tr)) < 1e-12      # and in fact exact to rounding
 
 
+@pytest.mark.parametrize("p,q", [(2, 1), (4, 2), (5, 3), (6, 5), (7, 6)])
+def test_up_to_the_overflow_of_the_ma_coefficients(cpa, p, q):
+    """MA roots swept down to 1e-200 in product, i.e. MA coefficients (the reference divides the MA polynomial by the product
+    of its roots, carpack.cpp:522-580) up to 1e200.  Below 1e150 -- everything short of the region where CARp::Variance's
+    products of two coefficient sums leave the double range (helpers.in_overflow_region) -- the kernels must follow the
+    oracle like anywhere else: same finite pattern (zero-root band aside), values to 1e-10 or arbitrated.  Inside the region
+    the reference returns artefacts (sigma^2 = ysigma^2 / inf = 0, or NaN): printed, not compared.  Two launch shapes."""
+    from helpers import assert_parity_states, in_overflow_region, irregular_series, loglik_truth, prior_like_theta
+    rng = np.random.default_rng(500 + p)
+    t, y, yerr = irregular_series(150, seed=p)
+    ctx = cpa.Context(t, y, yerr, p, q)
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    B = 1024
+    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(B)])
+    for b in range(B):
+        tot = rng.uniform(-460.0, -120.0)                # log of the product of the MA roots
+        if q >= 2:
+            w = rng.dirichlet(np.ones(q // 2))
+            for i in range(q // 2):
+                th[b, 3 + p + 2 * i] = tot * w[i]
+                # complex pairs (q2^2 < 4 q1) mostly; real pairs whose smaller root the reference still resolves otherwise
+                th[b, 3 + p + 2 * i + 1] = 0.5 * tot * w[i] + (rng.uniform(-4.0, 0.6) if rng.random() < 0.7 else rng.uniform(0.7, 12.0))
+            if q % 2:
+                th[b, 3 + p + q - 1] = rng.uniform(-3.0, 1.0)
+        else:
+            th[b, 3 + p] = tot
+    over = np.array([in_overflow_region(x, p, q) for x in th])
+    assert 0.1 * B < over.sum() < 0.6 * B                # the sweep straddles the boundary
+    want = m.logdensity_batch(th, nthreads=8)
+    inside = th[~over]
+    for reps in (1, 40):
+        got = ctx.logdensity(np.tile(th, (reps, 1)))[:B]
+        assert_parity_states(got[~over], want[~over], inside, p, q, RTOL, "%s below the overflow region" % ctx.kernel_name(reps * B),
+                             arbiter=lambda i: loglik_truth(t, y, yerr, inside[i], p, q)[0], max_arb_frac=0.1)
+        fo, fd = np.isfinite(want[over]), np.isfinite(got[over])
+        print("%s: %d states in the overflow region: oracle finite %d, device finite %d, both %d" % (
+            ctx.kernel_name(reps * B), over.sum(), fo.sum(), fd.sum(), (fo & fd).sum()))
+
+
 @pytest.mark.parametrize("p,q", [(2, 1), (5, 3), (7, 4)])
 def test_regular_cadence_series(cpa, p, q):
     """A regularly sampled series (constant dt, two gaps, a stretch of alternating steps): the throughput kernels run

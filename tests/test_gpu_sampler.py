@@ -154,6 +154,7 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
         smp, slp = ctx.pt_sample(40, thin=2)
         th, lp = ctx.pt_get_chains()
         acc, swp = ctx.pt_stats()
+        assert ctx.pt_kernel() == kern                       # (no silent fall-back: refused cooperative launch, timed-out exchange)
         res[kern] = (th, lp, smp, slp, acc, swp)
     a, b = res["ladder"], res["row"]
     np.testing.assert_allclose(b[0], a[0], rtol=1e-6, atol=1e-9)

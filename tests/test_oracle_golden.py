@@ -392,3 +392,35 @@ def test_zero_root_band_states(golden_dir):
         truth = orc.truth_logdensity(t, y, e, th, 5, 3)[0]
         assert np.isfinite(truth) and abs(device_value - truth) <= 1e-13 * abs(truth)
     assert not in_zero_root_band(g["theta"][0], 5, 3)
+
+
+def test_overflow_region_states():
+    """Two states the row sampler's hottest chains reached after 1e5 iterations (tools/soak_pt_row.py, round 3): MA roots of
+    1e-80, i.e. MA coefficients of 1e232 / 1e212.  The reference's variance sum overflows (carpack.cpp:377-409: inf - inf),
+    its log-density is NaN; the exact value of the formulas is finite; the device, whose products overflow to a signed
+    infinity instead, returned the finite artefacts below.  helpers.in_overflow_region marks such states; a state with MA
+    coefficients of 1e140 is not one of them and the oracle is still accurate there."""
+    from helpers import in_overflow_region, irregular_series
+    cases = [
+        (5, 3, 150, [17.22824544342013, 1.2745485191040822, 30.631556629773975, 3.3215189525138253, 0.04152298407997157, -2.1710738002768433,
+                     -3.0652113134025343, -3.1860764607521013, -431.8271481828337, -227.4478231315038, -102.69653144548043], -500.49841724813194),
+        (6, 5, 180, [9.287673296489519, 0.9496851981974919, 14.052320089691424, 2.836598980825528, -0.9118708180562727, -2.173393918906031,
+                     -0.39659888619471284, -2.5189781815345054, 0.4605053478983999, -388.83945708097895, -451.6081396505746, -99.91149364880701,
+                     -221.60789424027953, 48.86365195573411], -438.4889889274666),
+    ]
+    for p, q, n, th, device_value in cases:
+        t, y, e = irregular_series(n, seed=11 * p + q)
+        th = np.array(th)
+        m = orc.OracleModel(t, y, e, p, q, max_stdev=10.0 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2))
+        assert in_overflow_region(th, p, q)
+        assert np.max(np.abs(orc.ma_coefs(th, p, q))) > 1e200
+        assert np.isnan(m.logdensity(th, ignore_prior=True))
+        truth = orc.truth_logdensity(t, y, e, th, p, q)[0]
+        assert np.isfinite(truth) and abs(device_value - truth) > 1e-4 * abs(truth)
+    # 1e140: large, yet the arithmetic holds
+    t, y, e = irregular_series(150, seed=58)
+    th = np.array([17.2, 1.27, 30.6, 3.32, 0.0415, -2.17, -3.07, -3.19, -322.0, -150.0, -1.0])
+    assert 1e135 < np.max(np.abs(orc.ma_coefs(th, 5, 3))) < 1e150 and not in_overflow_region(th, 5, 3)
+    m = orc.OracleModel(t, y, e, 5, 3, max_stdev=1e3)
+    got, truth = m.logdensity(th, ignore_prior=True), orc.truth_logdensity(t, y, e, th, 5, 3)[0]
+    assert np.isfinite(got) and abs(got - truth) <= 1e-6 * abs(truth), (got, truth)
