@@ -105,35 +105,10 @@ def main():
     # launches of 30 us, far too short for a GPU that has just been woken up to reach the clocks it holds under this
     # load (round 2: 33.1 us per step in such a run against 29.7 us in a 2000-step run).  The legs are the same work a
     # user of the library would have had the device do; the headline region itself is unchanged.
-    # ---- secondary metric: MCMC iterations/s, BASELINE configs[2] shape ------------------------
-    # 16 temperatures x 64 independent ladders ("walkers") per GPU, persistent PT kernel; one
-    # iteration = every chain does one RAM step (one Kalman eval) + one exchange sweep.
-    mcmc = None
-    if not args.no_mcmc:
-        T_, R_ = 16, 64
-        ctx.pt_create(T_, R_, adapt_iters=10 ** 9, seed=11 + rank)
-        ctx.pt_shard(T_, 0, rank * R_)
-        ctx.pt_start(None)
-        ctx.pt_iterate(100)
-        barrier()
-        tm0 = time.perf_counter()
-        ctx.pt_iterate(args.mcmc_iters)
-        barrier()
-        tm = time.perf_counter() - tm0
-        if dist is not None:
-            tt = torch.tensor([tm], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tm = float(tt.item())
-        acc_, swp_ = ctx.pt_stats()
-        mcmc = {
-            "metric": "MCMC iterations/s (each iteration advances every chain once)",
-            "iters_per_s": args.mcmc_iters / tm,
-            "chain_evals_per_s": world * T_ * R_ * args.mcmc_iters / tm,
-            "temperatures": T_, "replicas_per_gpu": R_, "iters": args.mcmc_iters,
-            "accept_rate": float(acc_.mean()), "swap_rate": float(swp_[:, 1:].mean()),
-            "config": "configs[2] shape: CARMA(5,3), n=270, 16 temperatures x 64 walkers per GPU, RAM adapting",
-        }
-
+    # The sampler leg goes LAST, right in front of the warm-up: it is the same kind of load as the headline kernel (one
+    # four-wave workgroup per CU), 60 ms of it, whereas the throughput leg fills every SIMD with FP64 work and leaves the
+    # clocks where that load's power allows -- a kernel trace of a 20-step run (tools/trace_short_bench.sh) showed the
+    # headline launches at 31.0 us right behind it, drifting down by 0.01 us per launch.
     # ---- the same steps with TWO batches in flight (two streams, alternating): what a caller with independent batches
     # should do -- the second launch fills the half of every CU's issue slots that one four-wave workgroup leaves idle.
     # Extra key; the headline `value` above is one batch at a time on one stream.
@@ -195,6 +170,35 @@ def main():
                           "note": "algorithmic flop count of the reference's COMPLEX recursion (SURVEY.md 8d): the kernels work in real "
                                   "modal coordinates on the symmetric half of the matrix, about a third of those flops -- a fraction "
                                   "above 1 is this count's artefact, not a measurement error"},
+        }
+
+    # ---- secondary metric: MCMC iterations/s, BASELINE configs[2] shape ------------------------
+    # 16 temperatures x 64 independent ladders ("walkers") per GPU, persistent PT kernel; one
+    # iteration = every chain does one RAM step (one Kalman eval) + one exchange sweep.
+    mcmc = None
+    if not args.no_mcmc:
+        T_, R_ = 16, 64
+        ctx.pt_create(T_, R_, adapt_iters=10 ** 9, seed=11 + rank)
+        ctx.pt_shard(T_, 0, rank * R_)
+        ctx.pt_start(None)
+        ctx.pt_iterate(100)
+        barrier()
+        tm0 = time.perf_counter()
+        ctx.pt_iterate(args.mcmc_iters)
+        barrier()
+        tm = time.perf_counter() - tm0
+        if dist is not None:
+            tt = torch.tensor([tm], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tm = float(tt.item())
+        acc_, swp_ = ctx.pt_stats()
+        mcmc = {
+            "metric": "MCMC iterations/s (each iteration advances every chain once)",
+            "iters_per_s": args.mcmc_iters / tm,
+            "chain_evals_per_s": world * T_ * R_ * args.mcmc_iters / tm,
+            "temperatures": T_, "replicas_per_gpu": R_, "iters": args.mcmc_iters,
+            "accept_rate": float(acc_.mean()), "swap_rate": float(swp_[:, 1:].mean()),
+            "config": "configs[2] shape: CARMA(5,3), n=270, 16 temperatures x 64 walkers per GPU, RAM adapting",
         }
 
     for i in range(args.warmup):

@@ -9,6 +9,8 @@ import carma_pack_amd as cpa
 from carma_pack_amd.synth import theta_batch
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/carma53_readme.npz'))
 t, y, yerr = g['t'], g['y'], g['yerr']
+if os.environ.get('LANE_PROBE_REGULAR'):      # constant cadence: the transition factors are evaluated once
+    t = np.floor(t[0]) + 2.0 * np.arange(len(t))      # (exact differences: every step repeats)
 P, Q = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5, 3)
 ctx = cpa.Context(t, y, yerr, P, Q, max_stdev=10*np.sqrt(np.mean(y*y)-np.mean(y)**2))
 base = theta_batch(np.random.default_rng(2), 4096, P, Q, t, y, theta_center=g['theta'][0] if (P, Q) == (5, 3) else None)
