@@ -169,6 +169,35 @@ __global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restr
     if (live) out[e] = ll;
 }
 
+// One evaluation per lane with the transition factors from PRODUCER WAVES (carma_lane.h, LaneFactorsRing): workgroups of
+// four waves -- two consumers with a producer each (NP = 1, 128 evaluations), or one consumer with three producers
+// (NP = 3, 64 evaluations).  For launches in which a lone wave's instruction stream would be the run time.
+// Which wave plays which part rotates with the round of workgroups (blockIdx against the CU count): the waves of the
+// workgroups that share a CU land on its SIMDs in a fixed pattern (tools/ubench/wave_placement.hip), and two consumers
+// on one SIMD would wait for each other.
+template <int P, int NP>
+__global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restrict__ theta, int B, int d, int q,
+                                                           const double4* __restrict__ series, int n, Prior pr,
+                                                           int ignore_prior, double* __restrict__ out, int ncu, int rot)
+{
+    using Geo = LaneRingGeom<P, NP>;
+    extern __shared__ double lpc_ring[];
+    const int lane = threadIdx.x & 63;
+    const int round = (int)(blockIdx.x / (unsigned)ncu);
+    const int part = ((int)(threadIdx.x >> 6) + ((rot >> (4 * (round & 3))) & 3)) & 3;      // 0 .. NC-1: consumers
+    const int cons = part < Geo::NC ? part : (part - Geo::NC) / NP;
+    long e = ((long)blockIdx.x * Geo::NC + cons) * 64 + lane;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    double* ring = lpc_ring + cons * Geo::DOUBLES + lane;
+    if (part >= Geo::NC) {
+        lane_produce<P, NP>((part - Geo::NC) % NP, theta + e * d, ring, series, n);
+        return;
+    }
+    const double ll = logdensity_lane_ring<P, NP>(theta + e * d, q, series, n, pr, ignore_prior, ring);
+    if (live) out[e] = ll;
+}
+
 __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ theta, int B,
                                                      const double4* __restrict__ series, int n, Prior pr,
                                                      double* __restrict__ out)
@@ -293,7 +322,7 @@ static long p3l_max_rows()
 }
 
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
-enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE };
+enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC };
 // smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
 static long lane_min_evals()
 {
@@ -303,6 +332,46 @@ static long lane_min_evals()
     }();
     return tune >= 0 ? tune : 64L * 4 * device_cus() * 3 / 8;  // 3/8 of a wave per SIMD (24 576 on 256 CUs): 206 vs 212-236 us there
 }
+// Launches (lpc_min, lpc_max] take the lane kernel with producer waves, k_logdens_carma_lpc<P,3> (measured per order:
+// tools/lpc_probe.sh, profiles/r03/lpc_orders_v1.txt).  Below, the lane-group kernels still have at most one wave per SIMD
+// and are faster; above -- more than three workgroups per CU, or more than the registers allow (two at p = 5, 6, one at
+// p = 7) -- the SIMDs are full either way and the plain lane kernel does the same work without the LDS traffic.
+// CARMA_TUNE_LPC_MIN / _MAX override (read once).
+static long lpc_tune(const char* name, long dflt)
+{
+    const char* e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+static int lpc_rot()
+{
+    static const long v = lpc_tune("CARMA_TUNE_LPC_ROT", 0x0202);
+    return (int)v;
+}
+template <int P>
+static long lpc_min_evals()
+{
+    static const long v = lpc_tune("CARMA_TUNE_LPC_MIN", -1);
+    if (v >= 0) return v;
+    constexpr long EPW = 64 / GroupOf<P>::value;
+    const long one_wave_per_simd = EPW * 4 * device_cus(), one_wg_per_cu = 64L * device_cus();
+    return one_wave_per_simd < one_wg_per_cu ? one_wave_per_simd : one_wg_per_cu;
+}
+template <int P>
+static long lpc_max_evals()
+{
+    static const long v = lpc_tune("CARMA_TUNE_LPC_MAX", -1);
+    if (v >= 0) return v;
+    static std::atomic<int> blocks{0};                        // workgroups of this kernel a CU holds (registers, LDS)
+    int nb = blocks.load(std::memory_order_relaxed);
+    if (nb <= 0) {
+        const void* kern = reinterpret_cast<const void*>(&k_logdens_carma_lpc<P, 3>);
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneRingGeom<P, 3>::BYTES) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, LaneRingGeom<P, 3>::BYTES) != hipSuccess || nb <= 0)
+            nb = 1;
+        blocks.store(nb, std::memory_order_relaxed);
+    }
+    return 64L * (nb < 3 ? nb : 3) * device_cus();
+}
 template <int P>
 static LdShape logdens_shape(long B, int n)
 {
@@ -310,6 +379,7 @@ static LdShape logdens_shape(long B, int n)
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
+    if (B > lpc_min_evals<P>() && B <= lpc_max_evals<P>() && n >= 8) return LdShape::LPC;
     if (B >= lane_min_evals()) return LdShape::LANE;
     // few evaluations in flight: one wave's instruction stream is the run time, so split it (consumer + rho producer,
     // carma_ring.h).  Beyond 512 waves (two rounds of workgroups) the plain kernel with pair-shared exp/sincos is
@@ -360,6 +430,15 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             hipLaunchKernelGGL((k_logdens_carma_lane<P>), dim3((unsigned)(((long)B + 63) / 64)), dim3(64), 0, st, theta, B, d, q, series,
                                n, pr, ignore_prior, out);
             return hipGetLastError();
+        case LdShape::LPC: {
+            using Geo = LaneRingGeom<P, 3>;
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_lpc<P, 3>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::BYTES);
+            if (ea != hipSuccess) return ea;
+            hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta, B, d, q,
+                               series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
+            return hipGetLastError();
+        }
         case LdShape::PLAIN4:
             if (repeated_dt)
                 hipLaunchKernelGGL((k_logdens_carma<P, G, 4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, theta, B,
@@ -384,6 +463,7 @@ static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
         case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1%s>", P, G, dtc);
         case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4%s>", P, G, dtc);
         case LdShape::LANE: return snprintf(buf, len, "k_logdens_carma_lane<%d>", P);
+        case LdShape::LPC: return snprintf(buf, len, "k_logdens_carma_lpc<%d,3>", P);
     }
     return -1;
 }

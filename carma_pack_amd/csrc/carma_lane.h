@@ -145,9 +145,127 @@ CARMA_DEV bool lane_any(bool b)
 #endif
 }
 
-// Reset + n - 1 Updates -> log-likelihood sum (no prior)
+// Transition factors of one step, per coordinate: one exp/sincos per PAIR (the members are conjugates), one exp per real root
 template <int P>
-CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ series, int n)
+CARMA_DEV void lane_factors(const double (&wre)[P], const double (&wim)[P], const bool (&realpair)[(P + 1) / 2], bool anyreal,
+                            double dt, double (&cr)[P], double (&sr)[P])
+{
+#pragma unroll
+    for (int i = 0; i < P / 2; i++) {
+        double c, s;
+        cexp_step(wre[2 * i], wim[2 * i], dt, &c, &s);
+        cr[2 * i] = c;
+        sr[2 * i] = s;
+        cr[2 * i + 1] = c;
+        sr[2 * i + 1] = -s;
+    }
+    if (anyreal) {
+        // a quadratic factor with two real roots: the second member has its own modulus (and no phase: s = 0)
+#pragma unroll
+        for (int i = 0; i < P / 2; i++) {
+            const double e1 = exp_neg(wre[2 * i + 1] * dt);
+            if (realpair[i]) cr[2 * i + 1] = e1;
+        }
+    }
+    if (P & 1) cr[P - 1] = exp_neg(wre[P - 1] * dt);
+}
+
+// Where lane_filter takes a NEW time step's factors from.  LaneFactorsInline: the lane computes them itself.
+template <int P>
+struct LaneFactorsInline {
+    const LaneModel<P>& m;
+    bool anyreal;
+    CARMA_DEV void step(int) const {}
+    CARMA_DEV void get(int, double dt, double (&cr)[P], double (&sr)[P]) const
+    {
+        lane_factors<P>(m.wre, m.wim, m.realpair, anyreal, dt, cr, sr);
+    }
+};
+
+#if defined(__HIPCC__)
+// LaneFactorsRing: PRODUCER WAVES compute them (lane_produce: lane l of a producer serves lane l of its consumer) into a
+// two-buffer LDS ring, CH steps per buffer, one workgroup barrier per CH steps; with NP producers per consumer, producer k
+// takes the steps s = k (mod NP) of a buffer.  The factors do not depend on the state of the recursion, so the split takes
+// the ~220 exp/sincos instructions of a step (p = 5) out of the ~410 of a lone wave's instruction stream -- which IS the run
+// time while there is at most one wave per SIMD.  NP = 1: the producer is the longer of the two (224 vs 197 instructions);
+// NP = 3: the consumer is all that is left.  A step that repeats its predecessor's time step is skipped by both sides
+// (the test is wave-uniform).
+template <int P, int NP>
+struct LaneRingGeom {
+    static constexpr int CH = NP == 1 ? 4 : 2 * NP;
+    static constexpr int NC = 4 / (1 + NP);                   // consumers per workgroup of four waves
+    static constexpr int NV = P + P / 2;                      // c per coordinate, s per pair
+    static constexpr size_t DOUBLES = (size_t)2 * CH * NV * 64;                    // per consumer
+    static constexpr size_t BYTES = NC * DOUBLES * sizeof(double);                 // p = 5: 56 KiB (NP = 1), 42 KiB (NP = 3)
+};
+template <int P, int NP>
+struct LaneFactorsRing {
+    using Geo = LaneRingGeom<P, NP>;
+    const double* ring;                                       // [2][CH][NV][64], + lane
+    CARMA_DEV void step(int kk) const
+    {
+        if ((kk - 1) % Geo::CH == 0) __syncthreads();          // barrier c: chunk c is in the ring
+    }
+    CARMA_DEV void get(int kk, double, double (&cr)[P], double (&sr)[P]) const
+    {
+        const int c = (kk - 1) / Geo::CH, s = (kk - 1) % Geo::CH;
+        const double* b = ring + (size_t)((c & 1) * Geo::CH + s) * Geo::NV * 64;
+#pragma unroll
+        for (int r = 0; r < P; r++) cr[r] = b[r * 64];
+#pragma unroll
+        for (int i = 0; i < P / 2; i++) {
+            const double sv = b[(P + i) * 64];
+            sr[2 * i] = sv;
+            sr[2 * i + 1] = -sv;
+        }
+    }
+};
+template <int P, int NP>
+__device__ __forceinline__ void lane_produce(int k, const double* theta, double* ring /* + lane */, const double4* __restrict__ series,
+                                             int n)
+{
+    using Geo = LaneRingGeom<P, NP>;
+    double wre[P], wim[P];
+    bool realpair[(P + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const Cx w = poly_root(theta + 3, P, j);
+        wre[j] = w.re;
+        wim[j] = w.im;
+    }
+    bool anyreal = false;
+#pragma unroll
+    for (int i = 0; i < (P + 1) / 2; i++) {
+        realpair[i] = (2 * i + 1 < P) && (wim[2 * i] == 0.0);
+        anyreal = anyreal || realpair[i];
+    }
+    anyreal = __builtin_amdgcn_ballot_w64(anyreal) != 0;
+    const int nc = (n - 1 + Geo::CH - 1) / Geo::CH;
+    for (int c = 0; c < nc; c++) {
+#pragma unroll 1
+        for (int s = k; s < Geo::CH; s += NP) {
+            const int kk = 1 + c * Geo::CH + s;
+            if (kk >= n) break;
+            const double dt = series[kk].x;
+            // as the consumer decides: new factors unless the step repeats its predecessor's time step
+            if (kk == 1 || dt != series[kk - 1].x) {
+                double cr[P], sr[P];
+                lane_factors<P>(wre, wim, realpair, anyreal, dt, cr, sr);
+                double* b = ring + (size_t)((c & 1) * Geo::CH + s) * Geo::NV * 64;
+#pragma unroll
+                for (int r = 0; r < P; r++) b[r * 64] = cr[r];
+#pragma unroll
+                for (int i = 0; i < P / 2; i++) b[(P + i) * 64] = sr[2 * i];
+            }
+        }
+        __syncthreads();                                      // barrier c
+    }
+}
+#endif
+
+// Reset + n - 1 Updates -> log-likelihood sum (no prior)
+template <int P, class Src>
+CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ series, int n, const Src& src)
 {
     constexpr int NT = P * (P + 1) / 2;
     constexpr int PE = P & ~1;                               // coordinates that belong to pairs
@@ -167,38 +285,17 @@ CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ 
         cr[r] = 1.0;
         sr[r] = 0.0;
     }
-    bool anyreal = false;
-#pragma unroll
-    for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
-    anyreal = lane_any(anyreal);
     LogLikAcc acc;
     acc.init();
     double4 rprev = series[0];
     double dt_prev = -1.0;                                   // (a time step is never negative)
     for (int kk = 1; kk < n; kk++) {
         const double4 rec = series[kk];
-        // --- transition factors of this step: one exp/sincos per PAIR (the members are conjugates), one exp per real
-        // root; a repeated time step (wave-uniform: the series is shared) re-uses them
+        // --- transition factors of this step; a repeated time step (wave-uniform: the series is shared) re-uses them
+        src.step(kk);
         if (rec.x != dt_prev) {
             dt_prev = rec.x;
-#pragma unroll
-            for (int i = 0; i < P / 2; i++) {
-                double c, s;
-                cexp_step(m.wre[2 * i], m.wim[2 * i], rec.x, &c, &s);
-                cr[2 * i] = c;
-                sr[2 * i] = s;
-                cr[2 * i + 1] = c;
-                sr[2 * i + 1] = -s;
-            }
-            if (anyreal) {
-                // a quadratic factor with two real roots: the second member has its own modulus (and no phase: s = 0)
-#pragma unroll
-                for (int i = 0; i < P / 2; i++) {
-                    const double e1 = exp_neg(m.wre[2 * i + 1] * rec.x);
-                    if (m.realpair[i]) cr[2 * i + 1] = e1;
-                }
-            }
-            if (P & 1) cr[P - 1] = exp_neg(m.wre[P - 1] * rec.x);
+            src.get(kk, rec.x, cr, sr);
         }
         // --- var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z   (kfilter.cpp:180-184, 207-213)
         double pv = 0.0, pm = 0.0;
@@ -288,10 +385,30 @@ CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __re
 {
     LaneModel<P> m;
     lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
-    double ll = lane_filter<P>(m, series, n);
+    bool anyreal = false;
+#pragma unroll
+    for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
+    const LaneFactorsInline<P> src{m, lane_any(anyreal)};
+    double ll = lane_filter<P>(m, series, n, src);
     ll += log_prior(m.scale, pr.measerr_dof);
     if (m.sing || !m.valid) ll = -1.0 / 0.0;
     return ll;
 }
+
+#if defined(__HIPCC__)
+// the same with the factors from the producer wave's ring (consumer side of k_logdens_carma_lpc)
+template <int P, int NP>
+__device__ __forceinline__ double logdensity_lane_ring(const double* theta, int q, const double4* __restrict__ series, int n,
+                                                       const Prior& pr, int ignore_prior, const double* ring /* + lane */)
+{
+    LaneModel<P> m;
+    lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
+    const LaneFactorsRing<P, NP> src{ring};
+    double ll = lane_filter<P>(m, series, n, src);
+    ll += log_prior(m.scale, pr.measerr_dof);
+    if (m.sing || !m.valid) ll = -1.0 / 0.0;
+    return ll;
+}
+#endif
 
 }  // namespace carma

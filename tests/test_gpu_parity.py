@@ -244,7 +244,9 @@ def test_launch_shapes_agree(cpa, p, q):
     G = 2 if p <= 2 else (4 if p <= 4 else 8)
     pc_small, pc_big = 3100, min(4000, 512 * (64 // G))            # beyond the pipeline, within 512 waves
     res = {}
-    shapes = [("p3", 48), ("p3b", 1000), ("p3c", 1100), ("p3d", 2000), ("p3e", 3072), ("plain", 70000)]
+    lpc = 12000 if p >= 5 else 20000                                # one evaluation per lane + producer waves (round 3)
+    assert ctx.kernel_name(lpc) == "k_logdens_carma_lpc<%d,3>" % p and ctx.kernel_name(70000) == "k_logdens_carma_lane<%d>" % p
+    shapes = [("p3", 48), ("p3b", 1000), ("p3c", 1100), ("p3d", 2000), ("p3e", 3072), ("plain", 70000), ("lpc", lpc)]
     if pc_big > pc_small:
         shapes += [("pc", pc_small), ("pc2", pc_big)]
     for name, B in shapes:
@@ -261,6 +263,8 @@ def test_launch_shapes_agree(cpa, p, q):
         assert np.array_equal(res["p3"], res[name], equal_nan=True), name
     if "pc" in res:
         assert np.array_equal(res["pc"], res["pc2"], equal_nan=True)
+    # the producer waves evaluate the very function the lane kernel evaluates in line: same bits
+    assert np.array_equal(res["lpc"], res["plain"], equal_nan=True)
 
 
 @pytest.mark.parametrize("p,q", [(2, 0), (5, 3), (7, 4)])
@@ -490,8 +494,10 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
     ctx = cpa.Context(t, y, yerr, p, q)
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     from helpers import loglik_truth
-    B = 20000                                                   # lane-group throughput kernel
-    assert ctx.kernel_name(B).startswith("k_logdens_carma<") and ctx.kernel_name(40000).startswith("k_logdens_carma_lane<")
+    B = 12000 if p <= 4 else 8000                               # lane-group throughput kernel
+    BL, BP = 60000, (20000 if p <= 4 else 12000)                # one evaluation per lane: in line / with producer waves
+    assert ctx.kernel_name(B).startswith("k_logdens_carma<") and ctx.kernel_name(BL).startswith("k_logdens_carma_lane<")
+    assert ctx.kernel_name(BP).startswith("k_logdens_carma_lpc<")
     res = {}
     for name, pool in (("complex", cplx), ("real", real), ("mixed", np.concatenate([cplx, real])[rng.permutation(64)])):
         want = m.logdensity_batch(pool, ignore_prior=True, nthreads=8)
@@ -501,12 +507,13 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
         assert_parity(got[:pool.shape[0]], want, RTOL, "%s p=%d q=%d" % (name, p, q),
                       arbiter=lambda i, pool=pool: loglik_truth(t, y, yerr, pool[i], p, q)[0])
         res[name] = dict(zip(map(bytes, pool), got[:pool.shape[0]]))
-        # one evaluation per lane (40 000 evaluations): the second exponential of a real pair is a wave-uniform branch there
-        big = np.tile(pool, (40000 // pool.shape[0] + 1, 1))[:40000]
-        gl = ctx.logdensity(big, ignore_prior=True)
-        assert np.array_equal(gl, np.tile(gl[:pool.shape[0]], 40000 // pool.shape[0] + 1)[:40000], equal_nan=True), name
-        assert_parity(gl[:pool.shape[0]], want, RTOL, "lane kernel, %s p=%d q=%d" % (name, p, q),
-                      arbiter=lambda i, pool=pool: loglik_truth(t, y, yerr, pool[i], p, q)[0])
+        # one evaluation per lane: the second exponential of a real pair is a wave-uniform branch there
+        for b2 in (BL, BP):
+            big = np.tile(pool, (b2 // pool.shape[0] + 1, 1))[:b2]
+            gl = ctx.logdensity(big, ignore_prior=True)
+            assert np.array_equal(gl, np.tile(gl[:pool.shape[0]], b2 // pool.shape[0] + 1)[:b2], equal_nan=True), name
+            assert_parity(gl[:pool.shape[0]], want, RTOL, "%s, %s p=%d q=%d" % (ctx.kernel_name(b2), name, p, q),
+                          arbiter=lambda i, pool=pool: loglik_truth(t, y, yerr, pool[i], p, q)[0])
     # the same theta in an all-complex wave (pair-shared factors) and in a mixed wave (one evaluation per lane)
     for key, v in res["complex"].items():
         w = res["mixed"][key]
@@ -624,7 +631,7 @@ def test_up_to_the_overflow_of_the_ma_coefficients(cpa, p, q):
             ctx.kernel_name(reps * B), over.sum(), fo.sum(), fd.sum(), (fo & fd).sum()))
 
 
-@pytest.mark.parametrize("p,q", [(2, 1), (5, 3), (7, 4)])
+@pytest.mark.parametrize("p,q", [(4, 1), (5, 3), (7, 4)])
 def test_regular_cadence_series(cpa, p, q):
     """A regularly sampled series (constant dt, two gaps, a stretch of alternating steps): the throughput kernels run
     the variant that re-uses the transition factors of steps whose dt repeats (carma_core.h, RhoInline / RhoPair DTC).
@@ -639,20 +646,23 @@ def test_regular_cadence_series(cpa, p, q):
     y = 5.0 + np.sin(t / 9.0) + 0.3 * rng.standard_normal(n)
     yerr = np.full(n, 0.3) * rng.uniform(0.8, 1.2, n)
     ctx = cpa.Context(t, y, yerr, p, q)
-    assert ctx.kernel_name(20000).endswith(",true>") and ctx.kernel_name(70016).startswith("k_logdens_carma_lane<")
+    BG = {4: 12000, 5: 8000, 7: 20000}[p]                          # what still takes the lane-group throughput kernels
+    BP = 20000 if p <= 4 else 12000                               # one evaluation per lane + producer waves
+    assert ctx.kernel_name(BG).endswith(",true>") and ctx.kernel_name(70016).startswith("k_logdens_carma_lane<")
+    assert ctx.kernel_name(BP).startswith("k_logdens_carma_lpc<")
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(32)])
     r1 = 10.0 ** rng.uniform(-2.0, -0.5, 8)
     th[:8, 3], th[:8, 4] = np.log(r1 * r1 * 7.0), np.log(r1 * 8.0)  # one quadratic factor with two real roots
     want = m.logdensity_batch(th, ignore_prior=True)
-    for B in (32, 3200, 9600, 20000, 70016):                      # (70 016: one evaluation per lane, which always re-uses)
+    for B in (32, 3200, BG, BP, 70016):                           # (the last two: one evaluation per lane, which always re-uses)
         got = ctx.logdensity(np.tile(th, (B // 32, 1)), ignore_prior=True)
         assert np.array_equal(got, np.tile(got[:32], B // 32), equal_nan=True), ctx.kernel_name(B)
         assert_parity(got[:32], want, RTOL, "regular cadence p=%d q=%d %s" % (p, q, ctx.kernel_name(B)),
                       arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
     # an irregular series keeps the plain variant
     ti = np.cumsum(rng.uniform(1.0, 3.0, n))
-    assert not cpa.Context(ti, y, yerr, p, q).kernel_name(20000).endswith(",true>")
+    assert not cpa.Context(ti, y, yerr, p, q).kernel_name(BG).endswith(",true>")
 
 
 @pytest.mark.parametrize("unit", [1e-60, 1e-7, 1e9, 1e45])
@@ -755,23 +765,25 @@ def test_ill_conditioned_models_against_the_reference_python(cpa, golden_dir):
 
 @pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
 def test_lane_kernel_prior_like_sweep(cpa, p):
-    """k_logdens_carma_lane<P> -- one evaluation per lane, what launches of 32 768 evaluations and more take (round 3) --
-    for every order (p, q < p): 160 prior-like parameter vectors, tiled to 33 000 evaluations, bounds on and off, against the
-    oracle with the usual bar (1e-10, or no further from the quad-precision value than the oracle); every copy of a
-    vector gives the same bits wherever it sits in the launch."""
+    """k_logdens_carma_lane<P> -- one evaluation per lane, what launches beyond 49 152 evaluations take (round 3) -- and
+    k_logdens_carma_lpc<P,3>, the same recursion with the transition factors from three producer waves (8 193 / 16 385 ...
+    16 384 / 32 768 / 49 152 evaluations, by order), for every order (p, q < p): 160 prior-like parameter vectors, tiled, bounds
+    on and off, against the oracle with the usual bar (1e-10, or no further from the quad-precision value than the oracle);
+    every copy of a vector gives the same bits wherever it sits in the launch, and the two kernels give the same bits."""
     from helpers import loglik_truth
     for q in range(p):
         t, y, yerr = irregular_series(150, seed=300 * p + q)
         rng = np.random.default_rng(9000 + 10 * p + q)
         th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(160)])
         ctx = cpa.Context(t, y, yerr, p, q)
-        B = 33000
-        assert ctx.kernel_name(B) == "k_logdens_carma_lane<%d>" % p
+        B, Bp = 50001, (12001 if p >= 5 else 20001)
+        assert ctx.kernel_name(B) == "k_logdens_carma_lane<%d>" % p and ctx.kernel_name(Bp) == "k_logdens_carma_lpc<%d,3>" % p
         m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
-        big = np.tile(th, (B // 160 + 1, 1))[:B]
         for ign in (False, True):
             want = m.logdensity_batch(th, ignore_prior=ign, nthreads=os.cpu_count() or 8)
-            got = ctx.logdensity(big, ignore_prior=ign)
+            got = ctx.logdensity(np.tile(th, (B // 160 + 1, 1))[:B], ignore_prior=ign)
             assert np.array_equal(got, np.tile(got[:160], B // 160 + 1)[:B], equal_nan=True)
             assert_parity(got[:160], want, RTOL, "lane kernel p=%d q=%d" % (p, q),
                           arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.04)
+            gotp = ctx.logdensity(np.tile(th, (Bp // 160 + 1, 1))[:Bp], ignore_prior=ign)
+            assert np.array_equal(gotp, np.tile(got[:160], Bp // 160 + 1)[:Bp], equal_nan=True), "producer waves p=%d q=%d" % (p, q)

@@ -18,8 +18,8 @@ import oracle as orc
 m = orc.OracleModel(t, y, yerr, P, Q, max_stdev=ctx.prior()[0])
 want = m.logdensity_batch(base[:512], nthreads=8)
 dev = torch.device('cuda'); st = torch.cuda.current_stream().cuda_stream
-print("CARMA_TUNE_LANE_MIN=%s  CARMA(%d,%d)" % (os.environ.get("CARMA_TUNE_LANE_MIN", "(default)"), P, Q))
-for B in (16384, 24576, 32768, 65536, 131072, 1048576):
+print("  ".join("%s=%s" % (k[11:], os.environ[k]) for k in sorted(os.environ) if k.startswith("CARMA_TUNE_")) or "(defaults)", " CARMA(%d,%d)" % (P, Q))
+for B in [int(x) for x in os.environ.get("LANE_PROBE_B", "16384,24576,32768,65536,131072,1048576").split(",")]:
     th = torch.from_numpy(np.tile(base, (B // 4096 + 1, 1))[:B].copy()).to(dev)
     out = torch.empty(B, dtype=torch.float64, device=dev)
     for _ in range(3): ctx.logdensity_dev(th.data_ptr(), B, out.data_ptr(), stream=st)
