@@ -269,8 +269,8 @@ def test_launch_shapes_agree(cpa, p, q):
 
 @pytest.mark.parametrize("p,q", [(2, 0), (5, 3), (7, 4)])
 def test_series_lengths_around_chunk_boundaries(cpa, p, q):
-    """The ring kernels work in 16-step chunks (one barrier each, buffers rotating): every series length
-    around the chunk boundaries, in every launch shape that uses a ring, against the oracle."""
+    """The ring kernels work in 16-step chunks (one barrier each, buffers rotating; six steps in the lane kernel with
+    producer waves): every series length around the chunk boundaries, in every launch shape, against the oracle."""
     rng = np.random.default_rng(900 + p)
     # (n % 16 in 11..15: the wave pipeline completes the last chunk with 5..1 neutral pad data, carma_types.h p3l_pad)
     for n in (2, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 26, 27, 28, 29, 30, 31, 32, 33, 34, 43, 47, 48, 49, 50, 65):
@@ -283,7 +283,9 @@ def test_series_lengths_around_chunk_boundaries(cpa, p, q):
         dup = np.array([np.min(np.abs(r[:, None] - r[None, :]) + np.eye(p)) == 0.0 for r in roots])
         from helpers import loglik_truth
         arb = lambda i: loglik_truth(t, y, yerr, th[i % 12], p, q)[0]   # noqa: E731
-        for B in (12, 1100, 3200):       # four-wave pipeline, one and two workgroups per CU / G-lane producer-consumer
+        # four-wave pipeline, one and two workgroups per CU / G-lane producer-consumer / one evaluation per lane with producer
+        # waves (a six-step ring: n - 1 around its multiples too) and without
+        for B in (12, 1100, 3200, 12001 if p >= 5 else 20001, 50001):
             big = np.tile(th, (B // 12 + 1, 1))[:B]
             got = ctx.logdensity(big, ignore_prior=True)
             assert np.array_equal(got, np.tile(got[:12], B // 12 + 1)[:B], equal_nan=True), (n, B)
