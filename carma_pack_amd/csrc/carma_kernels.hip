@@ -365,8 +365,7 @@ static long lpc_max_evals()
     int nb = blocks.load(std::memory_order_relaxed);
     if (nb <= 0) {
         const void* kern = reinterpret_cast<const void*>(&k_logdens_carma_lpc<P, 3>);
-        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneRingGeom<P, 3>::BYTES) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, LaneRingGeom<P, 3>::BYTES) != hipSuccess || nb <= 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, LaneRingGeom<P, 3>::BYTES) != hipSuccess || nb <= 0)
             nb = 1;
         blocks.store(nb, std::memory_order_relaxed);
     }
@@ -432,9 +431,7 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             return hipGetLastError();
         case LdShape::LPC: {
             using Geo = LaneRingGeom<P, 3>;
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_lpc<P, 3>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::BYTES);
-            if (ea != hipSuccess) return ea;
+            static_assert(Geo::BYTES <= 64 * 1024, "within the LDS a launch may ask for without raising the kernel's limit");
             hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta, B, d, q,
                                series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
             return hipGetLastError();
