@@ -433,7 +433,9 @@ def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):
     ctx4 = cpa.Context(t4, y4, e4, 7, 6, device=dev_index)
     sh4 = par.LadderShard(ctx4, TG, R4, adapt_iters=10 ** 9, seed=SEED4, dist=dist if world > 1 else None, device="cpu")
     comm = None
-    if world > 1 and not share:      # (two ranks sharing one GPU: RCCL refuses; the torch.distributed stand-in runs)
+    # (ranks sharing one GPU -- the test hook: RCCL refuses, the torch.distributed stand-in runs; unless CARMA_RCCL_LIB names
+    # another transport for the library's native path, tests/shm_transport)
+    if world > 1 and (not share or os.environ.get("CARMA_RCCL_LIB")):
         comm = _lib.Comm.from_torch(dist, device=dev_index)
         sh4.attach_comm(comm)
     sh4.start()

@@ -34,6 +34,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -63,10 +64,17 @@ static Rccl* rccl()
     static Rccl api;
     static std::once_flag once;                              // (choose_order drives library calls from a thread pool)
     std::call_once(once, [] {
+        // CARMA_RCCL_LIB: bind THIS library instead (tests/shm_transport: a shared-memory test double of the eight entry
+        // points, with which a one-GPU box runs the nranks > 1 paths below -- RCCL refuses two ranks on one device)
+        const char* override_path = getenv("CARMA_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "librccl.so"};
-        for (const char* nm : names) {
-            api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-            if (api.lib) break;
+        if (override_path && *override_path) {
+            api.lib = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* nm : names) {
+                api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+                if (api.lib) break;
+            }
         }
         if (api.lib) {
 #define CARMA_RCCL_SYM(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym))

@@ -71,6 +71,34 @@ def test_two_ranks_sharing_the_gpu():
     assert ld["first_contact_check"]["equals_one_gpu_run"] is True, ld["first_contact_check"]
 
 
+def test_four_ranks_with_the_native_ladder_path():
+    """The line the driver's N > 1 runs produce, with the ladder leg on the library's NATIVE path (carma_pt_iterate_sharded:
+    pack kernel -> send/recv -> swap kernel on the sampler's stream, boundary checksums) -- four processes, two temperatures
+    each.  One GPU here, so the ranks share it and the eight RCCL entry points are the shared-memory test double of
+    tests/shm_transport (CARMA_RCCL_LIB); everything above them is what runs on four GPUs."""
+    import subprocess as sp
+    here = os.path.join(ROOT, "tests", "shm_transport")
+    lib = os.path.join(here, "libshm_rccl.so")
+    sp.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-o", lib, os.path.join(here, "shm_rccl.cpp"), "-lrt", "-lpthread"],
+           check=True, stdout=sp.PIPE, stderr=sp.STDOUT, timeout=600)
+    env = dict(os.environ, CARMA_BENCH_SHARE_GPU="1", CARMA_RCCL_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "4", "--steps", "50", "--warmup", "5", "--mcmc-iters", "100", "--no-pipelined", "--no-throughput",
+                        "--ladder-iters", "6"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 4 and j["finite_in_last_batch"] == 1024
+    ld = j["ladder_sharded"]
+    assert ld["rccl_ranks"] == 4 and ld["temperatures_per_rank"] == 2 and ld["transport"].startswith("rccl send/recv"), ld
+    fc = ld["first_contact_check"]
+    assert fc["equals_one_gpu_run"] is True and fc["boundary_checksums_agree"] == [1, 1, 1, 1], fc
+    rates = ld["boundary_swaps_by_rank"]
+    assert [r_["proposed"] for r_ in rates] == [128 * 16, 2 * 128 * 16, 2 * 128 * 16, 128 * 16]
+    assert all(r_["checksums_agree"] == 1 and 0.0 < r_["rate"] < 1.0 for r_ in rates)
+    assert j.get("ladder_leg_hung") in (None, False)
+
+
 def test_ladder_leg_cannot_hold_the_line_back():
     """The ladder-sharded leg is the only one with an exchange between the ranks; a collective that never returns must not
     cost the run its JSON line: with a watchdog of 10 ms every rank leaves and rank 0 prints the line without the leg."""

@@ -278,6 +278,106 @@ def test_rccl_exchange_between_two_gpus():
     assert (npr0, nsw0) == (pr0, sw0) and (npr1, nsw1) == (pr1, sw1)
 
 
+def _build_shm_transport():
+    """tests/shm_transport/shm_rccl.cpp -> libshm_rccl.so (hipcc; host code only)."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shm_transport")
+    src, lib = os.path.join(here, "shm_rccl.cpp"), os.path.join(here, "libshm_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-o", lib, src, "-lrt", "-lpthread"], check=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    return lib
+
+
+def _shm_rank_worker(rank, blocks_by_rank, port, q, lib, nsample):
+    """One PROCESS per rank, all on cuda:0, the native sharded path with nranks = len(blocks_by_rank): the boundary rows
+    travel through the shared-memory test double of the RCCL entry points (CARMA_RCCL_LIB)."""
+    os.environ["CARMA_RCCL_LIB"] = lib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=len(blocks_by_rank))     # carries the 128-byte id, as in production
+    try:
+        import carma_pack_amd as cpa
+        from carma_pack_amd import _lib, parallel as par
+        t, y, e = _series()
+        temps = par.ladder_temperatures(TG)
+        comm = _lib.Comm.from_torch(dist, device=0)
+        assert (comm.rank, comm.size) == (rank, len(blocks_by_rank))
+        slot0 = sum(sum(b) for b in blocks_by_rank[:rank])
+        ctxs = []
+        for Tl in blocks_by_rank[rank]:
+            c = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std())
+            c.pt_create(Tl, R, NITER, seed=SEED, temperatures=temps[slot0:slot0 + Tl])
+            c.pt_shard(TG, slot0, 0)
+            c.pt_start(None)
+            ctxs.append(c)
+            slot0 += Tl
+        _lib.pt_iterate_sharded(ctxs, NITER // 2, comm)
+        _lib.pt_iterate_sharded(ctxs, NITER - NITER // 2, comm)
+        samples = _lib.pt_sample_sharded(ctxs, nsample, 3, comm) if nsample else None
+        out = []
+        for c in ctxs:
+            th, lp = c.pt_get_chains()
+            assert c.pt_boundary_check() == 1
+            out.append((th, lp, c.pt_boundary_stats(), c.pt_iterations_done()))
+        q.put((rank, out, samples))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_shm_ranks(blocks_by_rank, nsample=0):
+    import torch.multiprocessing as mp
+    from helpers import queue_get
+    lib = _build_shm_transport()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shm_rank_worker, args=(r, blocks_by_rank, port, q, lib, nsample)) for r in range(len(blocks_by_rank))]
+    for p_ in procs:
+        p_.start()
+    res = sorted((queue_get(q, procs, 300) for _ in procs), key=lambda r: r[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("blocks_by_rank", [[[3], [2]], [[2], [2], [1]], [[1, 1], [2, 1]], [[1], [1], [1], [1], [1]]])
+def test_native_sharded_path_with_more_than_one_rank(blocks_by_rank):
+    """carma_pt_iterate_sharded / carma_pt_sample_sharded with nranks = 2, 3 and 5 PROCESSES (one or two blocks each):
+    which rank talks to which, in what order, the boundary self-check between processes.  RCCL refuses two ranks on one
+    device, so on this one-GPU box the eight RCCL entry points the library binds are a shared-memory test double
+    (tests/shm_transport, CARMA_RCCL_LIB) -- everything above them is the production code: `Comm.from_torch` (the id
+    travels through torch.distributed), `carma_comm_create` with nranks > 1, the pack / exchange / swap / sweep order.
+    The chain states must be the unsharded ladder's, bit for bit, whatever the partition; the rank that owns the coldest
+    temperature saves the samples."""
+    uth, ulp, _ = _unsharded()
+    res = _run_shm_ranks(blocks_by_rank)
+    ths = [o[0] for _, out, _ in res for o in out]
+    lps = [o[1] for _, out, _ in res for o in out]
+    assert [t_.shape[1] for t_ in ths] == [b for blocks in blocks_by_rank for b in blocks]
+    assert np.array_equal(np.concatenate(ths, axis=1), uth) and np.array_equal(np.concatenate(lps, axis=1), ulp)
+    assert all(o[3] == NITER for _, out, _ in res for o in out)
+    # every boundary proposed every iteration, and counted alike by its two sides
+    stats = [o[2] for _, out, _ in res for o in out]
+    nb = len(stats)
+    assert [s_[0] for s_ in stats] == [R * NITER * ((i > 0) + (i < nb - 1)) for i in range(nb)]
+    if nb == 2:
+        assert stats[0] == stats[1] and 0 < stats[0][1] < stats[0][0]
+
+
+def test_native_sharded_sampler_with_two_ranks():
+    """... and as a complete sampler: 7 saves, thin 3, on two processes -- rank 0 (which owns the coldest temperature) returns
+    the samples, and they are those of the one-process run of the same partition."""
+    one = _run_native([3, 2], nsample=7)
+    ref_samples, ref_slp = one.pop()
+    res = _run_shm_ranks([[3], [2]], nsample=7)
+    (_, out0, smp0), (_, out1, smp1) = res
+    assert smp0 is not None and np.array_equal(smp0[0], ref_samples) and np.array_equal(smp0[1], ref_slp)
+    assert np.array_equal(out0[0][0], one[0][0]) and np.array_equal(out1[0][0], one[1][0])
+
+
 def _replica_worker(rank, world, port, q):
     """CarmaModel.run_mcmc(dist=): independent ladders split over the ranks, coldest chains gathered on every rank."""
     import torch.distributed as dist
