@@ -188,6 +188,10 @@ int carma_simulate_car1(const double* time, int n, double sigsqr, double omega, 
 int carma_pt_run(carma_ctx* h, int ntemps, int nreplicas, int sample_size, int burnin, int thin,
                  const double* init, int ninit, uint64_t seed, double* samples, double* logposts);
 
+/* ntemps: the ladder must fit ONE workgroup of the fall-back kernel (k_pt: 8 chains per wave at p >= 5, at most 1024
+ * threads and 160 KiB of LDS) -- up to 88 temperatures at CARMA(5,3), 52 at CARMA(7,6); longer ladders are CARMA_EINVAL
+ * with the sizes in carma_last_error() (the reference's own runs use about ten), or are split into blocks over
+ * ranks (carma_pt_shard). */
 int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* temperatures,
                     int adapt_iters, uint64_t seed);
 int carma_pt_shard(carma_ctx* h, int ntemps_global, int slot0, int replica0);
