@@ -134,10 +134,18 @@ __device__ __forceinline__ void ram_adapt_row(const Grp<16>& g, RowChain& ch, in
 
 // ExchangeStep sweep hot -> cold (steps.hpp:318-362, same decisions as exchange_decide) executed by a
 // whole wave on values held in lanes: lane i (< T <= 64) owns temperature i's log-posterior, its
-// 1/T_i - 1/T_{i-1} and the log of its swap uniform.  Every step reads the two values it needs with
-// v_readlane (uniform index), so the serial dependence runs through SGPRs instead of T LDS round trips.
-// On return lane i holds the log-posterior now sitting at temperature i and the index of the chain
-// its state comes from; *swapped is set for the lanes whose pair (i, i-1) swapped.
+// 1/T_i - 1/T_{i-1} and the log of its swap uniform.
+// The serial part is the chain that travels down the ladder: the state at temperature i after pair (i + 1, i) -- `hot`,
+// wave-uniform.  Per step EVERY lane forms its own pair's acceptance against that `hot` (lane i's is the one that
+// counts: one bit of the ballot), and the only things carried to the next step are `hot` and the bit: v_add, v_mul,
+// v_cmp and a handful of scalar instructions, ~40 cycles of dependent latency (round 2 read six lanes and wrote three
+// predicated results per step: 4.3k cycles for sixteen temperatures, on the path every ladder waits for).
+// What each temperature ends up with follows from the swap bits alone and is worked out by all lanes at once:
+//   pair (i, i - 1) swapped  -> temperature i takes the state that was at i - 1;
+//   otherwise                -> it takes the travelling chain, which started at h = i + (number of consecutive swapped pairs
+//                               right above i) -- the chain that kept moving down through every one of them.
+// On return lane i holds the log-posterior now sitting at temperature i and the index of the chain its state comes
+// from; *swapped is set for the lanes whose pair (i, i-1) swapped.
 __device__ __forceinline__ void exchange_decide_wave(int T, int lane, double& lp, double dbeta, double logu, int& src,
                                                      bool* swapped)
 {
@@ -147,28 +155,26 @@ __device__ __forceinline__ void exchange_decide_wave(int T, int lane, double& lp
         return __hiloint2double(hi, lo);
     };
     const double lp_in = lp;
+    const double cold_l = __shfl_up(lp_in, 1, 64);          // lane i: the log-posterior at temperature i - 1
     double hot = rl(lp_in, T - 1);
-    int hot_src = T - 1;
-    bool sw = false;
+    unsigned long long mask = 0ull;
     for (int i = T - 1; i > 0; i--) {
-        const double cold = rl(lp_in, i - 1);
-        const double a = (cold - hot) * rl(dbeta, i);
-        const bool swap = rl(logu, i) < a;                 // uniform
-        const double lp_i = swap ? cold : hot;
-        const int src_i = swap ? i - 1 : hot_src;
-        if (lane == i) {
-            lp = lp_i;
-            src = src_i;
-            sw = swap;
-        }
-        if (!swap) {
-            hot = cold;
-            hot_src = i - 1;
-        }
+        const double a = (cold_l - hot) * dbeta;            // ExchangeStep's exponent, lane i's is pair (i, i - 1)
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(logu < a);
+        const bool swap = ((bal >> i) & 1ull) != 0ull;      // uniform
+        mask |= (unsigned long long)swap << i;
+        const double cold_i = rl(lp_in, i - 1);
+        hot = swap ? hot : cold_i;
     }
-    if (lane == 0) {
-        lp = hot;
-        src = hot_src;
+    const bool sw = ((mask >> lane) & 1ull) != 0ull;          // (bit 0 and the bits from T up are never set)
+    const unsigned long long above = ~((mask >> lane) >> 1);  // bit k: pair (lane + 1 + k, lane + k) did NOT swap
+    const int h = lane + __builtin_ctzll(above);
+    const int from = sw ? lane - 1 : h;
+    if (lane < T) {
+        src = from;
+        lp = __shfl(lp_in, from, 64);
+    } else {
+        (void)__shfl(lp_in, lane, 64);
     }
     *swapped = sw;
 }
