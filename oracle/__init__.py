@@ -17,6 +17,7 @@ from .oracle import (  # noqa: F401
     predict_car1,
     predict_carma,
     sort_dedup,
+    truth_filter,
     truth_logdensity,
     variance,
 )

@@ -73,8 +73,8 @@ static QC qpowi(QC a, int k)
 }
 
 /* returns 0 on success; out[0] = log-likelihood + log prior, out[1] = log-likelihood */
-int orc_truth_logdensity(int n, const double* t, const double* y, const double* yerr, int p, int q, const double* theta,
-                         double* out)
+static int truth_run(int n, const double* t, const double* y, const double* yerr, int p, int q, const double* theta,
+                     double* out, double* mean_out, double* var_out)
 {
     if (p < 2 || p >= PMAXQ || q < 0 || q >= p || n < 1) return -1;
     QC om[PMAXQ];
@@ -156,6 +156,8 @@ int orc_truth_logdensity(int n, const double* t, const double* y, const double* 
     }
     var += scale * (Q)yerr[0] * (Q)yerr[0];
     Q mean = 0, innov = (Q)y[0] - mu;
+    if (mean_out) mean_out[0] = 0.0;
+    if (var_out) var_out[0] = (double)var;
     Q ll = -logq(var) / 2 - innov * innov / var / 2;
     for (int k = 1; k < n; k++) {
         /* Update (kfilter.cpp:189-215) */
@@ -183,6 +185,8 @@ int orc_truth_logdensity(int n, const double* t, const double* y, const double* 
             var += qmul(b[i], s).re;
         }
         var += scale * (Q)yerr[k] * (Q)yerr[k];
+        if (mean_out) mean_out[k] = (double)mean;
+        if (var_out) var_out[k] = (double)var;
         innov = (Q)y[k] - mu - mean;
         ll += -logq(var) / 2 - innov * innov / var / 2;
     }
@@ -190,4 +194,19 @@ int orc_truth_logdensity(int n, const double* t, const double* y, const double* 
     out[0] = (double)(ll + logprior);
     out[1] = (double)ll;
     return 0;
+}
+
+int orc_truth_logdensity(int n, const double* t, const double* y, const double* yerr, int p, int q, const double* theta,
+                         double* out)
+{
+    return truth_run(n, t, y, yerr, p, q, theta, out, 0, 0);
+}
+
+/* the same filter, returning mean[n] / var[n] (KalmanFilter::Filter's public vectors, kfilter.hpp:31-32) of the data
+ * y - theta[2] with errors sqrt(theta[1]) yerr -- the arbiter of the mean / variance comparisons */
+int orc_truth_filter(int n, const double* t, const double* y, const double* yerr, int p, int q, const double* theta,
+                     double* mean, double* var)
+{
+    double out[2];
+    return truth_run(n, t, y, yerr, p, q, theta, out, mean, var);
 }

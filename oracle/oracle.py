@@ -65,6 +65,8 @@ def lib():
         L.orc_predict_car1.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         L.orc_truth_logdensity.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]
         L.orc_truth_logdensity.restype = C.c_int
+        L.orc_truth_filter.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_truth_filter.restype = C.c_int
         L.orc_sampler_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
@@ -87,6 +89,17 @@ def truth_logdensity(t, y, yerr, theta, p, q):
     if rc != 0:
         raise ValueError("orc_truth_logdensity: rc=%d" % rc)
     return float(out[0]), float(out[1])
+
+
+def truth_filter(t, y, yerr, theta, p, q):
+    """(mean[n], var[n]) of the reference's filter for theta in quad precision (oracle/carma_truth_q.c): the data are
+    y - theta[2], the errors sqrt(theta[1]) yerr, as CARMA_Base::LogDensity hands them to the filter."""
+    t, y, yerr, theta = _a(t), _a(y), _a(yerr), _a(theta)
+    mean, var = np.empty(t.size), np.empty(t.size)
+    rc = lib().orc_truth_filter(t.size, _p(t), _p(y), _p(yerr), int(p), int(q), _p(theta), _p(mean), _p(var))
+    if rc != 0:
+        raise RuntimeError("orc_truth_filter failed (%d)" % rc)
+    return mean, var
 
 
 def max_threads():

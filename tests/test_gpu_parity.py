@@ -765,6 +765,37 @@ def test_ill_conditioned_models_against_the_reference_python(cpa, golden_dir):
     print("%d of %d ill-conditioned vectors arbitrated (the reference itself is beyond 1e-10 on 11)" % (narb, len(g["p"])))
 
 
+def test_filter_mean_and_variance_of_ill_conditioned_models(cpa, golden_dir):
+    """KalmanFilter::Filter's mean[n] / var[n] (row A3) where the modal basis is ill conditioned: the same 36 parameter
+    vectors, the reference Python's own mean / variance vectors (make_golden_hard.py) in the oracle's place, and the
+    quad-precision filter (oracle.truth_filter, tied to the reference's vectors in test_oracle_golden.py) as the arbiter:
+    every value within 1e-9 of the reference's, or no further from the exact value than the reference's is."""
+    g = np.load(os.path.join(golden_dir, "illcond_readme.npz"))
+    t, y, e = g["t"], g["y"], g["yerr"]
+    narb = nworse = 0
+    worst_dev, worst_ref = 0.0, 0.0
+    for i in range(len(g["p"])):
+        p, q = int(g["p"][i]), int(g["q"][i])
+        th = g["theta"][i][: 3 + p + q]
+        roots = np.asarray(orc.ar_roots(th, p))
+        ma = np.asarray(orc.ma_coefs(th, p, q))
+        sig2 = th[0] ** 2 / orc.variance(roots, ma)
+        mean, var = cpa._lib.kfilter_carma(t, y - th[2], np.sqrt(th[1]) * e, sig2, roots, ma)
+        rm, rv = g["mean"][i], g["var"][i]
+        sc = np.abs(y - th[2]).max()
+        dev = max(np.max(np.abs(mean - rm)) / sc, np.max(np.abs(var - rv) / rv))
+        if dev > 1e-9:
+            narb += 1
+            tm, tv = orc.truth_filter(t, y, e, th, p, q)
+            eg = max(np.max(np.abs(mean - tm)) / sc, np.max(np.abs(var - tv) / tv))
+            er = max(np.max(np.abs(rm - tm)) / sc, np.max(np.abs(rv - tv) / tv))
+            worst_dev, worst_ref = max(worst_dev, eg), max(worst_ref, er)
+            nworse += eg > max(1e-9, er)
+            print("cond %.1e p=%d q=%d: device %.1e, reference Python %.1e from the exact mean / variance" % (g["cond"][i], p, q, eg, er))
+            assert eg <= max(1e-9, er), (i, eg, er)
+    print("%d of %d vectors arbitrated; worst device error %.1e, worst reference error %.1e" % (narb, len(g["p"]), worst_dev, worst_ref))
+
+
 @pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
 def test_lane_kernel_prior_like_sweep(cpa, p):
     """k_logdens_carma_lane<P> -- one evaluation per lane, what launches beyond 49 152 evaluations take (round 3) -- and

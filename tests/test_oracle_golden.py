@@ -424,3 +424,24 @@ def test_overflow_region_states():
     m = orc.OracleModel(t, y, e, 5, 3, max_stdev=1e3)
     got, truth = m.logdensity(th, ignore_prior=True), orc.truth_logdensity(t, y, e, th, 5, 3)[0]
     assert np.isfinite(got) and abs(got - truth) <= 1e-6 * abs(truth), (got, truth)
+
+
+def test_filter_arbiter_is_tied_to_the_reference_held_vectors(golden_dir):
+    """oracle.truth_filter (quad-precision mean[n] / var[n], the arbiter of the mean / variance comparisons) against the
+    reference Python's own vectors: README CARMA(5,3), every stored parameter vector, <= 1e-12; and on the ill-conditioned
+    set its distance from the reference's LAPACK LU grows with cond(EigenMat) as the log-likelihood's does."""
+    g = _load(golden_dir, "carma53_readme.npz")
+    t, y, e = g["t"], g["y"], g["yerr"]
+    worst = 0.0
+    for i in range(g["theta"].shape[0]):
+        if not np.all(np.isfinite(g["var"][i])):
+            continue
+        m, v = orc.truth_filter(t, y, e, g["theta"][i], 5, 3)
+        worst = max(worst, np.max(np.abs(v - g["var"][i]) / g["var"][i]), np.max(np.abs(m - g["mean"][i])) / np.abs(y).max())
+    assert worst <= 1e-12, worst
+    h = _load(golden_dir, "illcond_readme.npz")
+    low = [i for i in range(len(h["p"])) if h["cond"][i] < 1e5]
+    for i in low:
+        p, q = int(h["p"][i]), int(h["q"][i])
+        m, v = orc.truth_filter(h["t"], h["y"], h["yerr"], h["theta"][i][: 3 + p + q], p, q)
+        assert np.max(np.abs(v - h["var"][i]) / h["var"][i]) <= 1e-9, (i, h["cond"][i])
