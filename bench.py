@@ -351,16 +351,21 @@ def main():
 
             def give_up():
                 # The exchange hangs: rank 0 prints the line WITH the failure in it ("ladder_leg_hung": true and the leg's
-                # error), says so on stderr, and every rank leaves.  The exit code stays 0 on purpose: the line carries the
-                # headline measurement of this N, which was complete before the leg started, and a launcher that discards
-                # the output of a failed run would lose it -- the hang is reported in the line, not hidden.
+                # error; the headline measurement of this N was complete before the leg started), says so on stderr, and
+                # EVERY rank leaves with a non-zero status -- a wedged RCCL exchange is a failed run to the launcher; a
+                # harness that wants the partial numbers reads the line on rc != 0.  No retry in here: a process that has
+                # touched the GPU is never re-executed, a fresh process is the only retry.
                 if rank == 0 and printed.acquire(blocking=False):
                     out = dict(res)
                     out["ladder_leg_hung"] = True
                     out["ladder_sharded"] = {"metric": LADDER_TEXT, "error": "no result after %d s" % args.ladder_timeout}
-                    sys.stderr.write("bench.py: the ladder-sharded leg did not return within %d s; leaving\n" % args.ladder_timeout)
+                    sys.stderr.write("bench.py: the ladder-sharded leg did not return within %d s; leaving with status 3\n" % args.ladder_timeout)
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                    sys.stdout.flush()
+                elif rank != 0:
+                    sys.stderr.write("bench.py: rank %d: the ladder-sharded leg did not return within %d s; leaving with status 3\n" % (rank, args.ladder_timeout))
+                sys.stderr.flush()
+                os._exit(3)
 
             watchdog = threading.Timer(args.ladder_timeout, give_up)
             watchdog.daemon = True

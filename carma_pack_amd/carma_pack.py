@@ -142,6 +142,21 @@ def car1_process_batch(time, sigsqr, tau, npaths=1, seed=0, device=None):
 
 
 # ------------------------------------------------------------------------------------------------
+class BatchResult(object):
+    """scipy.optimize.OptimizeResult look-alike for one start of the lock-step optimiser (carma_mle_batched)."""
+
+    def __init__(self, x, fun, nit, nfev, success, message):
+        self.x, self.fun, self.nit, self.nfev, self.success, self.message = x, fun, nit, nfev, success, message
+
+    def __repr__(self):
+        return "BatchResult(fun=%r, nit=%d, success=%r)" % (self.fun, self.nit, self.success)
+
+
+# status codes of carma_mle_batched (include/carma_mi355.h) in words
+STATUS_TEXT = ("converged: projected gradient <= gtol", "converged: relative reduction of f <= ftol",
+               "maximum number of iterations reached", "line search failed")
+
+
 class MCMCSample(object):
     """Minimal sample container (the reference's samplers.MCMCSample holds the same `_samples` dict;
     its plotting/diagnostic methods are outside the hot path)."""
@@ -532,16 +547,8 @@ class CarmaModel(object):
             bnds += [(lo, hi)] * p + [(None, None)] * q
         return bnds
 
-    def get_mle(self, p, q, ntrials=100, njobs=1, seed=None, method="batched", return_all=False):
-        """Best of `ntrials` bounded quasi-Newton fits started from short tempered MCMC runs
-        (reference :92-129,195-260).  The reference launches ntrials separate 26-iteration samplers
-        and calls the C++ log-density once per function evaluation; here ONE sampler call with
-        `ntrials` independent replicas provides all starting points, and with method="batched" all
-        starts are optimised in lock-step (carma_pack_amd.batched_opt): one launch evaluates the
-        finite-difference stencils of every start.  method="scipy" runs scipy's L-BFGS-B per start
-        with a batched gradient.  `njobs` is accepted for compatibility.  Returns an object with
-        .x, .fun (= -loglik), .message like scipy's OptimizeResult (return_all=True: the list of all ntrials results,
-        in the order of the starts)."""
+    def _mle_problem(self, p, q, ntrials, seed):
+        """(model object, [ntrials, d] starting points, L-BFGS-B box) of a get_mle call (reference :195-240)."""
         if p == 1:
             proc = carmcmcLib.run_mcmc_car1(1, 25, self._time, self._y, self._ysig, 1, nreplicas=ntrials, seed=seed)
         else:
@@ -551,16 +558,28 @@ class CarmaModel(object):
         starts = proc.getAllSamples()[0][:, 0, :].copy()
         bnds = self._mle_bounds(p, q)
         rng = np.random.default_rng(seed)
-        d = starts.shape[1]
         starts[:, 1] = 1.0                                   # initial guess for the error scale (:217)
         for j, (lo, hi) in enumerate(bnds):
             if lo is not None:
                 out = (starts[:, j] < lo) | (starts[:, j] > hi)
                 starts[out, j] = rng.uniform(lo, hi, int(out.sum()))
+        return proc, starts, bnds
+
+    def get_mle(self, p, q, ntrials=100, njobs=1, seed=None, method="batched", return_all=False):
+        """Best of `ntrials` bounded quasi-Newton fits started from short tempered MCMC runs
+        (reference :92-129,195-260).  The reference launches ntrials separate 26-iteration samplers
+        and calls the C++ log-density once per function evaluation; here ONE sampler call with
+        `ntrials` independent replicas provides all starting points, and with method="batched" all
+        starts are optimised in lock-step (carma_mle.hip, C ABI carma_mle_batched): one launch evaluates the
+        finite-difference stencils of every start.  method="scipy" runs scipy's L-BFGS-B per start
+        with a batched gradient.  `njobs` is accepted for compatibility.  Returns an object with
+        .x, .fun (= -loglik), .message like scipy's OptimizeResult (return_all=True: the list of all ntrials results,
+        in the order of the starts)."""
+        proc, starts, bnds = self._mle_problem(p, q, ntrials, seed)
+        d = starts.shape[1]
 
         if method == "batched":
             # the lock-step optimiser inside the library (carma_mle.hip): no interpreter between the launches
-            from .batched_opt import BatchResult, STATUS_TEXT
             xs, fs, nits, nfevs, sts = proc.minimizeBatch(starts, bnds)
             results = [BatchResult(xs[i].copy(), float(fs[i]), int(nits[i]), int(nfevs[i]), int(sts[i]) < 2, STATUS_TEXT[int(sts[i])])
                        for i in range(xs.shape[0])]
@@ -568,13 +587,8 @@ class CarmaModel(object):
                 return results
             results = [r for r in results if np.isfinite(r.fun) and r.fun < 1e299] or results
             return min(results, key=lambda r: r.fun)
-        if method == "batched_py":                          # the same algorithm as a numpy loop (batched_opt.py)
-            from .batched_opt import minimize_batched
-            results = minimize_batched(lambda pts: -np.asarray(proc.getLogDensityBatch(pts)), starts, bnds)
-            if return_all:
-                return results
-            results = [r for r in results if np.isfinite(r.fun) and r.fun < 1e299] or results
-            return min(results, key=lambda r: r.fun)
+        if method != "scipy":
+            raise ValueError("method must be 'batched' or 'scipy'")
 
         def fun_and_grad(x):
             h = 1e-6 * np.maximum(1.0, np.abs(x))

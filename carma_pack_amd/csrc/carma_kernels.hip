@@ -361,13 +361,21 @@ static long lpc_max_evals()
 {
     static const long v = lpc_tune("CARMA_TUNE_LPC_MAX", -1);
     if (v >= 0) return v;
-    static std::atomic<int> blocks{0};                        // workgroups of this kernel a CU holds (registers, LDS)
-    int nb = blocks.load(std::memory_order_relaxed);
+    // workgroups of this kernel a CU holds (registers, LDS), cached per device like device_cus()
+    static std::atomic<int> blocks[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return 64L * device_cus();
+    }
+    int nb = blocks[dev].load(std::memory_order_relaxed);
     if (nb <= 0) {
         const void* kern = reinterpret_cast<const void*>(&k_logdens_carma_lpc<P, 3>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, LaneRingGeom<P, 3>::BYTES) != hipSuccess || nb <= 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, LaneRingGeom<P, 3>::BYTES) != hipSuccess || nb <= 0) {
+            (void)hipGetLastError();                          // the query's error must not surface as the next launch's
             nb = 1;
-        blocks.store(nb, std::memory_order_relaxed);
+        }
+        blocks[dev].store(nb, std::memory_order_relaxed);
     }
     return 64L * (nb < 3 ? nb : 3) * device_cus();
 }

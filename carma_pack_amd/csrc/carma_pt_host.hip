@@ -409,7 +409,11 @@ int carma_pt_set_chains(carma_ctx* h, const double* theta, const double* logpost
     }
     hipError_t e = hipMemcpy(s->d_theta, theta, sizeof(double) * nchain * c->d, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_lp, lp.data(), sizeof(double) * nchain, hipMemcpyHostToDevice);
+    // a new set of chains starts a new history of boundary decisions: the two sides of a boundary compare folds of the
+    // decisions since this point (carma_shard.hip), so one side re-created on its own must not inherit the old sum
+    if (e == hipSuccess && s->d_checksum) e = hipMemset(s->d_checksum, 0, 4 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "carma_pt_set_chains");
+    s->bnd_check = 0;
     s->started = true;
     return CARMA_OK;
 }

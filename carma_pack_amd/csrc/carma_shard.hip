@@ -335,6 +335,12 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
     }
     // every block of this process on ONE stream (block 0's): kernels, RCCL calls and swap kernels are ordered by it
     hipStream_t st = cs[0]->stream;
+    // The self-check covers THIS call: the call is collective, so both sides of every boundary clear their folds at the
+    // same point of the ladder's history (sums kept over a context's lifetime made a re-created neighbour a mismatch).
+    for (int i = 0; i < nlocal; i++) {
+        e = hipMemsetAsync(cs[i]->pt->d_checksum, 0, 4 * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return hip_fail(e, "carma_pt_iterate_sharded: checksum reset");
+    }
     for (int i = 1; i < nlocal; i++) {
         e = hipStreamSynchronize(cs[i]->stream);      // work enqueued earlier on a block's own stream (start-up)
         if (e != hipSuccess) return hip_fail(e, "carma_pt_iterate_sharded");

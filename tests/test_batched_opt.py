@@ -1,8 +1,13 @@
-"""CPU-only: the lock-step batched L-BFGS used by get_mle (no GPU needed: any batched objective)."""
+"""CPU-only: the numpy PROTOTYPE (tests/tools/batched_opt_proto.py) of the lock-step batched L-BFGS that the library
+runs natively (carma_mle.hip); test_gpu_api.py holds the native optimiser to it start by start."""
 import numpy as np
 from scipy.optimize import minimize
 
-from carma_pack_amd.batched_opt import minimize_batched
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+from batched_opt_proto import minimize_batched  # noqa: E402
 
 
 def _rosen(x):

@@ -1,7 +1,13 @@
 """GPU tests of the `_carmcmc` drop-in and the Python API; they read like the reference's own
 src/tests/testCarmcmc.py (n = 10 series, tiny samplers, binding overloads and defaults)."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+from batched_opt_proto import minimize_batched  # noqa: E402  (numpy prototype of the library's optimiser)
 
 pytestmark = pytest.mark.gpu
 
@@ -151,7 +157,8 @@ def test_carma_model_mcmc_and_mle(cm, golden_dir):
     # a backtracking decision falls the other way)
     for (pp, qq, nt) in ((1, 0, 8), (2, 0, 12), (3, 1, 16)):
         nat = model.get_mle(pp, qq, ntrials=nt, seed=11, return_all=True)
-        pyv = model.get_mle(pp, qq, ntrials=nt, seed=11, method="batched_py", return_all=True)
+        proc_, starts_, bnds_ = model._mle_problem(pp, qq, nt, 11)
+        pyv = minimize_batched(lambda pts: -np.asarray(proc_.getLogDensityBatch(pts)), starts_, bnds_)
         fa, fb = np.array([r.fun for r in nat]), np.array([r.fun for r in pyv])
         ok = (fa < 1e299) & (fb < 1e299)
         assert ok.sum() >= nt - 2

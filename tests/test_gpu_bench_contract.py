@@ -101,13 +101,15 @@ def test_four_ranks_with_the_native_ladder_path():
 
 def test_ladder_leg_cannot_hold_the_line_back():
     """The ladder-sharded leg is the only one with an exchange between the ranks; a collective that never returns must not
-    cost the run its JSON line: with a watchdog of 10 ms every rank leaves and rank 0 prints the line without the leg."""
+    cost the run its JSON line: with a watchdog of 10 ms rank 0 prints the line without the leg -- and every rank leaves with
+    a NON-ZERO status (a wedged exchange is a failed run to the launcher; the line is there to be read on rc != 0)."""
     env = dict(os.environ, CARMA_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "50", "--warmup", "5", "--no-mcmc", "--no-pipelined", "--no-throughput",
                         "--ladder-iters", "200", "--ladder-timeout", "0.01"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode != 0, "a hung ladder leg must not look like a successful run"
+    assert "leaving with status 3" in r.stderr, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 1e6 and "no result after" in j["ladder_sharded"]["error"] and j["ladder_leg_hung"] is True

@@ -1,4 +1,6 @@
-"""Lock-step bounded quasi-Newton minimiser for MANY independent starts.
+"""TEST INFRASTRUCTURE (numpy prototype; the product's optimiser is carma_mle.hip / carma_mle_batched).
+
+Lock-step bounded quasi-Newton minimiser for MANY independent starts.
 
 carma_pack's ``get_mle`` runs ``ntrials`` separate ``scipy.optimize.minimize(..., "L-BFGS-B")``
 searches and crosses the FFI once per function evaluation (reference carma_pack.py:92-129,195-260).
@@ -12,19 +14,7 @@ mirror L-BFGS-B's defaults (relative decrease <= 1e7*eps or projected gradient <
 import numpy as np
 
 
-class BatchResult(object):
-    """scipy.optimize.OptimizeResult look-alike for one start."""
-
-    def __init__(self, x, fun, nit, nfev, success, message):
-        self.x, self.fun, self.nit, self.nfev, self.success, self.message = x, fun, nit, nfev, success, message
-
-    def __repr__(self):
-        return "BatchResult(fun=%r, nit=%d, success=%r)" % (self.fun, self.nit, self.success)
-
-
-# status codes of carma_mle_batched (include/carma_mi355.h) in the words this module uses
-STATUS_TEXT = ("converged: projected gradient <= gtol", "converged: relative reduction of f <= ftol",
-               "maximum number of iterations reached", "line search failed")
+from carma_pack_amd.carma_pack import BatchResult, STATUS_TEXT  # noqa: F401  (the product's result type)
 
 
 def _project(x, lo, hi):
