@@ -26,7 +26,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (import torch BEFORE the HIP library so both share one HIP runtime)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_VALU_PEAK_TFLOPS = 78.6   # public MI355X FP64 vector peak
+FP64_VALU_PEAK_TFLOPS = 78.6   # public MI355X FP64 vector peak = 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
+MAX_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md: max clock; a wave64 VALU instruction holds its SIMD's issue port 4 cycles
 
 
 def main():
@@ -75,6 +76,19 @@ def main():
 
     import carma_pack_amd as cpa
     from carma_pack_amd.synth import theta_batch
+
+    # who is here: every rank's device, gathered once (a driver-run SCALE record shows at a glance that N ranks on N
+    # different devices took part, and which RCCL carried the barrier)
+    me = {"rank": rank, "local_rank": local_rank, "device_ordinal": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
+          "pci_bus_id": _pci_bus_id(dev_index)}
+    ranks_info = [me]
+    if dist is not None:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                          # noqa: BLE001 (a build without it)
+        rccl_version = None
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "carma53_readme.npz"))
     t, y, yerr = g["t"], g["y"], g["yerr"]
@@ -159,17 +173,11 @@ def main():
             tt = torch.tensor([tq], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tq = float(tt.item())
-        flops_per_eval_ = (n - 1) * (42 * p * p + 22 * p + 9)
         k_us = 1e3 * e0.elapsed_time(e1) / NT
         tput = {
             "metric": "Kalman log-lik evals/sec with the chip full (same series, %d evaluations per launch)" % BT,
             "evals_per_s": world * BT * NT / tq, "batch_per_gpu": BT, "launches": NT, "kernel": ctx.kernel_name(BT),
             "kernel_avg_us": k_us,
-            "fp64_valu": {"achieved_tflops": flops_per_eval_ * BT / (k_us * 1e-6) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                          "frac": flops_per_eval_ * BT / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          "note": "algorithmic flop count of the reference's COMPLEX recursion (SURVEY.md 8d): the kernels work in real "
-                                  "modal coordinates on the symmetric half of the matrix, about a third of those flops -- a fraction "
-                                  "above 1 is this count's artefact, not a measurement error"},
         }
 
     # ---- secondary metric: MCMC iterations/s, BASELINE configs[2] shape ------------------------
@@ -271,18 +279,20 @@ def main():
         # dispatch record names the kernel this run actually launched; none -> null, never a stale figure.
         # (gfx950 FETCH_SIZE can under-count wide coalesced reads by 2x, so 2*FETCH+WRITE is the upper bound.)
         kernel_name = ctx.kernel_name(B)
+        ids = cpa._lib.build_ids()
         traffic_gbs_bytes, traffic_src, pmc_extra = None, None, None
-        pj, pmc_path = committed_pmc(kernel_name, ((B + 3) // 4) * 256)       # same kernel, same launch shape
+        pj, pmc_path = committed_pmc(kernel_name, ((B + 3) // 4) * 256, ids)       # same kernel, same launch shape, same build
         if pj is not None and "FETCH_SIZE" in pj and "WRITE_SIZE" in pj:
             traffic_gbs_bytes = (2.0 * pj["FETCH_SIZE"]["mean"] + pj["WRITE_SIZE"]["mean"]) * 1024.0
-            pmc_extra = {k: pj[k]["mean"] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
-                                                     "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if k in pj}
-            traffic_src = "%s (rocprofv3 --pmc of this command, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch" % pmc_path
+            traffic_src = "%s (rocprofv3 --pmc of this command on this build, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch" % pmc_path
+        elif pj is None:
+            traffic_src = pmc_path                               # why there is none (no record / another build)
+        pmc_extra = pmc_digest(pj, pmc_path, 1e3 * kernel_ms)
         if mcmc is not None:
-            mcmc["pmc_per_iteration"] = pmc_digest(*committed_pmc("k_pt_row<%d," % p))
+            # per ITERATION: the iteration's wall time is what the counters are set against
+            mcmc["pmc_per_iteration"] = pmc_digest(*committed_pmc("k_pt_row<%d," % p, None, ids), 1e6 / mcmc["iters_per_s"])
         if tput is not None:
-            tput["pmc_per_launch"] = pmc_digest(*committed_pmc(tput["kernel"]))
-        fp64_tflops = flops_per_eval * B / (kernel_ms * 1e-3) / 1e12
+            tput["pmc_per_launch"] = pmc_digest(*committed_pmc(tput["kernel"], None, ids), tput["kernel_avg_us"])
         res = {
             "metric": "Kalman log-lik evals/sec, CARMA(5,3) n=270",
             "value": value,
@@ -318,15 +328,15 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_eval * B,
                 "binding_resource": "fp64_valu_issue",
                 "note": "HBM roofline reported as north_star asks; the kernel is bound by the FP64 VALU issue rate of one "
-                        "wave's dependent instruction stream (sequential n-step recursion): see fp64_valu",
+                        "wave's dependent instruction stream (sequential n-step recursion): pmc_per_launch.valu_issue_frac is the "
+                        "measured share of the chip's VALU issue slots, pmc_per_launch.fp64 the executed flops",
                 "pmc_per_launch": pmc_extra,
-                "fp64_valu": {
-                    "flops_per_eval": flops_per_eval,
-                    "achieved_tflops": fp64_tflops,
-                    "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                    "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
-                },
+                "algorithmic_flops_per_eval_reference_complex_count": flops_per_eval,
             },
+            "build": ids,
+            "backend": ("gloo (test hook: ranks share one GPU)" if share else "nccl (RCCL)") if world > 1 else "none (one rank)",
+            "rccl_version": rccl_version,
+            "ranks": ranks_info,
             "finite_in_last_batch": n_finite,
         }
         if mcmc is not None:
@@ -382,6 +392,17 @@ def main():
     if rank == 0:
         if ladder is not None:
             res["ladder_sharded"] = ladder
+            # first contact of the sharded ladder with RCCL, at top level: did N ranks exchange, and was it right
+            fc = ladder.get("first_contact_check") or {}
+            res["rccl_first_contact"] = {
+                "ranks_in_exchange": ladder.get("rccl_ranks"),
+                "verdict": ("error: " + ladder["error"]) if "error" in ladder else
+                           ("one rank: no exchange" if world == 1 else
+                            ("ok" if fc.get("equals_one_gpu_run") in (True, None) and all(v == 1 for v in (fc.get("boundary_checksums_agree") or []) if v is not None)
+                             and fc.get("equals_one_gpu_run") is not False else "MISMATCH")),
+                "equals_one_gpu_run": fc.get("equals_one_gpu_run"), "kernels_compared": fc.get("kernels_compared"),
+                "boundary_checksums_agree": fc.get("boundary_checksums_agree"), "transport": ladder.get("transport"),
+            }
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(t, y, yerr, p, q, max_stdev, pool_h[0], args.cpu_seconds)
         print(json.dumps(res), flush=True)
@@ -389,15 +410,25 @@ def main():
         dist.destroy_process_group()
 
 
-def committed_pmc(kernel_substr, grid=None):
+def _pci_bus_id(dev_index):
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        return "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:                                          # noqa: BLE001
+        return None
+
+
+def committed_pmc(kernel_substr, grid=None, ids=None):
     """Counters of `kernel_substr` from the newest committed rocprofv3 PMC summary (profiles/r*/pmc_*.json, written by
     tools/profile_round.sh + tools/summarize_prof.py from separate --pmc passes of this command) whose dispatch record
-    names that kernel (and launch grid); (None, None) when there is none -- never a stale or foreign figure."""
+    names that kernel (and launch grid) AND whose build stamp is the running library's: the same binary (build_id) or a
+    binary built from the same sources (source_id).  (None, reason) otherwise -- never a stale or foreign figure."""
     import glob
     import re
     # newest = highest (round, version) in the path (profiles/r03/pmc_v2.json); file times mean nothing after a checkout
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")),
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.relpath(f, ROOT))], reverse=True)
+    seen_other_build = None
     for pmc in cands:
         try:
             pj = json.load(open(pmc))
@@ -409,19 +440,45 @@ def committed_pmc(kernel_substr, grid=None):
             continue
         if grid is not None and str(disp.get("Grid_Size", "")) != str(grid):
             continue
+        stamp = pj.get("_ids") or {}
+        if ids is not None and not ((stamp.get("build_id") and stamp.get("build_id") == ids.get("build_id")) or
+                                    (stamp.get("source_id") and stamp.get("source_id") == ids.get("source_id"))):
+            seen_other_build = seen_other_build or os.path.relpath(pmc, ROOT)
+            continue
         return pj, os.path.relpath(pmc, ROOT)
-    return None, None
+    if seen_other_build:
+        return None, "none: the newest record of this kernel (%s) was measured on another build of the library" % seen_other_build
+    return None, "none: no committed counter record of this kernel"
 
 
-def pmc_digest(pj, src):
+def pmc_digest(pj, src, wall_us=None):
+    """The counters of one record, per launch (or per sampler iteration), and what follows from them and from the wall
+    time `wall_us` measured in THIS run:
+      valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x wall x 2.4 GHz)   -- share of the chip's VALU issue slots
+                        (every wave64 VALU instruction holds its SIMD's issue port for 4 cycles; FP64 DPP and
+                        transcendentals longer, so this is a lower bound of the port's busy share and can never exceed 1)
+      fp64: executed flops = (2 FMA + ADD + MUL instructions) x 64 lanes, as the hardware counts instructions (idle lanes
+            of a partly filled wave included) -- not the reference's complex-arithmetic count."""
     if pj is None:
-        return None
+        return {"source": src} if src else None
     out = {k: pj[k]["mean"] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
-                                      "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE") if k in pj}
+                                      "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU_FMA_F64",
+                                      "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "GRBM_GUI_ACTIVE")
+           if k in pj}
     out["per"] = pj.get("_per", "launch")
     out["kernel"] = (pj.get("_dispatch") or {}).get("Kernel_Name", "").split("(")[0].replace("void carma::", "")
     out["vgprs"] = (pj.get("_dispatch") or {}).get("VGPR_Count")
     out["source"] = "%s (rocprofv3 --pmc of this command, not live; FETCH/WRITE in KiB)" % src
+    out["measured_on"] = pj.get("_ids")
+    if wall_us and "SQ_INSTS_VALU" in out:
+        simds = 256 * 4
+        out["valu_issue_frac"] = out["SQ_INSTS_VALU"] * 4.0 / (simds * wall_us * 1e-6 * MAX_CLOCK_GHZ * 1e9)
+        out["valu_issue_frac_basis"] = "SQ_INSTS_VALU x 4 cycles / (%d SIMDs x %.2f us x %.1f GHz max clock)" % (simds, wall_us, MAX_CLOCK_GHZ)
+    if wall_us and all(k in out for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64")):
+        fl = (2.0 * out["SQ_INSTS_VALU_FMA_F64"] + out["SQ_INSTS_VALU_ADD_F64"] + out["SQ_INSTS_VALU_MUL_F64"]) * 64.0
+        tf = fl / (wall_us * 1e-6) / 1e12
+        out["fp64"] = {"executed_flops": fl, "achieved_tflops": tf, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                       "basis": "(2 x SQ_INSTS_VALU_FMA_F64 + _ADD_F64 + _MUL_F64) x 64 lanes / wall time of this run"}
     return out
 
 
@@ -450,7 +507,7 @@ def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):
     if world > 1:
         th, lp = ctx4.pt_get_chains()
         parts = [None] * world
-        dist.all_gather_object(parts, (th, lp, ctx4.pt_boundary_check() if comm is not None else None))
+        dist.all_gather_object(parts, (th, lp, ctx4.pt_boundary_check() if comm is not None else None, ctx4.pt_kernel()))
         if dist.get_rank() == 0:
             one = cpa.Context(t4, y4, e4, 7, 6, device=dev_index)
             one.pt_create(TG, R4, 10 ** 9, seed=SEED4, temperatures=par.ladder_temperatures(TG))
@@ -458,9 +515,21 @@ def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):
             one.pt_start(None)
             one.pt_iterate(WARM)
             uth, ulp = one.pt_get_chains()
+            # The sampler kernels take the same decisions but round differently (include/carma_mi355.h): bit equality is
+            # the test only when the blocks and the one-GPU run were on the SAME kernel; otherwise the comparison is to
+            # rounding (same decisions => the same states to 1e-6) and says so.
+            kern_blocks, kern_one = [p_[3] for p_ in parts], one.pt_kernel()
+            same_kernel = all(k_ == kern_one for k_ in kern_blocks)
+            gth = np.concatenate([p_[0] for p_ in parts], axis=1)
+            glp = np.concatenate([p_[1] for p_ in parts], axis=1)
+            if same_kernel:
+                equal = bool(np.array_equal(gth, uth) and np.array_equal(glp, ulp))
+            else:
+                equal = bool(np.allclose(gth, uth, rtol=1e-6, atol=1e-9) and np.allclose(glp, ulp, rtol=1e-6, atol=1e-9))
             check = {
-                "equals_one_gpu_run": bool(np.array_equal(np.concatenate([p_[0] for p_ in parts], axis=1), uth) and
-                                           np.array_equal(np.concatenate([p_[1] for p_ in parts], axis=1), ulp)),
+                "equals_one_gpu_run": equal,
+                "comparison": "bit for bit" if same_kernel else "to 1e-6 (the runs were on different sampler kernels)",
+                "kernels_compared": {"blocks": kern_blocks, "one_gpu_run": kern_one},
                 "boundary_checksums_agree": [p_[2] for p_ in parts],
                 "iterations_checked": WARM,
             }

@@ -66,6 +66,34 @@ def _share_rccl_with_torch():
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
+def build_ids():
+    """What is running: {"build_id": sha256 of the shared library that is loaded, "source_id": sha256 over the sources it is
+    built from (csrc/, include/, build.sh; None when the sources are not beside the library)}.  Profile records carry
+    these so that counters measured on one build are never attributed to another (bench.py, tools/summarize_prof.py)."""
+    import hashlib
+    out = {"build_id": None, "source_id": None}
+    try:
+        with open(LIB_PATH, "rb") as f:
+            out["build_id"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        pass
+    root = os.path.dirname(_HERE)
+    files = []
+    for sub in ("carma_pack_amd/csrc", "include"):
+        dd = os.path.join(root, sub)
+        if os.path.isdir(dd):
+            files += [os.path.join(dd, f) for f in sorted(os.listdir(dd)) if f.endswith((".h", ".hip", ".hpp", ".cpp"))]
+    bs = os.path.join(root, "build.sh")
+    if files and os.path.exists(bs):
+        h = hashlib.sha256()
+        for f in files + [bs]:
+            h.update(os.path.relpath(f, root).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        out["source_id"] = h.hexdigest()[:16]
+    return out
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(

@@ -5,12 +5,14 @@
 # follows "--" (no env/bash -c hop: the profiler's preloaded library has already initialised the GPU).
 # The PMC passes keep the sampler leg (300 iterations of k_pt_row in two dispatches) and the throughput leg
 # (k_logdens_carma<5,8,4>, 65 536 evaluations per launch) next to the headline kernel: one summary per kernel.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 REPO=$PWD
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# which build the counters below belong to (bench.py attaches them to a run of the same build only)
+python3 -c "import sys, json; sys.path.insert(0, '$REPO'); from carma_pack_amd._lib import build_ids; json.dump(build_ids(), open('$OUT/ids.json', 'w'))"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --no-cpu --no-pipelined > $OUT/stats.log 2>&1
 echo "stats rc=$?"
@@ -21,4 +23,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQ -o $TAG -- python3 $REPO/bench.py $PMC_ARGS > $OUT/pmc_SQ.log 2>&1
 echo "pmc SQ rc=$?"
+# instruction classes of the FP64 work (executed flops, not the reference's count) and the clock (GRBM_GUI_ACTIVE / 8 / time)
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_F64 -o $TAG -- python3 $REPO/bench.py $PMC_ARGS > $OUT/pmc_F64.log 2>&1
+echo "pmc F64 rc=$?"
 find $OUT -name "*.csv" | head -20

@@ -11,9 +11,15 @@ import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r03")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r04")
 pt_iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 os.makedirs(dst, exist_ok=True)
+sys.path.insert(0, root)
+from carma_pack_amd._lib import build_ids  # noqa: E402  (which build these counters belong to: bench.py checks it)
+
+IDS = build_ids()
+if os.path.exists(os.path.join(src, "ids.json")):           # stamped on the GPU box at measurement time
+    IDS = json.load(open(os.path.join(src, "ids.json")))
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "kernel_stats_%s.csv" % tag))
     print("copied", f)
@@ -44,6 +50,7 @@ def collect(kern, grid=None, per_iteration=0):
     res["_dispatch"] = disp
     res["_per"] = ("sampler iteration (counters summed over the kernel's dispatches / %d iterations)" % per_iteration) if per_iteration else "launch"
     res["_notes"] = NOTES
+    res["_ids"] = IDS
     return res
 
 
