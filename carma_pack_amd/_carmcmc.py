@@ -142,6 +142,12 @@ class CARMA(CARp):
         super(CARMA, self).__init__(track, label, time, y, yerr, p, temperature, device, _q=q)
 
 
+# CarmaSample post-processing on the device (no counterpart in the reference's binding: there it is Python loops over the
+# samples, carma_pack.py:513-546, 596-623); carma_pack.py calls these through this module like every other compute call
+sigma_noise_batch = _lib.sigma_noise_batch
+psd_band = _lib.psd_band
+
+
 def _pop_max_stdev(y):
     # RunCar*Sampler: var = E[y^2] - E[y]^2 (population), max_stdev = 10 sqrt(var) (carmcmc.cpp:35-40,85-89)
     y = _arr(y)

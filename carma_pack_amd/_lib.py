@@ -139,6 +139,8 @@ def _load():
     L.carma_kf_predict.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp]
     L.carma_simulate_carma.argtypes = [_dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, C.c_int, C.c_uint64, _dp, C.c_int]
     L.carma_simulate_car1.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, _dp, C.c_int]
+    L.carma_sigma_noise_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int]
+    L.carma_psd_band.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int]
     L.carma_pt_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64,
                                _dp, _dp]
     L.carma_pt_create.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64]
@@ -176,7 +178,7 @@ EXPORTS = [
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
     "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_mle_batched", "carma_kfilter_carma",
     "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_normalize_roots", "carma_kf_create_carma", "carma_kf_create_car1",
-    "carma_kf_destroy", "carma_kf_n", "carma_kf_filter", "carma_kf_predict", "carma_simulate_carma", "carma_simulate_car1", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
+    "carma_kf_destroy", "carma_kf_n", "carma_kf_filter", "carma_kf_predict", "carma_simulate_carma", "carma_simulate_car1", "carma_sigma_noise_batch", "carma_psd_band", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_sample_sharded", "carma_pt_boundary_stats",
@@ -560,6 +562,42 @@ def simulate_car1(time, sigsqr, omega, npaths=1, seed=0, device=None):
                                   C.c_uint64(int(seed) & (2 ** 64 - 1)), ptr(out), default_device() if device is None else device),
           "carma_simulate_car1")
     return out
+
+
+def sigma_noise_batch(ar_roots, ma_coefs, var, device=None):
+    """CarmaSample._sigma_noise for all samples in one launch (carma_sigma_noise_batch): ar_roots [ns, p] complex,
+    ma_coefs [ns, nma] lowest order first, var [ns] -> sigma [ns]."""
+    roots = np.atleast_2d(np.asarray(ar_roots, dtype=complex))
+    ns, p = roots.shape
+    om = as_f64(np.stack([roots.real, roots.imag], axis=-1))
+    ma = as_f64(np.atleast_2d(np.asarray(ma_coefs, dtype=float)))
+    v = as_f64(np.ravel(var))
+    if ma.shape[0] != ns or v.size != ns:
+        raise ValueError("sigma_noise_batch: one row of roots, MA coefficients and one variance per sample")
+    out = np.empty(ns)
+    check(lib.carma_sigma_noise_batch(p, ma.shape[1], ptr(om), ptr(ma), ptr(v), ns, ptr(out),
+                                      default_device() if device is None else device), "carma_sigma_noise_batch")
+    return out
+
+
+def psd_band(ar_coefs, ma_coefs, sigma, freq, percentiles, return_samples=False, device=None):
+    """The power spectrum of every sample on `freq` and np.percentile(..., percentiles) over the samples, on the device
+    (carma_psd_band).  ar_coefs [ns, p + 1] highest order first, ma_coefs [ns, nma] lowest first, sigma [ns].
+    Returns band [nf, nperc] (and the grid [nf, ns] with return_samples)."""
+    ar = as_f64(np.atleast_2d(np.asarray(ar_coefs, dtype=float)))
+    ma = as_f64(np.atleast_2d(np.asarray(ma_coefs, dtype=float)))
+    sg = as_f64(np.ravel(sigma))
+    fr = as_f64(np.ravel(freq))
+    pc = as_f64(np.ravel(percentiles))
+    ns = ar.shape[0]
+    if ma.shape[0] != ns or sg.size != ns:
+        raise ValueError("psd_band: one row of AR coefficients, MA coefficients and one sigma per sample")
+    band = np.empty((fr.size, pc.size))
+    grid = np.empty((fr.size, ns)) if return_samples else None
+    check(lib.carma_psd_band(ar.shape[1], ma.shape[1], ptr(ar), ptr(ma), ptr(sg), ns, ptr(fr), fr.size, ptr(pc), pc.size,
+                             ptr(band), ptr(grid) if return_samples else None, default_device() if device is None else device),
+          "carma_psd_band")
+    return (band, grid) if return_samples else band
 
 
 def pt_sample_sharded(contexts, nsamples, thin=1, comm=None):

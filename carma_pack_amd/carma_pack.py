@@ -290,19 +290,10 @@ class CarmaSample(MCMCSample):
         self._samples["ma_coefs"] = (c / c[:, self.q:self.q + 1])[:, ::-1].real
 
     def _sigma_noise(self):
-        roots, ma = self._samples["ar_roots"], self._samples["ma_coefs"]
-        ns, p = roots.shape
-        beta = np.zeros((ns, p))
-        beta[:, :ma.shape[1]] = ma
-        pw = np.arange(p)[None, :]
-        total = np.zeros(ns, dtype=complex)
-        for k in range(p):
-            rk = roots[:, k:k + 1]
-            others = np.delete(roots, k, axis=1)
-            denom = -2.0 * rk[:, 0].real * np.prod((others - rk) * (np.conj(others) + rk), axis=1)
-            num = np.sum(beta * rk ** pw, axis=1) * np.sum(beta * (-rk) ** pw, axis=1)
-            total += num / denom
-        self._samples["sigma"] = np.sqrt(self._samples["var"] / total.real)
+        """sigma of the driving noise per sample = sqrt(var / Variance(roots, ma, 1)) (reference :513-546): one launch for all
+        samples (carma_sigma_noise_batch)."""
+        self._samples["sigma"] = carmcmcLib.sigma_noise_batch(self._samples["ar_roots"], self._samples["ma_coefs"],
+                                                              self._samples["var"])
 
     def add_mle(self, MLE):
         x = np.asarray(MLE.x, dtype=float)
@@ -338,28 +329,23 @@ class CarmaSample(MCMCSample):
             return np.arange(nsamples0)
         return (np.arange(nsamples) * (nsamples0 / nsamples)).astype(int)
 
-    def _psd_samples(self, frequencies, index):
-        """sigma^2 |delta(2 pi i f)|^2 / |alpha(2 pi i f)|^2 for every (frequency, sample) pair (reference :601-618),
-        by Horner's rule on the whole [nfreq, nsamples] grid."""
-        sig = np.squeeze(self._samples["sigma"][index], axis=-1) if self._samples["sigma"].ndim > 1 else self._samples["sigma"][index]
-        ar, ma = self._samples["ar_coefs"][index], self._samples["ma_coefs"][index]
-        om = (2.0j * np.pi * np.asarray(frequencies, dtype=float))[:, None]
-        ar_poly = np.zeros((om.shape[0], ar.shape[0]), dtype=complex)
-        for k in range(ar.shape[1]):                    # ar_coefs: highest order first
-            ar_poly = ar_poly * om + ar[None, :, k]
-        ma_poly = np.zeros_like(ar_poly)
-        for k in range(ma.shape[1] - 1, -1, -1):        # ma_coefs: lowest order first
-            ma_poly = ma_poly * om + ma[None, :, k]
-        return sig[None, :] ** 2 * np.abs(ma_poly) ** 2 / np.abs(ar_poly) ** 2
+    def _psd_inputs(self, index):
+        sig = np.ravel(self._samples["sigma"])[index]
+        return self._samples["ar_coefs"][index], self._samples["ma_coefs"][index], sig
 
-    def _psd_credint(self, percentile, nsamples, frequencies, chunk=64):
+    def _psd_samples(self, frequencies, index):
+        """sigma^2 |delta(2 pi i f)|^2 / |alpha(2 pi i f)|^2 for every (frequency, sample) pair (reference :601-618): the
+        [nfreq, nsamples] grid from the device (carma_psd_band without percentiles)."""
+        ar, ma, sig = self._psd_inputs(index)
+        return carmcmcLib.psd_band(ar, ma, sig, frequencies, [], return_samples=True)[1]
+
+    def _psd_credint(self, percentile, nsamples, frequencies):
+        """(lower, median, upper) of the spectrum over the samples at every frequency (reference :596-623): grid and
+        percentiles on the device, one call (carma_psd_band)."""
         index = self._subsample(nsamples, self._samples["sigma"].shape[0])
         lower = (100.0 - percentile) / 2.0
-        out = np.empty((frequencies.size, 3))
-        for f0 in range(0, frequencies.size, chunk):     # bounded memory: chunk x nsamples complex values at a time
-            psd = self._psd_samples(frequencies[f0:f0 + chunk], index)
-            out[f0:f0 + chunk] = np.percentile(psd, [lower, 50.0, 100.0 - lower], axis=1).T
-        return out
+        ar, ma, sig = self._psd_inputs(index)
+        return carmcmcLib.psd_band(ar, ma, sig, frequencies, [lower, 50.0, 100.0 - lower])
 
     def plot_power_spectrum(self, percentile=68.0, nsamples=None, plot_log=True, color="b", alpha=0.5, sp=None,
                             doShow=True):
@@ -484,10 +470,8 @@ class Car1Sample(CarmaSample):
                                       carmcmcLib.vecD(self.ysig), float(sigsqr), float(np.exp(log_omega)))
         return kf, float(mu)
 
-    def _psd_samples(self, frequencies, index):
-        """sigma^2 / (omega^2 + (2 pi f)^2) (reference :1004-1013)."""
-        sig, lw = np.ravel(self._samples["sigma"])[index], np.ravel(self._samples["log_omega"])[index]
-        return sig[None, :] ** 2 / (np.exp(lw)[None, :] ** 2 + (2.0 * np.pi * np.asarray(frequencies)[:, None]) ** 2)
+    # (the spectrum sigma^2 / (omega^2 + (2 pi f)^2) of the reference (:1004-1013) is the general formula with
+    # alpha(s) = s + omega, delta = 1 -- the arrays generate_from_trace stores -- so CarmaSample's device path serves it)
 
 
 # ------------------------------------------------------------------------------------------------

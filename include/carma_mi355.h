@@ -163,6 +163,28 @@ int carma_simulate_car1(const double* time, int n, double sigsqr, double omega, 
                         double* out, int device);
 
 /*
+ * CarmaSample post-processing (src/carmcmc/carma_pack.py), one launch per quantity instead of a
+ * Python loop over the MCMC samples.
+ *
+ * carma_sigma_noise_batch == CarmaSample._sigma_noise (carma_pack.py:513-546; the Python twin of CARp::Variance,
+ *   src/carpack.cpp:377-409, with sigma = 1): sigma[s] = sqrt(var[s] / Variance(roots_s, ma_s, 1)) for ns samples.
+ *   ar_roots_re_im = [ns][p][2], ma_coefs = [ns][nma] (lowest order first, nma <= p), var = [ns]; all host pointers.
+ *   A sample whose variance sum is not positive gives NaN, as numpy's sqrt does.
+ *
+ * carma_psd_band == the numbers behind CarmaSample.plot_power_spectrum (carma_pack.py:548-648) and
+ *   Car1Sample.plot_power_spectrum (:950-1035): psd[f][s] = sigma_s^2 |delta_s(2 pi i f)|^2 / |alpha_s(2 pi i f)|^2 on the
+ *   nf x ns grid, then np.percentile(psd, percentiles, axis=samples) -- the exact order statistics, numpy's default linear
+ *   interpolation.  ar_coefs = [ns][nar] highest order first (np.poly order, nar = p + 1), ma_coefs = [ns][nma] lowest
+ *   order first, sigma = [ns], freq = [nf]; band = [nf][nperc] (nperc <= 4; 0: grid only); psd_samples = NULL or
+ *   [nf][ns] for the grid itself.  A NaN in a row makes that row's percentiles NaN (np.percentile).
+ */
+int carma_sigma_noise_batch(int p, int nma, const double* ar_roots_re_im, const double* ma_coefs, const double* var, int ns,
+                            double* sigma, int device);
+int carma_psd_band(int nar, int nma, const double* ar_coefs, const double* ma_coefs, const double* sigma, int ns,
+                   const double* freq, int nf, const double* percentiles, int nperc, double* band, double* psd_samples,
+                   int device);
+
+/*
  * Parallel-tempered Robust-Adaptive-Metropolis sampler == RunCarmaSampler / RunCar1Sampler
  * (src/carmcmc.cpp:30-177; bindings run_mcmc_car1 / run_mcmc_carma, boost_python_wrapper.cpp:76-77)
  * with every chain advanced on the GPU by one persistent kernel (carma_pt.hip).

@@ -3,6 +3,7 @@
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
 import this package.  ``carma_pack_amd`` (the product) never does.
 """
+from . import post  # noqa: F401  (CarmaSample post-processing restated in numpy)
 from .oracle import (  # noqa: F401
     NativeComparator,
     OracleModel,

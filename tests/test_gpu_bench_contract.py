@@ -45,7 +45,19 @@ def test_single_gpu_line():
     # the kernel label comes from the library's own launch table, the counters from a profile of that very kernel
     assert rf["kernel"] == "k_logdens_carma_p3l<5>" and rf["binding_resource"] == "fp64_valu_issue"
     assert rf["traffic"] is None or (rf["traffic_source"] and rf["traffic"] < rf["algorithmic_bytes_per_launch"])
-    assert 0.0 < rf["fp64_valu"]["frac"] < 1.0
+    # no fraction on the line may exceed 1, and counters are attached only when they were measured on the running build
+    def fracs(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k == "frac" or k.endswith("_frac"):
+                    assert v is None or 0.0 <= v <= 1.0, (path + "/" + k, v)
+                fracs(v, path + "/" + k)
+    fracs(j)
+    assert j["build"]["build_id"] and j["rccl_first_contact"]["verdict"] == "one rank: no exchange"
+    assert len(j["ranks"]) == 1 and j["ranks"][0]["device_ordinal"] == 0
+    for blk in (rf["pmc_per_launch"], j["mcmc"]["pmc_per_iteration"], j["throughput"]["pmc_per_launch"]):
+        assert blk is None or "SQ_INSTS_VALU" not in blk or blk["measured_on"]["source_id"] == j["build"]["source_id"] \
+            or blk["measured_on"]["build_id"] == j["build"]["build_id"]
     tp, ld = j["throughput"], j["ladder_sharded"]
     assert tp["batch_per_gpu"] == 65536 and tp["kernel"] == "k_logdens_carma_lane<5>" and tp["evals_per_s"] > j["value"]
     assert ld["temperatures"] == 8 and ld["replicas"] == 128 and ld["rccl_ranks"] == 1 and ld["iters_per_s"] > 0
@@ -60,6 +72,7 @@ def test_two_ranks_sharing_the_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert KEYS <= set(j) and "cpu_baseline" not in j                      # CPU leg runs on rank 0 at N=1 only
+    assert [r_["rank"] for r_ in j["ranks"]] == [0, 1] and j["rccl_first_contact"]["verdict"] == "ok", j["rccl_first_contact"]
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["finite_in_last_batch"] == 1024
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 2 * 1024) < 1e-6 * 2048          # whole-job aggregate
     ld = j["ladder_sharded"]                                                 # one ladder of 8 temperatures, 4 per rank

@@ -12,6 +12,42 @@ import oracle as orc
 from carma_pack_amd import carma_pack as cp
 
 
+@pytest.fixture(autouse=True)
+def _post_processing_stand_in(monkeypatch):
+    """CarmaSample computes sigma and the PSD band on the device (carma_post.hip).  Without a GPU the two compute hooks of
+    the `_carmcmc` mirror are replaced by the oracle's numpy restatement, so that the HOST logic of the classes
+    (dictionary, sub-sampling, return contracts) is still exercised here -- and the restatement itself is held to the
+    reference's own output by the golden files below.  With a GPU the product's own path runs."""
+    if cpa._lib.lib.carma_device_count() == 0:
+        monkeypatch.setattr(cp.carmcmcLib, "sigma_noise_batch", orc.post.sigma_noise)
+        monkeypatch.setattr(cp.carmcmcLib, "psd_band", orc.post.psd_band)
+
+
+def test_post_processing_hooks_fail_loudly_without_a_gpu():
+    if cpa._lib.lib.carma_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from carma_pack_amd import _lib
+    with pytest.raises(cpa.CarmaDeviceError):
+        _lib.sigma_noise_batch(np.array([[-0.1 + 0.2j, -0.1 - 0.2j]]), np.array([[1.0]]), np.array([1.0]))
+    with pytest.raises(cpa.CarmaDeviceError):
+        _lib.psd_band(np.array([[1.0, 0.2, 0.05]]), np.array([[1.0]]), np.array([1.0]), [0.1, 0.2], [16.0, 50.0, 84.0])
+    with pytest.raises(ValueError):                            # argument checks come before any device work
+        _lib.psd_band(np.array([[1.0, 0.2, 0.05]]), np.array([[1.0]]), np.array([1.0]), [0.1], [16.0, 50.0, 84.0, 1.0, 2.0])
+
+
+def test_numpy_restatement_of_the_roots_is_the_reference_formula(golden_dir):
+    """oracle.post.roots_from_log_quads is carma_pack.py:439-468 literally; the product takes the smaller of two REAL roots
+    from the product q1 / big root instead (as the kernels do) -- identical for complex pairs, and to rounding otherwise."""
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    th = g["theta"]
+    np.testing.assert_allclose(orc.post.roots_from_log_quads(th[:, 3:8]), g["omega"], rtol=1e-13)
+    np.testing.assert_allclose(cp._roots_from_log_quads(th[:, 3:8]), orc.post.roots_from_log_quads(th[:, 3:8]), rtol=1e-13)
+    lq = np.log(np.array([[0.02, 0.5, 0.3], [1e-3, 4.0, 0.1]]))           # two real roots per quadratic factor
+    a, b = cp._roots_from_log_quads(lq), orc.post.roots_from_log_quads(lq)
+    assert np.all(a.imag == 0) and np.all(b.imag == 0)
+    np.testing.assert_allclose(a, b, rtol=1e-10)
+
+
 def test_alias_package_exports():
     for name in ("vecD", "vecvecD", "vecC", "pairD", "CAR1", "CARp", "CARMA", "run_mcmc_car1", "run_mcmc_carma",
                  "KalmanFilter1", "KalmanFilterp", "CarmaModel", "CarmaSample", "Car1Sample", "get_ar_roots",
