@@ -8,7 +8,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 objs=""
-for f in carma_kernels carma_pt carma_capi carma_pt_host carma_shard carma_mle carma_post; do
+for f in carma_kernels carma_pt carma_capi carma_pt_host carma_shard carma_mle carma_post carma_pt_lane; do
   if [ ! -f build/$f.o ] || [ -n "$(find $SRC include -newer build/$f.o -type f | head -1)" ]; then
     $HIPCC $FLAGS -c $SRC/$f.hip -o build/$f.o
   fi

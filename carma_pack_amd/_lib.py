@@ -369,8 +369,9 @@ class Context:
         return acc, swp
 
     def pt_kernel(self):
-        """"row" (k_pt_row) or "ladder" (k_pt): the sampler kernel this context is on (carma_pt_kernel_in_use)."""
-        return "row" if lib.carma_pt_kernel_in_use(self._h) == 1 else "ladder"
+        """"row" (k_pt_row), "ladder" (k_pt) or "lane" (k_pt_lane, large ensembles): the sampler kernel this context is on
+        (carma_pt_kernel_in_use)."""
+        return {1: "row", 2: "lane"}.get(lib.carma_pt_kernel_in_use(self._h), "ladder")
 
     def pt_iterations_done(self):
         return lib.carma_pt_iterations_done(self._h)

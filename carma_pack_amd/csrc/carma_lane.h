@@ -182,6 +182,28 @@ struct LaneFactorsInline {
     }
 };
 
+// LaneFactorsParked: as LaneFactorsInline, with the AR roots PARKED IN MEMORY (LDS: w[0..P) real parts, w[P..2P) imaginary
+// parts of this lane's roots) instead of 4 P registers held through the whole recursion -- for callers that have other
+// state to keep alive around the filter (the lane-per-chain sampler, carma_pt_lane.hip): 2 P LDS reads per NEW time step
+// against a spill inside the loop.
+template <int P>
+struct LaneFactorsParked {
+    const double* w;
+    bool rp[(P + 1) / 2];
+    bool anyreal;
+    CARMA_DEV void step(int) const {}
+    CARMA_DEV void get(int, double dt, double (&cr)[P], double (&sr)[P]) const
+    {
+        double wre[P], wim[P];
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            wre[r] = w[r];
+            wim[r] = w[P + r];
+        }
+        lane_factors<P>(wre, wim, rp, anyreal, dt, cr, sr);
+    }
+};
+
 #if defined(__HIPCC__)
 // LaneFactorsRing: PRODUCER WAVES compute them (lane_produce: lane l of a producer serves lane l of its consumer) into a
 // two-buffer LDS ring, CH steps per buffer, one workgroup barrier per CH steps; with NP producers per consumer, producer k
@@ -389,6 +411,32 @@ CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __re
 #pragma unroll
     for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
     const LaneFactorsInline<P> src{m, lane_any(anyreal)};
+    double ll = lane_filter<P>(m, series, n, src);
+    ll += log_prior(m.scale, pr.measerr_dof);
+    if (m.sing || !m.valid) ll = -1.0 / 0.0;
+    return ll;
+}
+
+// the same with the roots parked in `park` (2 P doubles of this lane's own memory) during the recursion
+template <int P>
+CARMA_DEV double logdensity_lane_parked(const double* theta, int q, const double4* __restrict__ series, int n, const Prior& pr,
+                                        int ignore_prior, double* park)
+{
+    LaneModel<P> m;
+    lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
+    LaneFactorsParked<P> src;
+    src.w = park;
+    bool anyreal = false;
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        park[r] = m.wre[r];
+        park[P + r] = m.wim[r];
+    }
+#pragma unroll
+    for (int i = 0; i < (P + 1) / 2; i++) src.rp[i] = m.realpair[i];
+#pragma unroll
+    for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
+    src.anyreal = lane_any(anyreal);
     double ll = lane_filter<P>(m, series, n, src);
     ll += log_prior(m.scale, pr.measerr_dof);
     if (m.sing || !m.valid) ll = -1.0 / 0.0;

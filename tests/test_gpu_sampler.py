@@ -169,6 +169,67 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
     np.testing.assert_array_equal(b[5], a[5])
 
 
+@pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1), (3, 1, 1, 5), (4, 2, 17, 2),
+                                     (2, 0, 33, 1), (3, 2, 64, 1), (5, 3, 16, 9), (6, 2, 7, 40), (5, 0, 16, 130)])
+@pytest.mark.parametrize("kern", ["lane", "lane3"])
+def test_lane_kernel_walks_the_ladder_kernels_trajectory(cpa, p, q, T, R, kern, monkeypatch):
+    """k_pt_lane (one chain per LANE, the sweep inside the wave; "lane3": with producer waves for the transition factors)
+    against k_pt from the same seed and start: same Philox keys, same formulas in the same order -- the same accept and
+    swap decisions, chain states and saved samples equal to rounding.  Ladder lengths that do and do not divide 64 (idle
+    lanes, ladders that end in the middle of a wave's last ladder slot), one ladder per wave (T = 33, 64), more ladders
+    than one wave holds."""
+    from helpers import irregular_series
+    t, y, yerr = irregular_series(80 - 3 * (p % 2), seed=70 + p)
+    ms = _pop_stdev(y)
+    res = {}
+    for k in ("ladder", kern):
+        monkeypatch.setenv("CARMA_PT_KERNEL", k)
+        ctx = cpa.Context(t, y, yerr, p, q, max_stdev=ms)
+        ctx.pt_create(T, R, adapt_iters=120, seed=77)
+        ctx.pt_start(None)
+        ctx.pt_iterate(150)
+        smp, slp = ctx.pt_sample(40, thin=2)
+        th, lp = ctx.pt_get_chains()
+        acc, swp = ctx.pt_stats()
+        assert ctx.pt_kernel() == ("lane" if k != "ladder" else "ladder")
+        res[k] = (th, lp, smp, slp, acc, swp)
+    a, b = res["ladder"], res[kern]
+    np.testing.assert_array_equal(b[4], a[4])                # acceptance counts: every Metropolis decision the same
+    np.testing.assert_array_equal(b[5], a[5])                # swap counts
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-9)
+    for i in (1, 3):
+        rel = np.abs(b[i] - a[i]) / np.abs(a[i])
+        assert rel.max() <= 1e-6 and np.mean(rel > 1e-8) <= 1e-3, (rel.max(), np.mean(rel > 1e-8))
+
+
+def test_lane_kernel_is_the_choice_for_large_ensembles(cpa, monkeypatch):
+    """Dispatch by chain count (carma_pt_create): small ensembles keep the row / ladder kernels, tens of thousands of
+    chains take one chain per lane; the stored log-posterior of every chain equals the oracle's LogDensity of its state."""
+    from helpers import irregular_series
+    monkeypatch.delenv("CARMA_PT_KERNEL", raising=False)
+    t, y, yerr = irregular_series(60, seed=5)
+    ms = _pop_stdev(y)
+    ctx = cpa.Context(t, y, yerr, 3, 1, max_stdev=ms)
+    ctx.pt_create(8, 16, adapt_iters=50, seed=3)
+    assert ctx.pt_kernel() in ("row", "ladder")
+    ctx.pt_create(8, 2048, adapt_iters=50, seed=3)           # 16 384 chains: producer waves
+    assert ctx.pt_kernel() == "lane"
+    ctx.pt_create(8, 4096 + 3, adapt_iters=50, seed=3)       # 32 792 chains: one chain per lane, a ragged last wave
+    assert ctx.pt_kernel() == "lane"
+    ctx.pt_start(None)
+    ctx.pt_iterate(30)
+    th, lp = ctx.pt_get_chains()
+    acc, swp = ctx.pt_stats()
+    assert 0.05 < acc.mean() < 0.8 and swp[:, 1:].mean() > 0.02
+    m = orc.OracleModel(t, y, yerr, 3, 1, max_stdev=ms)
+    idx = np.random.default_rng(0).choice(th.shape[0] * 8, 3000, replace=False)
+    flat, flp = th.reshape(-1, 7)[idx], lp.reshape(-1)[idx]
+    from helpers import assert_parity, loglik_truth
+    assert_parity(flp, m.logdensity_batch(flat, nthreads=os.cpu_count() or 8), 1e-10, "lane sampler chain states",
+                  arbiter=lambda i: loglik_truth(t, y, yerr, flat[i], 3, 1)[0], max_arb_frac=0.02)
+
+
 def test_gpu_sampler_matches_literal_cpu_sampler(cpa):
     """Distributional parity of A9-A11: the GPU sampler (all RAM steps of an iteration concurrently,
     then the swap sweep; Philox) against the oracle's literal restatement of the reference's sampler
