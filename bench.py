@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mcmc", action="store_true", help="skip the secondary MCMC iterations/s leg")
     ap.add_argument("--mcmc-iters", type=int, default=2000)
+    ap.add_argument("--no-mcmc-large", action="store_true", help="skip the large-ensemble sampler leg (16 x 4096 ladders)")
     ap.add_argument("--graph", action="store_true", help="replay the steps as a hipGraph instead of launching each directly "
                     "(measured: 34.43 vs 34.66 us per step -- the gap between dependent kernels is not the host's)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight leg")
@@ -179,6 +180,35 @@ def main():
             "evals_per_s": world * BT * NT / tq, "batch_per_gpu": BT, "launches": NT, "kernel": ctx.kernel_name(BT),
             "kernel_avg_us": k_us,
         }
+
+    # ---- the sampler with a LARGE ensemble (before the configs[2]-shape leg, which stays last: see ORDER OF THE LEGS): 16 temperatures x 4096 ladders = 65 536 chains per GPU, one chain per lane,
+    # an iteration = propose kernel + the batched log-density launch + finish kernel (carma_pt_lane.hip)
+    mcmc_large = None
+    if not args.no_mcmc and not args.no_mcmc_large:
+        T_, R_, IT_ = 16, 4096, 60
+        big_ctx = cpa.Context(t, y, yerr, p, q, max_stdev=max_stdev, device=dev_index)
+        big_ctx.pt_create(T_, R_, adapt_iters=10 ** 9, seed=13 + rank)
+        big_ctx.pt_shard(T_, 0, rank * R_)
+        big_ctx.pt_start(None)
+        big_ctx.pt_iterate(10)
+        barrier()
+        tm0 = time.perf_counter()
+        big_ctx.pt_iterate(IT_)
+        barrier()
+        tm = time.perf_counter() - tm0
+        if dist is not None:
+            tt = torch.tensor([tm], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tm = float(tt.item())
+        acc_, swp_ = big_ctx.pt_stats()
+        mcmc_large = {
+            "metric": "MCMC iterations/s, large ensemble (each iteration advances every chain once)",
+            "iters_per_s": IT_ / tm, "chain_evals_per_s": world * T_ * R_ * IT_ / tm, "us_per_iteration": 1e6 * tm / IT_,
+            "temperatures": T_, "replicas_per_gpu": R_, "chains_per_gpu": T_ * R_, "iters": IT_, "sampler": big_ctx.pt_kernel(),
+            "log_density_kernel": big_ctx.kernel_name(T_ * R_),
+            "accept_rate": float(acc_.mean()), "swap_rate": float(swp_[:, 1:].mean()),
+        }
+        del big_ctx
 
     # ---- secondary metric: MCMC iterations/s, BASELINE configs[2] shape ------------------------
     # 16 temperatures x 64 independent ladders ("walkers") per GPU, persistent PT kernel; one
@@ -341,6 +371,8 @@ def main():
         }
         if mcmc is not None:
             res["mcmc"] = mcmc
+        if mcmc_large is not None:
+            res["mcmc_large"] = mcmc_large
         if pipelined is not None:
             res["pipelined"] = pipelined
         if tput is not None:

@@ -32,9 +32,9 @@ struct PtState {
     unsigned long long epoch = 0;               // launches so far (PtRowSync::epoch)
     unsigned* d_abort = nullptr;
     double* d_backup = nullptr;         // chain state before the chunk in flight (theta, logpost, chol): abort recovery
-    // lane-per-chain kernel (k_pt_lane, large ensembles): -1 = not in use, 0 = chain waves only, 3 = with producer waves
-    int lane_np = -1;
-    double* d_lane_scratch = nullptr;   // chain-minor state rows (current value, R^T z, packed factor)
+    // large ensembles (carma_pt_lane.hip): one chain per lane, an iteration as propose kernel + batched log-density + finish kernel
+    bool use_lane = false;
+    double* d_lane_scratch = nullptr;   // chain-minor working state (current value, R^T z, packed factor, proposals, ...)
     // ladder sharded across ranks (carma_shard.hip): boundary staging and statistics
     double *d_send = nullptr, *d_recv = nullptr;       // [R][d+1] each
     unsigned* d_bnd_swaps = nullptr;                   // [1] accepted boundary swaps (this block's side)

@@ -48,12 +48,12 @@ hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const dou
                          const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
                          unsigned* nswap, double* samples, double* sample_lp, hipStream_t st);
 
-// lane-per-chain sampler for large ensembles (carma_pt_lane.hip): a ladder's T <= 64 chains are T consecutive lanes;
-// np = 0: one chain wave per 64 lanes, np = 3: plus three producer waves for its transition factors.
-// scratch: pt_lane_scratch_doubles(p, T * R) doubles of device memory (chain-minor state rows)
-size_t pt_lane_scratch_doubles(int p, long nchain);
-hipError_t launch_pt_lane(int p, const PtLaunch& L, int np, double* scratch, const double4* series, const Prior& pr,
+// sampler for large ensembles (carma_pt_lane.hip): one chain per lane, an iteration = propose kernel + the batched
+// log-density launch above + finish kernel; a ladder's T <= 64 chains are T consecutive lanes.  Enqueues L.niter
+// iterations on st.  scratch: pt_lane_scratch_doubles(d, T * R) doubles of device memory (chain-minor working state).
+size_t pt_lane_scratch_doubles(int d, long nchain);
+hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const double4* series, const Prior& pr,
                           const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
-                          unsigned* nswap, double* samples, double* sample_lp, hipStream_t st);
+                          unsigned* nswap, double* samples, double* sample_lp, bool repeated_dt, hipStream_t st);
 
 }  // namespace carma

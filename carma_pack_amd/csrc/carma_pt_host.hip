@@ -75,8 +75,8 @@ static int chunk_iters(const Ctx* c)
         const double est_us = std::max(1.0, 0.14 * c->n);
         return (int)std::max(1.0, std::min(16384.0, 500000.0 / est_us));
     }
-    if (c->pt && c->pt->lane_np >= 0) {                   // one chain per lane: ~0.7 us per datum per iteration at one wave per SIMD
-        const double est_us = std::max(1.0, 0.7 * c->n);
+    if (c->pt && c->pt->use_lane) {                       // large ensembles: >= ~0.45 us per datum per iteration, 3 launches each
+        const double est_us = std::max(1.0, 0.45 * c->n);
         return (int)std::max(1.0, std::min(4096.0, 250000.0 / est_us));
     }
     const double est_us = std::max(1.0, 0.8 * c->n * (c->p >= 5 ? 1.0 : 0.5));
@@ -175,9 +175,9 @@ static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save
             s->use_row = false;
         }
     }
-    if (!s->use_row && s->lane_np >= 0) {
-        e = launch_pt_lane(c->p, L, s->lane_np, s->d_lane_scratch, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps,
-                           s->d_theta, s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
+    if (!s->use_row && s->use_lane) {
+        e = launch_pt_lane(c->p, L, s->d_lane_scratch, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta,
+                           s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->repeated_dt, st);
     } else if (!s->use_row) {
         e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
                       s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
@@ -344,30 +344,21 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     // Kernel choice.  The row variant needs every workgroup of the grid resident at the same time
     // (its swap step is a cross-workgroup rendezvous); otherwise one workgroup per ladder (k_pt).
     // CARMA_PT_KERNEL=ladder|row overrides (row only where it is safe).
-    // Large ensembles: ONE CHAIN PER LANE (k_pt_lane).  From lane_min chains on the SIMDs hold a chain wave each anyway
-    // and a lane is the cheapest place for a chain; between lpc_min and lane_min three producer waves per chain wave take
-    // the exp / sincos off the chain waves' instruction streams (measured: tools/mcmc_bigR_probe.py, profiles/r04/).
-    // CARMA_PT_KERNEL=lane|lane3 forces it (T <= 64, p >= 2), CARMA_TUNE_PT_LANE_MIN / _LPC_MIN move the thresholds.
+    // Large ensembles: ONE CHAIN PER LANE, an iteration as propose kernel + batched log-density launch + finish kernel
+    // (carma_pt_lane.hip).  From lane_min chains on the batched launch beats what the persistent kernels get out of a chain
+    // (measured: tools/mcmc_lane_probe.py, profiles/r04/).  CARMA_PT_KERNEL=lane forces it (T <= 64, p >= 2),
+    // CARMA_TUNE_PT_LANE_MIN moves the threshold.
     const char* force = getenv("CARMA_PT_KERNEL");
     if (e == hipSuccess && c->p >= 2 && ntemps <= 64) {
-        auto tune = [](const char* name, long dflt) {
-            const char* v = getenv(name);
-            return v ? atol(v) : dflt;
-        };
-        const long cus = device_cus();
-        const long lane_min = tune("CARMA_TUNE_PT_LANE_MIN", 64L * 4 * cus / 2);      // half a chain wave per SIMD: 32 768 chains on 256 CUs
-        const long lpc_min = tune("CARMA_TUNE_PT_LPC_MIN", 64L * cus * 3 / 4);        // 12 288 chains
-        int np = -1;
-        if (force && std::strcmp(force, "lane") == 0) np = 0;
-        else if (force && std::strcmp(force, "lane3") == 0) np = 3;
-        else if (!force && (long)nchain >= lane_min) np = 0;
-        else if (!force && (long)nchain >= lpc_min) np = 3;
-        if (np >= 0) {
-            s->lane_np = np;
-            e = hipMalloc(&s->d_lane_scratch, sizeof(double) * pt_lane_scratch_doubles(c->p, (long)nchain));
+        const char* tv = getenv("CARMA_TUNE_PT_LANE_MIN");
+        const long lane_min = tv ? atol(tv) : 48L * device_cus();             // 12 288 chains on 256 CUs
+        const bool forced = force && std::strcmp(force, "lane") == 0;
+        if (forced || (!force && (long)nchain >= lane_min)) {
+            s->use_lane = true;
+            e = hipMalloc(&s->d_lane_scratch, sizeof(double) * pt_lane_scratch_doubles(d, (long)nchain));
         }
     }
-    if (e == hipSuccess && c->p >= 2 && s->lane_np < 0) {
+    if (e == hipSuccess && c->p >= 2 && !s->use_lane) {
         const int wpl = (ntemps + 3) / 4;
         const long cap = pt_row_capacity(c->p, d, ntemps, c->n);
         const bool want = !(force && std::strcmp(force, "ladder") == 0);
@@ -605,7 +596,7 @@ int carma_pt_kernel_in_use(const carma_ctx* h)
 {
     if (!h || !reinterpret_cast<const Ctx*>(h)->pt) return CARMA_EINVAL;
     const PtState* s = reinterpret_cast<const Ctx*>(h)->pt;
-    return s->use_row ? 1 : (s->lane_np >= 0 ? 2 : 0);
+    return s->use_row ? 1 : (s->use_lane ? 2 : 0);
 }
 
 long carma_pt_iterations_done(const carma_ctx* h)

@@ -227,7 +227,8 @@ int carma_pt_sample(carma_ctx* h, int nsamples, int thin, double* samples, doubl
 int carma_pt_stats(carma_ctx* h, double* accept_rate, double* swap_rate, int reset);
 long carma_pt_iterations_done(const carma_ctx* h);
 /* which sampler kernel the context is on: 1 = k_pt_row (one chain per DPP row, ladders spread over workgroups), 0 = k_pt
- * (one workgroup per ladder), 2 = k_pt_lane (one chain per lane, large ensembles).  A context created on k_pt_row drops to
+ * (one workgroup per ladder), 2 = one chain per lane with an iteration as propose kernel + batched log-density launch +
+ * finish kernel (carma_pt_lane.hip: ensembles of tens of thousands of chains, ladders of at most 64 temperatures).  A context created on k_pt_row drops to
  * k_pt -- silently -- when a cooperative launch is refused or a cross-workgroup exchange times out; tests assert that it
  * did not.  The kernels draw from the same Philox keys and take the same accept / swap decisions, but round the RAM
  * update and the log-density differently (launch shapes of the same evaluation, 1e-8 apart at most on well-conditioned

@@ -171,11 +171,12 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
 
 @pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1), (3, 1, 1, 5), (4, 2, 17, 2),
                                      (2, 0, 33, 1), (3, 2, 64, 1), (5, 3, 16, 9), (6, 2, 7, 40), (5, 0, 16, 130)])
-@pytest.mark.parametrize("kern", ["lane", "lane3"])
+@pytest.mark.parametrize("kern", ["lane"])
 def test_lane_kernel_walks_the_ladder_kernels_trajectory(cpa, p, q, T, R, kern, monkeypatch):
-    """k_pt_lane (one chain per LANE, the sweep inside the wave; "lane3": with producer waves for the transition factors)
-    against k_pt from the same seed and start: same Philox keys, same formulas in the same order -- the same accept and
-    swap decisions, chain states and saved samples equal to rounding.  Ladder lengths that do and do not divide 64 (idle
+    """The sampler for large ensembles (carma_pt_lane.hip: one chain per LANE, an iteration = propose kernel + batched
+    log-density launch + finish kernel with the sweep inside the wave) against k_pt from the same seed and start: same
+    Philox keys, same formulas in the same order -- the same accept and swap decisions, chain states and saved samples
+    equal to rounding.  Ladder lengths that do and do not divide 64 (idle
     lanes, ladders that end in the middle of a wave's last ladder slot), one ladder per wave (T = 33, 64), more ladders
     than one wave holds."""
     from helpers import irregular_series
@@ -213,7 +214,7 @@ def test_lane_kernel_is_the_choice_for_large_ensembles(cpa, monkeypatch):
     ctx = cpa.Context(t, y, yerr, 3, 1, max_stdev=ms)
     ctx.pt_create(8, 16, adapt_iters=50, seed=3)
     assert ctx.pt_kernel() in ("row", "ladder")
-    ctx.pt_create(8, 2048, adapt_iters=50, seed=3)           # 16 384 chains: producer waves
+    ctx.pt_create(8, 2048, adapt_iters=50, seed=3)           # 16 384 chains
     assert ctx.pt_kernel() == "lane"
     ctx.pt_create(8, 4096 + 3, adapt_iters=50, seed=3)       # 32 792 chains: one chain per lane, a ragged last wave
     assert ctx.pt_kernel() == "lane"

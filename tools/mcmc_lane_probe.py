@@ -1,5 +1,5 @@
 """MCMC iterations/s of large ensembles (16 temperatures, CARMA(5,3), n = 270) per sampler kernel: the ladder kernel k_pt,
-one chain per lane (k_pt_lane), one chain per lane with producer waves.  LANE_PROBE_R: replica counts."""
+one chain per lane with an iteration as three launches (carma_pt_lane.hip).  LANE_PROBE_R: replica counts."""
 import os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,5 +24,5 @@ if len(sys.argv) > 1:
     sys.exit(0)
 Rs = [int(x) for x in os.environ.get("LANE_PROBE_R", "256,512,768,1024,1536,2048,3072,4096,8192").split(",")]
 for R in Rs:
-    for kern in os.environ.get("LANE_PROBE_KERNELS", "ladder,lane3,lane,auto").split(","):
+    for kern in os.environ.get("LANE_PROBE_KERNELS", "ladder,lane,auto").split(","):
         subprocess.run([sys.executable, os.path.abspath(__file__), kern, str(R)])
