@@ -162,10 +162,13 @@ __global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restr
                                                           const double4* __restrict__ series, int n, Prior pr,
                                                           int ignore_prior, double* __restrict__ out)
 {
+    __shared__ double s_tab[MATH_TAB_N];                     // tables of the table-based exp / sincos (carma_math.h)
+    math_tab_fill(s_tab);
+    __syncthreads();
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e < B;
     if (!live) e = B - 1;
-    const double ll = logdensity_lane<P>(theta + e * d, q, series, n, pr, ignore_prior);
+    const double ll = logdensity_lane<P>(theta + e * d, q, series, n, pr, ignore_prior, s_tab);
     if (live) out[e] = ll;
 }
 
@@ -190,8 +193,11 @@ __global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restr
     const bool live = e < B;
     if (!live) e = B - 1;
     double* ring = lpc_ring + cons * Geo::DOUBLES + lane;
+    __shared__ double s_tab[MATH_TAB_N];                     // tables of the table-based exp / sincos (carma_math.h)
+    math_tab_fill(s_tab);
+    __syncthreads();
     if (part >= Geo::NC) {
-        lane_produce<P, NP>((part - Geo::NC) % NP, theta + e * d, ring, series, n);
+        lane_produce<P, NP>((part - Geo::NC) % NP, theta + e * d, ring, series, n, s_tab);
         return;
     }
     const double ll = logdensity_lane_ring<P, NP>(theta + e * d, q, series, n, pr, ignore_prior, ring);

@@ -145,15 +145,17 @@ CARMA_DEV bool lane_any(bool b)
 #endif
 }
 
-// Transition factors of one step, per coordinate: one exp/sincos per PAIR (the members are conjugates), one exp per real root
+// Transition factors of one step, per coordinate: one exp/sincos per PAIR (the members are conjugates), one exp per real root.
+// Round 4: the table-based forms of carma_math.h (tab: the 160 table entries, in LDS on the device) -- 45 instead of 65
+// instructions per complex exponential, which were 46 % of this kernel's instruction stream.
 template <int P>
 CARMA_DEV void lane_factors(const double (&wre)[P], const double (&wim)[P], const bool (&realpair)[(P + 1) / 2], bool anyreal,
-                            double dt, double (&cr)[P], double (&sr)[P])
+                            double dt, double (&cr)[P], double (&sr)[P], const double* tab)
 {
 #pragma unroll
     for (int i = 0; i < P / 2; i++) {
         double c, s;
-        cexp_step(wre[2 * i], wim[2 * i], dt, &c, &s);
+        cexp_step_tab(wre[2 * i], wim[2 * i], dt, &c, &s, tab);
         cr[2 * i] = c;
         sr[2 * i] = s;
         cr[2 * i + 1] = c;
@@ -163,11 +165,11 @@ CARMA_DEV void lane_factors(const double (&wre)[P], const double (&wim)[P], cons
         // a quadratic factor with two real roots: the second member has its own modulus (and no phase: s = 0)
 #pragma unroll
         for (int i = 0; i < P / 2; i++) {
-            const double e1 = exp_neg(wre[2 * i + 1] * dt);
+            const double e1 = exp_neg_tab(wre[2 * i + 1] * dt, tab);
             if (realpair[i]) cr[2 * i + 1] = e1;
         }
     }
-    if (P & 1) cr[P - 1] = exp_neg(wre[P - 1] * dt);
+    if (P & 1) cr[P - 1] = exp_neg_tab(wre[P - 1] * dt, tab);
 }
 
 // Where lane_filter takes a NEW time step's factors from.  LaneFactorsInline: the lane computes them itself.
@@ -175,32 +177,11 @@ template <int P>
 struct LaneFactorsInline {
     const LaneModel<P>& m;
     bool anyreal;
+    const double* tab;
     CARMA_DEV void step(int) const {}
     CARMA_DEV void get(int, double dt, double (&cr)[P], double (&sr)[P]) const
     {
-        lane_factors<P>(m.wre, m.wim, m.realpair, anyreal, dt, cr, sr);
-    }
-};
-
-// LaneFactorsParked: as LaneFactorsInline, with the AR roots PARKED IN MEMORY (LDS: w[0..P) real parts, w[P..2P) imaginary
-// parts of this lane's roots) instead of 4 P registers held through the whole recursion -- for callers that have other
-// state to keep alive around the filter (the lane-per-chain sampler, carma_pt_lane.hip): 2 P LDS reads per NEW time step
-// against a spill inside the loop.
-template <int P>
-struct LaneFactorsParked {
-    const double* w;
-    bool rp[(P + 1) / 2];
-    bool anyreal;
-    CARMA_DEV void step(int) const {}
-    CARMA_DEV void get(int, double dt, double (&cr)[P], double (&sr)[P]) const
-    {
-        double wre[P], wim[P];
-#pragma unroll
-        for (int r = 0; r < P; r++) {
-            wre[r] = w[r];
-            wim[r] = w[P + r];
-        }
-        lane_factors<P>(wre, wim, rp, anyreal, dt, cr, sr);
+        lane_factors<P>(m.wre, m.wim, m.realpair, anyreal, dt, cr, sr, tab);
     }
 };
 
@@ -244,7 +225,7 @@ struct LaneFactorsRing {
 };
 template <int P, int NP>
 __device__ __forceinline__ void lane_produce(int k, const double* theta, double* ring /* + lane */, const double4* __restrict__ series,
-                                             int n)
+                                             int n, const double* tab)
 {
     using Geo = LaneRingGeom<P, NP>;
     double wre[P], wim[P];
@@ -272,7 +253,7 @@ __device__ __forceinline__ void lane_produce(int k, const double* theta, double*
             // as the consumer decides: new factors unless the step repeats its predecessor's time step
             if (kk == 1 || dt != series[kk - 1].x) {
                 double cr[P], sr[P];
-                lane_factors<P>(wre, wim, realpair, anyreal, dt, cr, sr);
+                lane_factors<P>(wre, wim, realpair, anyreal, dt, cr, sr, tab);
                 double* b = ring + (size_t)((c & 1) * Geo::CH + s) * Geo::NV * 64;
 #pragma unroll
                 for (int r = 0; r < P; r++) b[r * 64] = cr[r];
@@ -403,40 +384,14 @@ CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ 
 // log-likelihood + log prior
 template <int P>
 CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __restrict__ series, int n, const Prior& pr,
-                                 int ignore_prior)
+                                 int ignore_prior, const double* tab)
 {
     LaneModel<P> m;
     lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
     bool anyreal = false;
 #pragma unroll
     for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
-    const LaneFactorsInline<P> src{m, lane_any(anyreal)};
-    double ll = lane_filter<P>(m, series, n, src);
-    ll += log_prior(m.scale, pr.measerr_dof);
-    if (m.sing || !m.valid) ll = -1.0 / 0.0;
-    return ll;
-}
-
-// the same with the roots parked in `park` (2 P doubles of this lane's own memory) during the recursion
-template <int P>
-CARMA_DEV double logdensity_lane_parked(const double* theta, int q, const double4* __restrict__ series, int n, const Prior& pr,
-                                        int ignore_prior, double* park)
-{
-    LaneModel<P> m;
-    lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
-    LaneFactorsParked<P> src;
-    src.w = park;
-    bool anyreal = false;
-#pragma unroll
-    for (int r = 0; r < P; r++) {
-        park[r] = m.wre[r];
-        park[P + r] = m.wim[r];
-    }
-#pragma unroll
-    for (int i = 0; i < (P + 1) / 2; i++) src.rp[i] = m.realpair[i];
-#pragma unroll
-    for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
-    src.anyreal = lane_any(anyreal);
+    const LaneFactorsInline<P> src{m, lane_any(anyreal), tab};
     double ll = lane_filter<P>(m, series, n, src);
     ll += log_prior(m.scale, pr.measerr_dof);
     if (m.sing || !m.valid) ll = -1.0 / 0.0;

@@ -10,6 +10,7 @@
 //                 arguments (pathological gap/min-dt ratios) take the library path.
 // Shared with the CPU lane emulator (tests/emu), hence plain C++ with fma().
 #pragma once
+#include "carma_math_tab.h"
 
 namespace carma {
 
@@ -198,6 +199,114 @@ CARMA_DEV void cexp_step_impl(double a, double b, double dt, double* re, double*
     *re = e * co;
     *im = e * so;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TABLE-BASED forms (round 4; the one-evaluation-per-lane kernels, where exp / sincos were 156 of the 338 instructions of a
+// wave-step): arguments reduced by ln 2 / 32 and pi / 32 instead of ln 2 and pi / 2, the coarse part from a table of 32 + 64
+// correctly rounded entries (carma_math_tab.h: 2^(j/32); sin, cos of k pi / 32 -- in LDS on the device, math_tab_fill), the
+// fine part from SHORT polynomials: exp to r^6 on |r| <= ln 2 / 64 (truncation 3e-18), sin to t^9, cos to t^8 on
+// |t| <= pi / 64 (2e-21, 2e-20) -- 13 polynomial steps instead of 26, and the table covers the full circle, so the
+// quadrant selects go as well.  ~45 instead of ~65 instructions per complex exponential.  Max error against quad
+// precision (tests/test_emu_core.py::test_table_math_accuracy): <= 2.5 ulp of the larger of |re|, |im|.
+// tab: MATH_TAB_N doubles (CARMA_MATH_TAB_VALUES).
+CARMA_DEV double exp_neg_tab(double x, const double* tab)
+{
+    const double n = rint(x * INV_LN2_32);
+    double r = fma3(-n, LN2_32_HI, x);
+    r = fma3(-n, LN2_32_LO, r);
+    // n is integral; beyond +-2200 * 32 the result has long over/underflowed, clamp so the int conversion is well defined
+    const int i = (int)fmin(fmax(n, -70400.0), 70400.0);
+    const double e = tab[i & 31];
+    // exp(r) - 1 = r q(r): the table entry enters as e + e (r q), so its rounding is the only half-ulp that is not scaled down
+    double q = 1.0 / 720.0;
+    q = fma3(q, r, 1.0 / 120.0);
+    q = fma3(q, r, 1.0 / 24.0);
+    q = fma3(q, r, 1.0 / 6.0);
+    q = fma3(q, r, 0.5);
+    q = fma3(q, r, 1.0);
+    return ldexp(fma3(e, q * r, e), i >> 5);
+}
+
+// phases the table form reduces itself: |n| < 2^20 keeps n PI_32_1 and n PI_32_2 exact
+constexpr double CEXP_TAB_MAXPHASE = 98304.0;
+
+template <bool CHECK>
+CARMA_DEV void cexp_step_tab_impl(double a, double b, double dt, double* re, double* im, const double* tab)
+{
+    const double x = a * dt;
+    const double ph = b * dt;
+    if (CHECK && !(fabs(ph) < CEXP_TAB_MAXPHASE)) {
+        // rare: library reduction for huge phases (NaN also lands here)
+        const double e = exp_neg_tab(x, tab);
+        const SinCos sc = sincos_slow(ph);
+        *re = e * sc.c;
+        *im = e * sc.s;
+        return;
+    }
+    const double n1 = rint(x * INV_LN2_32);
+    const double n2 = rint(ph * INV_PI_32);
+    double r = fma3(-n1, LN2_32_HI, x);
+    double t = fma3(-n2, PI_32_1, ph);
+    r = fma3(-n1, LN2_32_LO, r);
+    t = fma3(-n2, PI_32_2, t);
+    t = fma3(-n2, PI_32_3, t);
+    const int i1 = (int)fmin(fmax(n1, -70400.0), 70400.0);
+    const int i2 = (int)n2;
+    const double e0 = tab[i1 & 31];
+    const double sa = tab[MATH_TAB_SC + 2 * (i2 & 63)], ca = tab[MATH_TAB_SC + 2 * (i2 & 63) + 1];
+    const double z = t * t;
+    // exp(r) - 1 = r pe, sin t - t = t z ps, cos t - 1 = z pc: the table entries enter as x + x (small), see exp_neg_tab
+    double pe = 1.0 / 720.0;
+    double ps = 1.0 / 362880.0;
+    double pc = 1.0 / 40320.0;
+    pe = fma3(pe, r, 1.0 / 120.0);
+    ps = fma3(ps, z, -1.0 / 5040.0);
+    pc = fma3(pc, z, -1.0 / 720.0);
+    pe = fma3(pe, r, 1.0 / 24.0);
+    ps = fma3(ps, z, 1.0 / 120.0);
+    pc = fma3(pc, z, 1.0 / 24.0);
+    pe = fma3(pe, r, 1.0 / 6.0);
+    ps = fma3(ps, z, -1.0 / 6.0);
+    pc = fma3(pc, z, -0.5);
+    pe = fma3(pe, r, 0.5);
+    const double tz = t * z;
+    const double cm = pc * z;                                // cos t - 1
+    pe = fma3(pe, r, 1.0);
+    const double st = fma3(tz, ps, t);                       // sin t
+    const double e = ldexp(fma3(e0, pe * r, e0), i1 >> 5);
+    const double sn = fma3(sa, cm, ca * st) + sa;            // sin(k pi / 32 + t) = sa + (sa (cos t - 1) + ca sin t)
+    const double cs = fma3(ca, cm, -(sa * st)) + ca;
+    *re = e * cs;
+    *im = e * sn;
+}
+
+template <bool EXACT = false>
+CARMA_DEV void cexp_step_tab(double a, double b, double dt, double* re, double* im, const double* tab)
+{
+    static_assert(!EXACT, "the table form has no residual-recovery variant");
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool slow = !(fabs(b * dt) < CEXP_TAB_MAXPHASE);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {     // once per wave: see cexp_step
+        cexp_step_tab_impl<true>(a, b, dt, re, im, tab);
+        return;
+    }
+    cexp_step_tab_impl<false>(a, b, dt, re, im, tab);
+#else
+    cexp_step_tab_impl<true>(a, b, dt, re, im, tab);
+#endif
+}
+
+#if defined(__HIPCC__)
+// the tables in device memory, and their copy into a kernel's LDS (all threads of the workgroup call it; the caller
+// synchronises before the first use)
+__device__ static const double c_math_tab[MATH_TAB_N] = {CARMA_MATH_TAB_VALUES};
+__device__ __forceinline__ void math_tab_fill(double* lds_tab)
+{
+    for (int i = threadIdx.x; i < MATH_TAB_N; i += blockDim.x) lds_tab[i] = c_math_tab[i];
+}
+#else
+static const double h_math_tab[MATH_TAB_N] = {CARMA_MATH_TAB_VALUES};
+#endif
 
 // The huge-phase test is made ONCE PER WAVE: a per-lane test compiles to an exec-masked block in front of the fast path
 // and the branch over it is TAKEN every time -- ~30 cycles of instruction-fetch bubble per evaluation when the SIMD has

@@ -68,12 +68,12 @@ extern "C" int emu_logdensity_carma_lane(int p, int q, const double* theta, int 
     for (int b = 0; b < B; b++) {
         const double* th = theta + (size_t)b * d;
         switch (p) {
-            case 2: out[b] = logdensity_lane<2>(th, q, s4, n, pr, ignore_prior); break;
-            case 3: out[b] = logdensity_lane<3>(th, q, s4, n, pr, ignore_prior); break;
-            case 4: out[b] = logdensity_lane<4>(th, q, s4, n, pr, ignore_prior); break;
-            case 5: out[b] = logdensity_lane<5>(th, q, s4, n, pr, ignore_prior); break;
-            case 6: out[b] = logdensity_lane<6>(th, q, s4, n, pr, ignore_prior); break;
-            case 7: out[b] = logdensity_lane<7>(th, q, s4, n, pr, ignore_prior); break;
+            case 2: out[b] = logdensity_lane<2>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
+            case 3: out[b] = logdensity_lane<3>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
+            case 4: out[b] = logdensity_lane<4>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
+            case 5: out[b] = logdensity_lane<5>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
+            case 6: out[b] = logdensity_lane<6>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
+            case 7: out[b] = logdensity_lane<7>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
             default: return -1;
         }
     }

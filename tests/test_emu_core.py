@@ -179,3 +179,37 @@ def test_lane_code_regular_cadence():
         from helpers import loglik_truth
         assert_parity(emu.logdensity_carma_lane(t, y, yerr, p, q, th, pr), m.logdensity_batch(th), 1e-10, "lane regular cadence",
                       arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.2)
+
+
+def test_table_math_accuracy():
+    """The table-based exp / complex exponential of carma_math.h (round 4: arguments reduced by ln 2 / 32 and pi / 32, coarse part
+    from correctly rounded tables, short polynomials) against QUAD precision on a million arguments spread over the decades
+    the prior admits -- the host build of the very functions the kernels compile (tests/tools/proto/table_math_accuracy.cpp)."""
+    import ctypes as C
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "tools", "proto", "table_math_accuracy.cpp")
+    so = os.path.join(here, "emu", "libtable_math.so")
+    csrc = os.path.join(os.path.dirname(here), "carma_pack_amd", "csrc")
+    deps = [src, os.path.join(csrc, "carma_math.h"), os.path.join(csrc, "carma_math_tab.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-mfma", "-DTABLE_MATH_NO_MAIN", "-I", csrc, "-o", so, src,
+                               "-lquadmath"])
+    lib = C.CDLL(so)
+    out = (C.c_double * 4)()
+    assert lib.table_math_accuracy(1000000, 7, out) == 0
+    exp_tab, exp_old, cexp_tab, cexp_old = list(out)
+    print("max error (ulp): exp_neg_tab %.2f (exp_neg %.2f), cexp_step_tab %.2f (cexp_step %.2f)" % (exp_tab, exp_old, cexp_tab, cexp_old))
+    assert exp_tab < 2.0 and cexp_tab < 3.6
+    assert cexp_tab <= cexp_old + 0.25                       # no worse than the polynomial-only form it replaces
+
+
+def test_math_tables_are_the_generators_output():
+    """carma_math_tab.h is generated (tools/gen_math_tables.py, mpmath): regenerate and compare."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "carma_pack_amd", "csrc", "carma_math_tab.h")
+    before = open(path).read()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_math_tables.py")], stdout=subprocess.DEVNULL)
+    assert open(path).read() == before
