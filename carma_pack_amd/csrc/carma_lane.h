@@ -152,6 +152,10 @@ template <int P>
 CARMA_DEV void lane_factors(const double (&wre)[P], const double (&wim)[P], const bool (&realpair)[(P + 1) / 2], bool anyreal,
                             double dt, double (&cr)[P], double (&sr)[P], const double* tab)
 {
+#if defined(CARMA_AB_NOTAB)                                  // A/B builds only: the polynomial-only forms of round 3
+#define cexp_step_tab(a, b, dt, c, s, tab) cexp_step(a, b, dt, c, s)
+#define exp_neg_tab(x, tab) exp_neg(x)
+#endif
 #pragma unroll
     for (int i = 0; i < P / 2; i++) {
         double c, s;
@@ -170,6 +174,10 @@ CARMA_DEV void lane_factors(const double (&wre)[P], const double (&wim)[P], cons
         }
     }
     if (P & 1) cr[P - 1] = exp_neg_tab(wre[P - 1] * dt, tab);
+#if defined(CARMA_AB_NOTAB)
+#undef cexp_step_tab
+#undef exp_neg_tab
+#endif
 }
 
 // Where lane_filter takes a NEW time step's factors from.  LaneFactorsInline: the lane computes them itself.
