@@ -60,6 +60,77 @@ def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=N
     return float(rel.max())
 
 
+def cond_eigenmat(theta, p):
+    """2-norm condition number of the reference's EigenMat (the Vandermonde matrix of the AR roots, kfilter.cpp:144-149) --
+    what its LU solve (:157-158) amplifies rounding by."""
+    import oracle as orc
+    w = np.asarray(orc.ar_roots(np.asarray(theta, dtype=float), p))
+    E = np.vander(w, p, increasing=True).T
+    with np.errstate(all="ignore"):
+        try:
+            return float(np.linalg.cond(E))
+        except np.linalg.LinAlgError:
+            return np.inf
+
+
+def parity_census(got, want, thetas, p, labels, bounds, arbiter, rtol=1e-10, what="", arb_factor=1.25):
+    """Parity BY CLASS instead of one allowance for everything: `labels[i]` names the class of entry i (e.g. "cold" / "hot"),
+    `bounds[class]` is the largest fraction of that class's finite entries that may differ from the oracle by more than rtol.
+    Every such entry is arbitrated against the quad-precision value (the device must be within rtol of it, or no further from
+    it than arb_factor x the oracle's own distance: sampler states with cond(EigenMat) ~ 1e5 exist on which BOTH
+    double-precision recursions end up 2e-10 from the exact value, 2.11e-10 against 1.96e-10 measured), and the census is printed: per class the count, the fraction, the worst difference, and cond(EigenMat)
+    of the entries beyond rtol against the rest -- the entries beyond rtol are the ill-conditioned ones, on which the
+    reference's own LU is rtol ... 1e-3 away from the exact value of its formulas."""
+    got, want, labels = np.asarray(got, dtype=float), np.asarray(want, dtype=float), np.asarray(labels)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin), "%s: finite pattern differs" % what
+    rel = np.zeros(got.size)
+    rel[fin] = np.abs(got[fin] - want[fin]) / np.abs(want[fin])
+    out = {}
+    for cls in sorted(set(labels.tolist())):
+        sel = fin & (labels == cls)
+        bad = np.flatnonzero(sel & (rel > rtol))
+        n = int(sel.sum())
+        frac = bad.size / max(n, 1)
+        cb = [cond_eigenmat(thetas[i], p) for i in bad]
+        rest = np.flatnonzero(sel & (rel <= rtol))
+        cr = [cond_eigenmat(thetas[i], p) for i in rest[:: max(1, rest.size // 50)]]
+        print("%s census [%s]: %d of %d finite entries beyond %.0e of the oracle (%.2f %%, allowed %.2f %%), worst %.2e; "
+              "cond(EigenMat) median %.1e for those, %.1e for the rest" % (
+                  what, cls, bad.size, n, rtol, 100 * frac, 100 * bounds[cls], rel[bad].max() if bad.size else 0.0,
+                  np.median(cb) if cb else 0.0, np.median(cr) if cr else 0.0))
+        assert frac <= bounds[cls], "%s [%s]: %.2f %% of the entries beyond %.0e (allowed %.2f %%)" % (what, cls, 100 * frac, rtol, 100 * bounds[cls])
+        for i in bad:
+            truth = arbiter(int(i))
+            eg, eo = abs(got[i] - truth), abs(want[i] - truth)
+            assert eg <= max(rtol * abs(truth), arb_factor * eo), (
+                "%s [%s]: entry %d is further from the exact value than the oracle (gpu err %.2e, oracle err %.2e)" % (
+                    what, cls, i, eg / abs(truth), eo / abs(truth)))
+            print("%s [%s]: entry %d: gpu %.2e, oracle %.2e from the exact value, cond(EigenMat) %.1e" % (
+                what, cls, i, eg / abs(truth), eo / abs(truth), cond_eigenmat(thetas[i], p)))
+        out[cls] = (bad.size, n)
+    return out
+
+
+def assert_same_evaluation(a, b, thetas, p, what="", rtol=1e-8, cond_min=1e5, ceiling=1e-6):
+    """Two launch shapes of the same evaluation (a, b: log-posteriors of the states `thetas`): within rtol of each other -- the
+    bar for WELL-CONDITIONED states, kept as it was --; an entry beyond it must be a flagged ill-conditioned state
+    (cond(EigenMat) >= cond_min, where rounding is amplified on both sides) and still within `ceiling`."""
+    a, b = np.ravel(np.asarray(a, dtype=float)), np.ravel(np.asarray(b, dtype=float))
+    th = np.asarray(thetas, dtype=float).reshape(a.size, -1)
+    fin = np.isfinite(a)
+    assert np.array_equal(np.isfinite(b), fin), what
+    rel = np.zeros(a.size)
+    rel[fin] = np.abs(b[fin] - a[fin]) / np.abs(a[fin])
+    bad = np.flatnonzero(rel > rtol)
+    assert rel.max() <= ceiling, "%s: %.2e apart" % (what, rel.max())
+    for i in bad:
+        c = cond_eigenmat(th[i], p)
+        assert c >= cond_min, "%s: a well-conditioned state (cond(EigenMat) %.1e) differs by %.2e between the kernels" % (what, c, rel[i])
+    if bad.size:
+        print("%s: %d of %d states beyond %.0e (all ill-conditioned), worst %.2e" % (what, bad.size, a.size, rtol, rel.max()))
+
+
 def in_zero_root_band(theta, p, q):
     """True when a quadratic factor of theta (AR or MA; log coefficients lq1, lq2 -> q1 = e^lq1, q2 = e^lq2) has two real roots
     with 4 q1 / q2^2 between 2^-54 and 2^-51: the band in which the reference's smaller root -(q2 - sqrt(q2^2 - 4 q1)) / 2 is

@@ -135,9 +135,15 @@ def test_prior_bounds_and_failures(cpa, readme):
     want = m.logdensity_batch(cases[:8], ignore_prior=True)
     fin = np.isfinite(want)
     assert_parity(got[fin], want[fin], RTOL, "ignore_prior")
-    # roots 1e-6 apart: cond(E) ~ 1e12+, both LU's are noise-dominated; only the magnitude is pinned
+    # roots 1e-6 apart: cond(EigenMat) ~ 1e12+, the reference's LU (and the oracle's) is noise-dominated there -- the device's
+    # closed forms are not: pinned to the QUAD-PRECISION value of the reference's formulas (round 4; before: "1e-3 of the oracle")
+    from helpers import loglik_truth
     g8, w8 = ctx.logdensity(cases[8], ignore_prior=True), m.logdensity(cases[8], ignore_prior=True)
-    assert np.isfinite(g8) and abs(g8 - w8) < 1e-3 * abs(w8)
+    t8 = loglik_truth(g["t"], g["y"], g["yerr"], cases[8], 5, 3)[0]
+    print("roots 1e-6 apart: device %.3e from the exact value, oracle %.3e" % (abs(g8 - t8) / abs(t8), abs(w8 - t8) / abs(t8)))
+    # measured: device 4.7e-7, oracle 1.0e-5 from the exact value (the closed forms lose the six digits of the root difference,
+    # twice; the LU loses more)
+    assert np.isfinite(g8) and abs(g8 - t8) <= 2e-6 * abs(t8) and abs(g8 - t8) <= abs(w8 - t8)
     assert not np.isfinite(ctx.logdensity(cases[9], ignore_prior=True))
 
 

@@ -159,12 +159,12 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
     a, b = res["ladder"], res["row"]
     np.testing.assert_allclose(b[0], a[0], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-9)
-    # stored log-posteriors: the two kernels are different launch shapes of the same evaluation -- 1e-8 apart at most,
-    # except on the odd ill-conditioned state a hot chain visits (one of 7200 at 1.6e-8 with 2160 chains): all within
-    # 1e-6, all but one in a thousand within 1e-8
-    for k in (1, 3):
-        rel = np.abs(b[k] - a[k]) / np.abs(a[k])
-        assert rel.max() <= 1e-6 and np.mean(rel > 1e-8) <= 1e-3, (rel.max(), np.mean(rel > 1e-8))
+    # stored log-posteriors: the two kernels are different launch shapes of the same evaluation -- 1e-8 apart at most on
+    # WELL-CONDITIONED states (the bar of round 2, kept); what exceeds it must be a flagged ill-conditioned state a hot
+    # chain visits (cond(EigenMat) >= 1e5), and stays within 1e-6
+    from helpers import assert_same_evaluation
+    assert_same_evaluation(a[1], b[1], b[0], p, "chain states, row vs ladder kernel")
+    assert_same_evaluation(a[3], b[3], b[2], p, "saved samples, row vs ladder kernel")
     np.testing.assert_array_equal(b[4], a[4])
     np.testing.assert_array_equal(b[5], a[5])
 
@@ -199,9 +199,9 @@ def test_lane_kernel_walks_the_ladder_kernels_trajectory(cpa, p, q, T, R, kern, 
     np.testing.assert_array_equal(b[5], a[5])                # swap counts
     np.testing.assert_allclose(b[0], a[0], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-9)
-    for i in (1, 3):
-        rel = np.abs(b[i] - a[i]) / np.abs(a[i])
-        assert rel.max() <= 1e-6 and np.mean(rel > 1e-8) <= 1e-3, (rel.max(), np.mean(rel > 1e-8))
+    from helpers import assert_same_evaluation
+    assert_same_evaluation(a[1], b[1], b[0], p, "chain states, lane vs ladder kernel")
+    assert_same_evaluation(a[3], b[3], b[2], p, "saved samples, lane vs ladder kernel")
 
 
 def test_lane_kernel_is_the_choice_for_large_ensembles(cpa, monkeypatch):
