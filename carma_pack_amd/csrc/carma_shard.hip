@@ -29,6 +29,9 @@
 // RCCL is bound at run time (dlopen of librccl.so.1: the copy PyTorch already loaded when there is one), so the
 // library itself has no link-time dependency on it; without RCCL carma_comm_* fail loudly.
 #include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <utility>
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
@@ -346,6 +349,22 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
         if (e != hipSuccess) return hip_fail(e, "carma_pt_iterate_sharded");
     }
     const unsigned tpb = 64;
+    // CARMA_SHARD_STAMPS=1 (measurements only; read once): HIP events between the stages of the first 64 iterations of a call,
+    // summed per stage and printed when the call ends -- the boundary budget behind DESIGN.md section 7's pipelining argument
+    static const bool stamps_on = [] {
+        const char* v = getenv("CARMA_SHARD_STAMPS");
+        return v && v[0] == '1';
+    }();
+    enum { ST_START, ST_RAM, ST_PACK, ST_XFER, ST_SWAP, ST_SWEEP, ST_N };
+    std::vector<std::pair<int, hipEvent_t>> stamps;
+    auto stamp = [&](int tag, long it) {
+        if (!stamps_on || it >= 64) return;
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        (void)hipEventRecord(ev, st);
+        stamps.emplace_back(tag, ev);
+    };
+    long cur_it = 0;
     struct Side {
         int local;      // index of the local block
         int mine;       // its boundary temperature (local index)
@@ -361,6 +380,7 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
         }
         hipError_t el = hipGetLastError();
         if (el != hipSuccess) return hip_fail(el, "k_shard_pack");
+        stamp(ST_PACK, cur_it);
         // Sends and receives between one pair of ranks are matched in issue order; the only pair with two transfers in
         // flight is this rank with itself, where the lower block's data has to land in the upper block's buffer and vice
         // versa -- so every side issues its send, then the receive INTO THE OTHER SIDE'S BUFFER when the peer is this rank.
@@ -378,6 +398,7 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
         }
         nr = api->GroupEnd();
         if (nr != ncclSuccess) return rccl_fail(nr, "ncclGroupEnd");
+        stamp(ST_XFER, cur_it);
         for (int a = 0; a < nsides; a++) {
             PtState* s = cs[sides[a].local]->pt;
             const unsigned hot_slot = sides[a].upper ? s->slot0 + (unsigned)s->T : s->slot0;      // global slot of the hotter chain
@@ -389,14 +410,18 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
         }
         el = hipGetLastError();
         if (el != hipSuccess) return hip_fail(el, "k_shard_swap");
+        stamp(ST_SWAP, cur_it);
         return CARMA_OK;
     };
     int rc_loop = CARMA_OK;
     for (long it = 0; it < niter && rc_loop == CARMA_OK; it++) {
         const unsigned long long iter = s0->iter;     // index of the iteration about to run (== every block's)
+        cur_it = it;
+        stamp(ST_START, it);
         // one block: the sampler kernel with its own sweep; several: RAM steps only, the sweep follows piece by piece
         for (int i = 0; i < nlocal && rc_loop == CARMA_OK; i++) rc_loop = pt_enqueue(cs[i], 1, nblocks == 1 ? 1 : 0, 0, nullptr, st);
         if (rc_loop != CARMA_OK) break;
+        stamp(ST_RAM, it);
         if (nblocks > 1) {
             // the sweep of the whole ladder, hottest pair first, as far as this process holds a side of it
             for (int i = nlocal - 1; i >= 0 && rc_loop == CARMA_OK; i--) {
@@ -416,6 +441,7 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
                         rc_loop = hip_fail(e, "k_shard_sweep");
                         break;
                     }
+                    stamp(ST_SWEEP, it);
                 }
                 if (gb > 0) {
                     if (i > 0) {                                        // the colder neighbour is this process's block i - 1
@@ -470,6 +496,25 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
     }
     e = hipStreamSynchronize(st);
     if (e != hipSuccess && rc_loop == CARMA_OK) rc_loop = hip_fail(e, "carma_pt_iterate_sharded");
+    if (!stamps.empty()) {
+        double sum[ST_N] = {0, 0, 0, 0, 0, 0};
+        long cnt[ST_N] = {0, 0, 0, 0, 0, 0};
+        for (size_t k = 1; k < stamps.size(); k++) {
+            float ms = 0.f;
+            if (stamps[k].first != ST_START && hipEventElapsedTime(&ms, stamps[k - 1].second, stamps[k].second) == hipSuccess) {
+                sum[stamps[k].first] += 1e3 * ms;
+                cnt[stamps[k].first]++;
+            }
+        }
+        const long its = cnt[ST_RAM] ? cnt[ST_RAM] : 1;
+        fprintf(stderr, "carma_shard stamps: rank %d, %d local block(s) of %d, R = %d, %ld iterations | per iteration (us): sampler kernel(s) %.1f, "
+                        "pack %.1f (%ld), send/recv %.1f (%ld), swap %.1f (%ld), block sweep %.1f (%ld) | per stage (us): pack %.2f, send/recv %.2f, "
+                        "swap %.2f, sweep %.2f\n", rank, nlocal, nblocks, R, its, sum[ST_RAM] / its, sum[ST_PACK] / its, cnt[ST_PACK] / its,
+                sum[ST_XFER] / its, cnt[ST_XFER] / its, sum[ST_SWAP] / its, cnt[ST_SWAP] / its, sum[ST_SWEEP] / its, cnt[ST_SWEEP] / its,
+                cnt[ST_PACK] ? sum[ST_PACK] / cnt[ST_PACK] : 0.0, cnt[ST_XFER] ? sum[ST_XFER] / cnt[ST_XFER] : 0.0,
+                cnt[ST_SWAP] ? sum[ST_SWAP] / cnt[ST_SWAP] : 0.0, cnt[ST_SWEEP] ? sum[ST_SWEEP] / cnt[ST_SWEEP] : 0.0);
+        for (auto& pr_ : stamps) (void)hipEventDestroy(pr_.second);
+    }
     bool any_abort = false;
     for (int i = 0; i < nlocal; i++) {
         bool aborted = false;
