@@ -56,14 +56,15 @@ if __name__ == "__main__":
     spec = os.path.join(tmp, "spec.json")
     json.dump(cs, open(spec, "w"))
     outs = {}
-    for kern in ("row", "ladder"):
+    KA = os.environ.get("FUZZ_KERNEL", "row")               # "lane": the large-ensemble path (carma_pt_lane.hip) against the ladder kernel
+    for kern in (KA, "ladder"):
         f = os.path.join(tmp, kern + ".npy")
         subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", kern, spec, f], check=True)
         outs[kern] = np.load(f, allow_pickle=True)
     import oracle as orc
     from helpers import assert_parity_states, irregular_series, loglik_truth
     fails, kinds = 0, {}
-    for c, a, b in zip(cs, outs["row"], outs["ladder"]):
+    for c, a, b in zip(cs, outs[KA], outs["ladder"]):
         p, q, T, R, n, sd = c
         kinds[a["kernel"][:8]] = kinds.get(a["kernel"][:8], 0) + 1
         if a["kernel"].startswith("rejected") or b["kernel"].startswith("rejected"):
@@ -73,11 +74,14 @@ if __name__ == "__main__":
             continue
         try:
             assert b["kernel"] == "ladder"
-            np.testing.assert_allclose(a["th"], b["th"], rtol=1e-6, atol=1e-9)
+            # (values to rounding: the kernels round the rank-1 update differently and a chain amplifies that from iteration to
+            # iteration -- 1 component in 3.4 million at 1.2e-6 after 40 iterations, fuzz_sampler_lane_v1.txt; the decisions below
+            # are compared exactly)
+            np.testing.assert_allclose(a["th"], b["th"], rtol=1e-5, atol=1e-8)
             fin = np.isfinite(b["lp"])
             assert np.array_equal(np.isfinite(a["lp"]), fin)
-            rel = np.abs(a["lp"][fin] - b["lp"][fin]) / np.abs(b["lp"][fin])
-            assert rel.max() <= 1e-6 and np.mean(rel > 1e-8) <= 1e-3, rel.max()
+            from helpers import assert_same_evaluation
+            assert_same_evaluation(b["lp"], a["lp"], a["th"], p, "states")
             assert np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["swp"], b["swp"])
             t, y, yerr = irregular_series(n, seed=sd)
             m = orc.OracleModel(t, y, yerr, p, q, max_stdev=10.0 * y.std())
@@ -90,6 +94,6 @@ if __name__ == "__main__":
             fails += 1
             print("FAILED CARMA(%d,%d) T=%d R=%d n=%d seed=%d (%s): %s" % (p, q, T, R, n, sd, a["kernel"], str(ex)[:300]), flush=True)
     if os.environ.get("FUZZ_VERBOSE"):
-        for c, a in zip(cs, outs["row"]):
+        for c, a in zip(cs, outs[KA]):
             print("CARMA(%d,%d) T=%2d R=%3d workgroups %4d n=%2d -> %s" % (c[0], c[1], c[2], c[3], c[3] * ((c[2] + 3) // 4), c[4], a["kernel"][:8]))
-    print("%d cases, %d failed; kernel the 'row' run was on: %s" % (len(cs), fails, kinds))
+    print("%d cases, %d failed; kernel the '%s' run was on: %s" % (len(cs), fails, KA, kinds))
