@@ -271,6 +271,9 @@ __device__ __forceinline__ void pipe3l_produce(const Grp<16>& g, int pw, const d
 #pragma unroll
             for (int it = 0; it < NIT; it++) entry(it, ec0[it], es0[it], e10[it]);
         } else {
+#if defined(CARMA_AB_NOPROD)                                  // timing-only A/B build: what the producers' work costs the others
+            if (c < 3)
+#endif
 #pragma unroll 1
             for (int it = 0; it < NIT; it++) {
                 double ec, es, e1;
@@ -491,6 +494,9 @@ __device__ __forceinline__ double pipe3l_mean(const Grp<16>& g, double mu, const
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
         const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
+#if defined(CARMA_AB_NOMEAN)                                  // timing-only A/B build: what the mean wave's work costs the others
+        if (c > 0) continue;
+#endif
         if (len == C) {
             if (fm == 0) {
 #pragma unroll
