@@ -14,9 +14,9 @@ mkdir -p $OUT
 # which build the counters below belong to (bench.py attaches them to a run of the same build only)
 python3 -c "import sys, json; sys.path.insert(0, '$REPO'); from carma_pack_amd._lib import build_ids; json.dump(build_ids(), open('$OUT/ids.json', 'w'))"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --no-cpu --no-pipelined > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --no-cpu --no-pipelined --no-mcmc-large > $OUT/stats.log 2>&1
 echo "stats rc=$?"
-PMC_ARGS="--steps 50 --warmup 5 --no-cpu --no-pipelined --no-ladder --mcmc-iters 200"
+PMC_ARGS="--steps 50 --warmup 5 --no-cpu --no-pipelined --no-ladder --no-mcmc-large --mcmc-iters 200"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o $TAG -- python3 $REPO/bench.py $PMC_ARGS > $OUT/pmc_$c.log 2>&1
   echo "pmc $c rc=$?"
