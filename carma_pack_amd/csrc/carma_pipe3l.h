@@ -359,8 +359,24 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         RA::gain_nt(S, k, nt);
     };
     const unsigned long long* flag_b = reinterpret_cast<const unsigned long long*>(ring + Geo::FLAG_OFF);
+#if defined(CARMA_CHUNK_STAMPS)
+    // diagnostic build: where a chunk of the covariance wave spends its cycles -- arriving at the barrier (drain of the last
+    // link write), released from it, first pass's operands in registers, end of the sixteen passes
+    unsigned long long cs_bar = 0, cs_head = 0, cs_body = 0, cs_t0 = 0, cs_t1 = 0, cs_t2 = 0, cs_t3 = 0;
+#define CHUNK_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#endif
     for (int c = 0; c < nc; c++) {
+#if defined(CARMA_CHUNK_STAMPS)
+        __builtin_amdgcn_sched_barrier(0);
+        CHUNK_STAMP(cs_t0);
+        if (c > 1) cs_body += cs_t0 - cs_t3;
+#endif
         __syncthreads();                                      // barrier c
+#if defined(CARMA_CHUNK_STAMPS)
+        __builtin_amdgcn_sched_barrier(0);
+        CHUNK_STAMP(cs_t1);
+        if (c > 1) cs_bar += cs_t1 - cs_t0;
+#endif
         // yerr_j^2 is wave-uniform: the chunk's sixteen values in two wide scalar loads from the plain array behind the
         // records (scalar-memory and LDS returns share a counter, so a scalar load inside a pass would drain the LDS
         // prefetch every step).  Requested FIRST, so that their latency runs under that of the LDS reads below.
@@ -368,8 +384,13 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         const int len = (n - c * C < C) ? n - c * C : C;
         double ev[C];
         if (len == C) {
+#if defined(CARMA_AB_NOEV)                                    // timing-only A/B build: what the chunk's scalar loads cost the head
+#pragma unroll
+            for (int s = 0; s < C; s++) ev[s] = 0.01 * (s + 1);
+#else
 #pragma unroll
             for (int s = 0; s < C; s++) ev[s] = e_arr[j0 + s];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         ring_b = reinterpret_cast<const double2*>(ring + Geo::RING_OFF + (size_t)(c % 3) * C * Geo::SLOT) + Geo::entry(lane);
@@ -380,6 +401,12 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
         rowm = (unsigned)(fm64 >> (16 * (lane >> 4))) & 0xffffu;                   // this row's evaluation
         const unsigned fm_lo = __builtin_amdgcn_readfirstlane((unsigned)fm64), fm_hi = __builtin_amdgcn_readfirstlane((unsigned)(fm64 >> 32));
         const unsigned fm = (fm_lo | (fm_lo >> 16) | fm_hi | (fm_hi >> 16)) & 0xffffu;     // any row (= the finest grid's)
+#if defined(CARMA_CHUNK_STAMPS)
+        __builtin_amdgcn_sched_barrier(0);
+        CHUNK_STAMP(cs_t3);                                   // (waits for the head's LDS reads and scalar loads)
+        if (c > 1) cs_head += cs_t3 - cs_t1;
+        (void)cs_t2;
+#endif
         if (len == C) {
             if (fm == 0) {
                 // no re-base in this chunk (the rule for posterior-like parameters): a copy of the passes without the
@@ -409,6 +436,12 @@ __device__ __forceinline__ void pipe3l_cov(const Grp<16>& g, const Model<P>& m, 
             }
         }
     }
+#if defined(CARMA_CHUNK_STAMPS)
+    if (blockIdx.x == 0 && lane == 0)
+        printf("p3l covariance wave, %d chunks: per chunk (cycles) sixteen passes %llu | barrier (incl. draining the link write) %llu | head: pointers, "
+               "flag word, first entry, yerr^2 loads %llu\n", nc, cs_body / (unsigned long long)(nc > 2 ? nc - 2 : 1),
+               cs_bar / (unsigned long long)(nc > 2 ? nc - 2 : 1), cs_head / (unsigned long long)(nc > 2 ? nc - 2 : 1));
+#endif
     __syncthreads();                                          // barrier nc
 }
 
