@@ -2,6 +2,8 @@
 // per LANE, and an iteration as three launches instead of one persistent kernel:
 //
 //     k_ram_propose   t8 draws, thn = th + R^T z                          AdaptiveMetro::DoStep, src/steps.cpp:60-73
+//                     (a launch of its own for the first iteration of a chunk only: afterwards the proposal of iteration
+//                     i + 1 rides on the finish kernel of iteration i, the factor still in registers)
 //     K1              the Kalman log-density of every proposal: the batched log-density launch of carma_kernels.hip,
 //                     whichever shape serves that many evaluations (producer-wave lane kernel, lane kernel, ...)
 //                                                                         Accept, src/steps.cpp:36-56 -> carpack.hpp:131-176
@@ -148,7 +150,9 @@ __global__ __launch_bounds__(256) void k_ram_propose(PtLaunch L, RamState S)
 
 // Metropolis decision with the tempered ratio (steps.cpp:36-56), the RAM rank-1 update of the factor (steps.cpp:82-99,
 // CholUpdateR1 :111-131), the exchange sweep of the ladder (steps.hpp:318-362), Sampler::SaveValues (samplers.cpp:118-124)
-template <int D>
+// NEXT: the proposal of the FOLLOWING iteration right behind (what k_ram_propose does, with the factor still in registers):
+// one launch and one pass over the factor less per iteration.
+template <int D, bool NEXT>
 __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, const double* __restrict__ temps,
                                                     unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,
                                                     double* __restrict__ samples, double* __restrict__ sample_lp)
@@ -164,11 +168,13 @@ __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, cons
     double* vec = s_vec + tid * RAM_DS;
     const int wbase = tid & ~63;                             // this wave's first slot
     const bool adapt = (long)iter < (long)L.maxiter;
-    // the factor and v: requested up front (independent loads), used by the adaptation below
+    // the factor and v: requested up front (independent loads), used by the adaptation below (and by the next proposal)
     double Rr[NT], v[D];
-    if (adapt) {
+    if (adapt || NEXT) {
 #pragma unroll
         for (int i = 0; i < NT; i++) Rr[i] = S.R[(long)i * S.nc + x.gi];
+    }
+    if (adapt) {
 #pragma unroll
         for (int j = 0; j < D; j++) v[j] = S.v[(long)j * S.nc + x.gi];
     }
@@ -252,6 +258,39 @@ __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, cons
         for (int j = 0; j < d; j++) samples[(x.lad * L.sample_cap + L.save_offset) * d + j] = S.th[(long)j * S.nc + x.gi];
         sample_lp[x.lad * L.sample_cap + L.save_offset] = lp;
     }
+    if constexpr (NEXT) {
+        // ---- the next iteration's proposal (k_ram_propose): the current value is what the sweep assigned to this lane
+        double cur[D];
+        if (exch) {
+            const double* src = s_vec + (wbase + x.lbase + s_src[tid]) * RAM_DS;
+#pragma unroll
+            for (int j = 0; j < D; j++) cur[j] = src[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; j++) cur[j] = S.th[(long)j * S.nc + x.gi];
+        }
+        double z[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) z[i] = 0.0;
+        double znorm2 = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < D; k++) {
+            const double zk = rng_student_t8(key, iter + 1, (uint32_t)k);
+#pragma unroll
+            for (int i = 0; i < D; i++) z[i] = i == k ? zk : z[i];
+            znorm2 += zk * zk;
+        }
+        if (!x.active) return;
+        S.z2[x.gi] = znorm2;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k <= j; k++) acc += Rr[k * D - k * (k - 1) / 2 + (j - k)] * z[k];
+            S.v[(long)j * S.nc + x.gi] = acc;
+            S.thn[x.gi * D + j] = cur[j] + acc;
+        }
+    }
 }
 
 // doubles of working state for nchain chains of dimension d (RamState)
@@ -311,14 +350,20 @@ hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const doubl
         const bool save = L.save_thin > 0 && ((it + 1) % L.save_thin) == 0;
         Li.save_thin = save ? 1 : 0;
         Li.save_offset = save ? L.save_offset + (it + 1) / L.save_thin - 1 : 0;
-        e = ram_launch_d(L.d, [&](auto dc) {
-            hipLaunchKernelGGL((k_ram_propose<decltype(dc)::value>), dim3(grid), dim3(256), 0, st, Li, S);
-        });
+        if (it == 0)                                         // (later proposals ride on the finish kernel of the iteration before)
+            e = ram_launch_d(L.d, [&](auto dc) {
+                hipLaunchKernelGGL((k_ram_propose<decltype(dc)::value>), dim3(grid), dim3(256), 0, st, Li, S);
+            });
         if (e == hipSuccess) e = launch_logdens_carma(p, S.thn, (int)nc, L.d, L.q, series, L.n, pr, 0, S.ll, st, repeated_dt);
         if (e == hipSuccess) {
+            const bool next = it + 1 < L.niter;
             e = ram_launch_d(L.d, [&](auto dc) {
-                hipLaunchKernelGGL((k_ram_finish<decltype(dc)::value>), dim3(grid), dim3(256), 0, st, Li, S, temps, naccept, nswap,
-                                   samples, sample_lp);
+                if (next)
+                    hipLaunchKernelGGL((k_ram_finish<decltype(dc)::value, true>), dim3(grid), dim3(256), 0, st, Li, S, temps, naccept,
+                                       nswap, samples, sample_lp);
+                else
+                    hipLaunchKernelGGL((k_ram_finish<decltype(dc)::value, false>), dim3(grid), dim3(256), 0, st, Li, S, temps, naccept,
+                                       nswap, samples, sample_lp);
             });
         }
     }
