@@ -29,6 +29,8 @@ namespace carma {
 constexpr int POST_PMAX = CARMA_PMAX;       // AR order <= 7: alpha has <= 8 coefficients, delta <= 7
 constexpr int POST_NQ = 8;                  // order statistics per row: two per percentile, four percentiles
 constexpr int PSD_FT = 8;                   // frequencies per lane of k_psd_grid
+constexpr int QT = 1024;                    // threads of k_row_quantiles (one workgroup per row)
+constexpr int QU = 4;                       // independent loads in flight per thread and trip of its row loops
 
 struct Cd {
     double re, im;
@@ -130,7 +132,7 @@ __device__ __forceinline__ double np_lerp(double a, double b, double t)
 // One workgroup per row.  ranks[2 j], ranks[2 j + 1] = the order statistics either side of percentile j, gammas[j] its
 // interpolation weight.  Radix select, most significant byte first: after the pass over byte B every rank knows the top
 // (8 - B) bytes of its order statistic and its rank among the elements that share them.
-__global__ __launch_bounds__(256) void k_row_quantiles(const double* __restrict__ grid, int ns, int nq,
+__global__ __launch_bounds__(QT) void k_row_quantiles(const double* __restrict__ grid, int ns, int nq,
                                                        const int* __restrict__ ranks, const double* __restrict__ gammas,
                                                        double* __restrict__ band /* [rows][nq / 2] */)
 {
@@ -152,12 +154,17 @@ __global__ __launch_bounds__(256) void k_row_quantiles(const double* __restrict_
     {
         unsigned long long lo = ~0ull, hi = 0ull;
         unsigned nn = 0;
-        for (int i = tid; i < ns; i += 256) {
-            const double x = row[i];
-            nn += (x != x) ? 1u : 0u;
-            const unsigned long long k = key_of(x);
-            lo = k < lo ? k : lo;
-            hi = k > hi ? k : hi;
+        for (long i0 = tid; i0 < ns; i0 += (long)QT * QU) {
+            double x[QU];
+#pragma unroll
+            for (int u = 0; u < QU; u++) x[u] = i0 + (long)u * QT < ns ? row[i0 + (long)u * QT] : row[tid < ns ? tid : 0];   // (a repeat of an element of the row)
+#pragma unroll
+            for (int u = 0; u < QU; u++) {
+                nn += (x[u] != x[u]) ? 1u : 0u;
+                const unsigned long long k = key_of(x[u]);
+                lo = k < lo ? k : lo;
+                hi = k > hi ? k : hi;
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long lo2 = __shfl_xor(lo, o, 64), hi2 = __shfl_xor(hi, o, 64);
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void k_row_quantiles(const double* __restrict_
                 }
             rep[tid] = r0;
         }
-        for (int i = tid; i < POST_NQ * 256; i += 256) (&hist[0][0])[i] = 0u;
+        for (int i = tid; i < POST_NQ * 256; i += QT) (&hist[0][0])[i] = 0u;
         __syncthreads();
         unsigned long long pf[POST_NQ];
         bool own[POST_NQ];
@@ -203,16 +210,24 @@ __global__ __launch_bounds__(256) void k_row_quantiles(const double* __restrict_
             own[r] = r < nq && rep[r] == r;
             pf[r] = own[r] ? prefix[r] : 0ull;
         }
-        for (int i = tid; i < ns; i += 256) {
-            const unsigned long long k = key_of(row[i]);
-            const unsigned byte = (unsigned)(k >> shift) & 255u;
+        for (long i0 = tid; i0 < ns; i0 += (long)QT * QU) {
+            double x[QU];
 #pragma unroll
-            for (int r = 0; r < POST_NQ; r++)
-                if (own[r] && (pass == 7 || ((k ^ pf[r]) >> (shift + 8)) == 0ull)) atomicAdd(&hist[r][byte], 1u);
+            for (int u = 0; u < QU; u++) x[u] = i0 + (long)u * QT < ns ? row[i0 + (long)u * QT] : 0.0;
+#pragma unroll
+            for (int u = 0; u < QU; u++) {
+                if (i0 + (long)u * QT < ns) {
+                    const unsigned long long k = key_of(x[u]);
+                    const unsigned byte = (unsigned)(k >> shift) & 255u;
+#pragma unroll
+                    for (int r = 0; r < POST_NQ; r++)
+                        if (own[r] && (pass == 7 || ((k ^ pf[r]) >> (shift + 8)) == 0ull)) atomicAdd(&hist[r][byte], 1u);
+                }
+            }
         }
         __syncthreads();
-        // wave w resolves ranks w, w + 4: lane l owns bins 4 l .. 4 l + 3
-        for (int r = wave; r < nq; r += 4) {
+        // wave w resolves rank w: lane l owns bins 4 l .. 4 l + 3
+        for (int r = wave; r < nq; r += QT / 64) {
             const unsigned* h = hist[rep[r]];
             const unsigned c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
             unsigned incl = c0 + c1 + c2 + c3;
@@ -363,7 +378,7 @@ int carma_psd_band(int nar, int nma, const double* ar_coefs, const double* ma_co
                            d_m, d_s, ns, d_f + f0, nfc, d_g);
         e = hipGetLastError();
         if (e == hipSuccess && nperc > 0) {
-            hipLaunchKernelGGL(k_row_quantiles, dim3(nfc), dim3(256), 0, nullptr, d_g, ns, 2 * nperc, d_rk, d_gam,
+            hipLaunchKernelGGL(k_row_quantiles, dim3(nfc), dim3(QT), 0, nullptr, d_g, ns, 2 * nperc, d_rk, d_gam,
                                d_band + (size_t)f0 * nperc);
             e = hipGetLastError();
         }
