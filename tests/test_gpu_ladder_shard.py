@@ -205,6 +205,25 @@ def test_native_rccl_exchange_walks_the_same_trajectory():
     assert acc[0] + acc[2] + acc[4] == acc[1] + acc[3]
 
 
+def test_sharded_ladder_on_the_large_ensemble_path(monkeypatch):
+    """The same with the blocks on the sampler path for large ensembles (carma_pt_lane.hip; forced here, CARMA_PT_KERNEL=lane):
+    global temperature slots and replica offsets reach its Philox keys, a block's iteration without its own sweep
+    (do_exchange = 0) leaves the chain-major state arrays as the sweep / boundary kernels expect them -- blocks 3 + 2 and
+    2 + 2 + 1 through RCCL-to-self walk the one-block ladder's trajectory bit for bit, and that one is the ladder kernel's
+    to rounding with the same boundary decisions."""
+    uth0, ulp0, _ = _unsharded()                            # default kernels
+    monkeypatch.setenv("CARMA_PT_KERNEL", "lane")
+    one = _run_native([5], rccl=False)
+    uth, ulp = one[0][0], one[0][1]
+    np.testing.assert_allclose(uth, uth0, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(ulp, ulp0, rtol=1e-8)
+    for blocks in ([3, 2], [2, 2, 1]):
+        out = _run_native(blocks)
+        assert np.array_equal(np.concatenate([o[0] for o in out], axis=1), uth), blocks
+        assert np.array_equal(np.concatenate([o[1] for o in out], axis=1), ulp), blocks
+        assert all(o[3] == NITER for o in out)
+
+
 def test_sharded_ladder_saves_the_coldest_chain():
     """carma_pt_sample_sharded: the sharded ladder as a complete sampler -- after every thin-th iteration AND its
     boundary swaps the coldest chain of every replica is saved (Sampler::SaveValues, samplers.cpp:118-124): the last
