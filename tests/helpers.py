@@ -71,7 +71,8 @@ def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=N
                 ns = noise_scale(int(i))
                 print("%s: entry %d: gpu err %.2e, oracle err %.2e here, up to %.2e within 3 ulp of theta" % (
                     what, i, eg / abs(truth), eo / abs(truth), ns))
-                eo = max(eo, ns * abs(truth) / max(arb_factor, 1e-300))
+                # (twice the largest of 6 p neighbours: a handful of samples underestimates a scale)
+                eo = max(eo, 2.0 * ns * abs(truth) / max(arb_factor, 1e-300))
             assert eg <= max(rtol * abs(truth), arb_factor * eo), (
                 "%s: entry %d differs from the oracle by %.2e and is further from the exact value "
                 "(gpu err %.2e, oracle err %.2e)" % (what, i, abs(got[i] - want[i]) / abs(want[i]),
