@@ -121,6 +121,9 @@ def _load():
     L.carma_mle_batched.restype = C.c_int
     L.carma_logprior.argtypes = [C.c_void_p, _dp]
     L.carma_logprior.restype = C.c_double
+    L.carma_kfilter_batch_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp,
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.carma_kfilter_batch_carma.restype = C.c_int
     L.carma_kfilter_carma.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp,
                                       _ip, C.c_int]
     L.carma_kfilter_car1.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _ip, C.c_int]
@@ -176,7 +179,7 @@ lib = _load()
 EXPORTS = [
     "carma_version", "carma_last_error", "carma_device_count", "carma_ctx_create", "carma_ctx_destroy",
     "carma_ctx_n", "carma_ctx_dim", "carma_ctx_get_data", "carma_ctx_get_prior", "carma_ctx_set_prior",
-    "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_mle_batched", "carma_kfilter_carma",
+    "carma_logdensity_batch", "carma_logdensity_batch_dev", "carma_logdensity_kernel_name", "carma_logprior", "carma_mle_batched", "carma_kfilter_carma", "carma_kfilter_batch_carma",
     "carma_kfilter_car1", "carma_predict_carma", "carma_predict_car1", "carma_normalize_roots", "carma_kf_create_carma", "carma_kf_create_car1",
     "carma_kf_destroy", "carma_kf_n", "carma_kf_filter", "carma_kf_predict", "carma_simulate_carma", "carma_simulate_car1", "carma_sigma_noise_batch", "carma_psd_band", "carma_pt_run", "carma_pt_create", "carma_pt_shard", "carma_pt_bind_state",
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
@@ -502,6 +505,35 @@ def kfilter_carma(time, y, yerr, sigsqr, omega, ma, device=None):
         raise CarmaError("KalmanFilterp: singular eigenvector matrix (solve failed)")
     check(rc, "carma_kfilter_carma")
     return mean[:nout.value], var[:nout.value]
+
+
+def kfilter_carma_batch(time, y, yerr, sigsqr, omega, ma, mu=None, device=None):
+    """Filter() of B models on one series in one launch: sigsqr [B], omega [B][p] complex, ma [B][nma], mu [B] or None
+    -> (mean [B][n], var [B][n], singular [B] bool).  mu is subtracted from y inside and added back to mean."""
+    time, y, yerr = as_f64(time), as_f64(y), as_f64(yerr)
+    omega = np.atleast_2d(np.asarray(omega, dtype=complex))
+    B, p = omega.shape
+    om = as_f64(np.stack([omega.real, omega.imag], axis=-1))
+    ma = as_f64(np.atleast_2d(ma))
+    sig = as_f64(np.atleast_1d(sigsqr))
+    if ma.shape[0] != B or sig.size != B:
+        raise ValueError("kfilter_carma_batch: sigsqr, omega and ma must describe the same number of models")
+    mu_ = None if mu is None else as_f64(np.atleast_1d(mu))
+    if mu_ is not None and mu_.size != B:
+        raise ValueError("kfilter_carma_batch: mu must have one entry per model")
+    mean, var = np.empty((B, time.size)), np.empty((B, time.size))
+    sing = np.zeros(B, dtype=np.int32)
+    nout = C.c_int(0)
+    rc = lib.carma_kfilter_batch_carma(ptr(time), ptr(y), ptr(yerr), time.size, p, B, ptr(sig), ptr(om), ptr(ma), ma.shape[1],
+                                       ptr(mu_) if mu_ is not None else None, ptr(mean), ptr(var),
+                                       sing.ctypes.data_as(C.POINTER(C.c_int)), C.byref(nout),
+                                       default_device() if device is None else device)
+    check(rc, "carma_kfilter_batch_carma")
+    m = nout.value
+    # (the library writes rows of n_out values back to back)
+    mean = mean.reshape(-1)[:B * m].reshape(B, m)
+    var = var.reshape(-1)[:B * m].reshape(B, m)
+    return mean, var, sing.astype(bool)
 
 
 def kfilter_car1(time, y, yerr, sigsqr, omega, device=None):

@@ -571,6 +571,56 @@ int carma_kfilter_carma(const double* time, const double* y, const double* yerr,
     return rc;
 }
 
+int carma_kfilter_batch_carma(const double* time, const double* y, const double* yerr, int n, int p, int nmodels, const double* sigsqr,
+                              const double* omega_re_im, const double* ma, int nma, const double* mu, double* mean, double* var,
+                              int* singular, int* n_out, int device)
+{
+    if (!time || !y || !yerr || n < 2 || p < 2 || p > CARMA_PMAX || nmodels < 1 || !sigsqr || !omega_re_im || !ma || nma < 1 ||
+        nma > p || !mean || !var) {
+        set_error("carma_kfilter_batch_carma: bad argument (n >= 2, 2 <= p <= %d, 1 <= nma <= p, nmodels >= 1)", CARMA_PMAX);
+        return CARMA_EINVAL;
+    }
+    int rc = select_device(device);
+    if (rc != CARMA_OK) return rc;
+    std::vector<double> t(time, time + n), yy(y, y + n), ee(yerr, yerr + n);
+    sort_dedup(t, yy, ee);
+    const int m = (int)t.size();
+    if (n_out) *n_out = m;
+    const std::vector<double> s = pack_series(t, yy, ee);
+    const int PW = 3 * p + 2;
+    std::vector<double> par((size_t)nmodels * PW, 0.0);
+    for (int b = 0; b < nmodels; b++) {
+        double* pb = par.data() + (size_t)b * PW;
+        if (normalize_roots(p, omega_re_im + (size_t)b * 2 * p, pb) != CARMA_OK) {
+            set_error("carma_kfilter_batch_carma: model %d: the AR roots must be real or come in complex-conjugate pairs", b);
+            return CARMA_EINVAL;
+        }
+        for (int i = 0; i < nma; i++) pb[2 * p + i] = ma[(size_t)b * nma + i];     // zero padded to p (kfilter.hpp:318-320)
+        pb[3 * p] = sigsqr[b];
+        pb[3 * p + 1] = mu ? mu[b] : 0.0;
+    }
+    double *d_s = nullptr, *d_par = nullptr, *d_mv = nullptr, *d_mean = nullptr, *d_var = nullptr;
+    int* d_sing = nullptr;
+    const size_t nmv = (size_t)2 * m * ((size_t)nmodels + 64), nout = (size_t)nmodels * m;
+    hipError_t e = hipMalloc(&d_s, sizeof(double) * s.size());
+    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = hipMalloc(&d_mv, sizeof(double) * nmv);
+    if (e == hipSuccess) e = hipMalloc(&d_mean, sizeof(double) * nout);
+    if (e == hipSuccess) e = hipMalloc(&d_var, sizeof(double) * nout);
+    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int) * nmodels);
+    if (e == hipSuccess) e = hipMemcpy(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launch_kfilter_batch(p, d_par, nmodels, reinterpret_cast<const double4*>(d_s), m, d_mv, d_sing, d_mean, d_var, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(mean, d_mean, sizeof(double) * nout, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(var, d_var, sizeof(double) * nout, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && singular) e = hipMemcpy(singular, d_sing, sizeof(int) * nmodels, hipMemcpyDeviceToHost);
+    for (void* q : {(void*)d_s, (void*)d_par, (void*)d_mv, (void*)d_mean, (void*)d_var, (void*)d_sing})
+        if (q) (void)hipFree(q);
+    if (e != hipSuccess) return hip_fail(e, "carma_kfilter_batch_carma");
+    return CARMA_OK;
+}
+
 int carma_kfilter_car1(const double* time, const double* y, const double* yerr, int n, double sigsqr, double omega,
                        double* mean, double* var, int* n_out, int device)
 {

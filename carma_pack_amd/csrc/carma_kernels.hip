@@ -204,6 +204,39 @@ __global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restr
     if (live) out[e] = ll;
 }
 
+// KalmanFilterp::Filter() for MANY models at once (round 4): one model per lane (carma_lane.h kfilter_lane), the series shared.
+// par: per model [B][3 P + 2]: P roots (re, im) in normalised order, P MA coefficients, sigsqr, mu.  mv: [2 n][B] (mean rows, then
+// variance rows; a wave's stores of one row are contiguous) -- transposed into the caller's [B][n] arrays by k_transpose_mv.
+template <int P>
+__global__ __launch_bounds__(64) void k_kfilter_carma_lane(const double* __restrict__ par, int B, const double4* __restrict__ series,
+                                                          int n, double* __restrict__ mv, int* __restrict__ singular)
+{
+    __shared__ double s_tab[MATH_TAB_N];
+    math_tab_fill(s_tab);
+    __syncthreads();
+    long e = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    const double* pm = par + e * (3 * P + 2);
+    // idle lanes of the last wave write to a spare column (mv has B + 64 columns)
+    const bool sing = kfilter_lane<P>(pm, pm + 2 * P, pm[3 * P], pm[3 * P + 1], series, n, s_tab, mv + (live ? e : (long)B + threadIdx.x),
+                                      (long)B + 64);
+    if (live) singular[e] = sing ? 1 : 0;
+}
+
+// in [rows][ld] (first `cols` columns of every row) -> out [cols][rows]
+__global__ __launch_bounds__(256) void k_transpose_mv(const double* __restrict__ in, long ld, int rows, int cols, double* __restrict__ out)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;    // bx: column block of `in`, by: row block
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(long)(by + j) * ld + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < cols && by + tx < rows) out[(long)(bx + j) * rows + by + tx] = tile[tx][j];
+}
+
 __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ theta, int B,
                                                      const double4* __restrict__ series, int n, Prior pr,
                                                      double* __restrict__ out)
@@ -539,6 +572,27 @@ hipError_t launch_kfilter_carma(int p, const double* om, const double* ma, doubl
         case 7: return launch_kfilter_p<7>(om, ma, sigsqr, series, n, mean, var, singular, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_kfilter_batch(int p, const double* par, int B, const double4* series, int n, double* mv, int* singular,
+                                double* mean, double* var, hipStream_t st)
+{
+    (void)hipGetLastError();
+    const unsigned blocks = (unsigned)(((long)B + 63) / 64);
+    switch (p) {
+#define CARMA_KFB(N) \
+    case N: hipLaunchKernelGGL((k_kfilter_carma_lane<N>), dim3(blocks), dim3(64), 0, st, par, B, series, n, mv, singular); break;
+        CARMA_KFB(2) CARMA_KFB(3) CARMA_KFB(4) CARMA_KFB(5) CARMA_KFB(6) CARMA_KFB(7)
+#undef CARMA_KFB
+        default: return hipErrorInvalidValue;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long ld = (long)B + 64;
+    const dim3 grid((unsigned)((B + 31) / 32), (unsigned)((n + 31) / 32));
+    hipLaunchKernelGGL(k_transpose_mv, grid, dim3(256), 0, st, mv, ld, n, B, mean);
+    hipLaunchKernelGGL(k_transpose_mv, grid, dim3(256), 0, st, mv + (size_t)n * ld, ld, n, B, var);
+    return hipGetLastError();
 }
 
 template <int P>

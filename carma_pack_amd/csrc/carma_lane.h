@@ -275,8 +275,11 @@ __device__ __forceinline__ void lane_produce(int k, const double* theta, double*
 #endif
 
 // Reset + n - 1 Updates -> log-likelihood sum (no prior)
-template <int P, class Src>
-CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ series, int n, const Src& src)
+// WRITE_MV: also store mean_k = h.z + mu and var_k of every datum (KalmanFilter::GetMean / GetVar,
+// src/include/kfilter.hpp:116-117) to mv[k * mv_stride] and mv[(n + k) * mv_stride]
+template <int P, class Src, bool WRITE_MV = false>
+CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ series, int n, const Src& src, double* mv = nullptr,
+                             long mv_stride = 0)
 {
     constexpr int NT = P * (P + 1) / 2;
     constexpr int PE = P & ~1;                               // coordinates that belong to pairs
@@ -317,6 +320,10 @@ CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ 
         }
         const double var = m.s0 + pv + rprev.z * m.scale;
         const double innov = (rprev.y - m.mu) - pm;
+        if constexpr (WRITE_MV) {
+            mv[(long)(kk - 1) * mv_stride] = pm + m.mu;
+            mv[(long)(n + kk - 1) * mv_stride] = var;
+        }
         acc.add_var(var);
         const double s = recip(var);
         const double si = s * innov;
@@ -382,10 +389,86 @@ CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ 
         }
         const double var = m.s0 + pv + rprev.z * m.scale;
         const double innov = (rprev.y - m.mu) - pm;
+        if constexpr (WRITE_MV) {
+            mv[(long)(n - 1) * mv_stride] = pm + m.mu;
+            mv[(long)(2 * n - 1) * mv_stride] = var;
+        }
         acc.add_var(var);
         acc.chi2 += innov * (recip(var) * innov);
     }
     return acc.total();
+}
+
+// KalmanFilterp(time, y, yerr, sigsqr, omega, ma_coefs) as one lane: the model from its roots (adjacent conjugate pairs first,
+// then the real roots: carma_normalize_roots) and MA coefficients (lowest order first, zero padded to P) instead of theta --
+// b_r = beta(omega_r) and beta(-omega_r) by Horner, kappa_r = beta(-omega_r) / (alpha'(omega_r) alpha(-omega_r)) (struct Model),
+// s0 = sigsqr * sum_r Re(b_r kappa_r), c_r = sigsqr kappa_r, all in the real modal coordinates of lane_model_from_theta.
+template <int P>
+CARMA_DEV void lane_model_from_roots(const double* om_re_im, const double* ma, double sigsqr, double mu, LaneModel<P>& m)
+{
+    Cx w[P], b[P], kap[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) w[j] = Cx{om_re_im[2 * j], om_re_im[2 * j + 1]};
+    bool sing = false;
+    double var1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        Cx br = {0.0, 0.0}, bm = {0.0, 0.0};
+        const Cx nw = {-w[r].re, -w[r].im};
+#pragma unroll
+        for (int i = P - 1; i >= 0; i--) {
+            br = cadd(cmul(br, w[r]), Cx{ma[i], 0.0});
+            bm = cadd(cmul(bm, nw), Cx{ma[i], 0.0});
+        }
+        b[r] = br;
+        Cx ap = {1.0, 0.0}, am = {1.0, 0.0};
+#pragma unroll
+        for (int l = 0; l < P; l++) {
+            const Cx dl = csub(w[r], w[l]);
+            const Cx sl = {-(w[r].re + w[l].re), -(w[r].im + w[l].im)};
+            if (l != r) ap = cmul(ap, dl);
+            am = cmul(am, sl);
+        }
+        if (ap.re == 0.0 && ap.im == 0.0) sing = true;
+        kap[r] = cdiv(bm, cmul(ap, am));
+        var1 += b[r].re * kap[r].re - b[r].im * kap[r].im;
+    }
+    m.s0 = sigsqr * var1;
+    m.scale = 1.0;
+    m.mu = mu;
+    m.sing = sing;
+    m.valid = true;
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        m.wre[r] = w[r].re;
+        m.wim[r] = w[r].im;
+        const bool cpx = (w[r].im != 0.0) && (r < (P & ~1));
+        const int ev = r & ~1;
+        if (cpx) {
+            m.h[r] = (r & 1) ? 2.0 * b[r].im : 2.0 * b[r].re;
+            m.c[r] = sigsqr * ((r & 1) ? kap[ev].im : kap[r].re);
+        } else {
+            m.h[r] = b[r].re;
+            m.c[r] = sigsqr * kap[r].re;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (P + 1) / 2; i++) m.realpair[i] = (2 * i + 1 < P) && (w[2 * i].im == 0.0);
+}
+
+// Filter() of one model per lane: mean[n], var[n] into mv (see lane_filter); returns the repeated-root flag
+template <int P>
+CARMA_DEV bool kfilter_lane(const double* om_re_im, const double* ma, double sigsqr, double mu, const double4* __restrict__ series,
+                            int n, const double* tab, double* mv, long mv_stride)
+{
+    LaneModel<P> m;
+    lane_model_from_roots<P>(om_re_im, ma, sigsqr, mu, m);
+    bool anyreal = false;
+#pragma unroll
+    for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
+    const LaneFactorsInline<P> src{m, lane_any(anyreal), tab};
+    (void)lane_filter<P, LaneFactorsInline<P>, true>(m, series, n, src, mv, mv_stride);
+    return m.sing;
 }
 
 // CARMA_Base::LogDensity (carpack.hpp:131-176): -inf outside the prior bounds or on a repeated root, else

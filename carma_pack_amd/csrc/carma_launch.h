@@ -23,6 +23,10 @@ hipError_t launch_kfilter_carma(int p, const double* om_re_im, const double* ma,
 hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* series, int n, double* mean, double* var,
                                hipStream_t st);
 
+// Filter() of B models in one launch (one model per lane): par = [B][3 p + 2] (roots re/im in normalised order, p MA
+// coefficients, sigsqr, mu), mv = scratch of 2 n (B + 64) doubles; mean / var = [B][n] (device)
+hipError_t launch_kfilter_batch(int p, const double* par, int B, const double4* series, int n, double* mv, int* singular,
+                                double* mean, double* var, hipStream_t st);
 hipError_t launch_predict_carma(int p, const double* om_re_im, const double* ma, double sigsqr, const double4* series,
                                 int n, const double* tpred, int M, double* pmean, double* pvar, int* singular,
                                 hipStream_t st);

@@ -119,6 +119,18 @@ double carma_logprior(const carma_ctx* h, const double* theta);
 int carma_kfilter_carma(const double* time, const double* y, const double* yerr, int n, int p,
                         double sigsqr, const double* omega_re_im, const double* ma, int nma,
                         double* mean, double* var, int* n_out, int device);
+/*
+ * Filter() of nmodels CARMA(p, nma-1) models on ONE series in one launch (one model per lane): what
+ * a caller looping KalmanFilterp(...).Filter() over posterior samples does (carma_pack.py:374-386 builds
+ * one filter per call).  sigsqr [nmodels], omega_re_im [nmodels][p][2], ma [nmodels][nma] (ma[.][0] = 1),
+ * mu [nmodels] or NULL (0): subtracted from y and added back to mean, as carma_pack.py:399-400 / :442 do
+ * around the filter.  mean, var: [nmodels][n_out] row-major (allocate [nmodels][n]).  singular
+ * [nmodels] or NULL: 1 where a model has coincident roots (its rows are then not meaningful: the reference's solve throws).
+ */
+int carma_kfilter_batch_carma(const double* time, const double* y, const double* yerr, int n, int p,
+                              int nmodels, const double* sigsqr, const double* omega_re_im,
+                              const double* ma, int nma, const double* mu, double* mean, double* var,
+                              int* singular, int* n_out, int device);
 /* KalmanFilter1(time,y,yerr,sigsqr,omega).Filter() (kfilter.hpp:222-245; kfilter.cpp:19-48). */
 int carma_kfilter_car1(const double* time, const double* y, const double* yerr, int n,
                        double sigsqr, double omega, double* mean, double* var, int* n_out,

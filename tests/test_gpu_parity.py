@@ -851,3 +851,50 @@ def test_lane_kernel_prior_like_sweep(cpa, p):
                           arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.04)
             gotp = ctx.logdensity(np.tile(th, (Bp // 160 + 1, 1))[:Bp], ignore_prior=ign)
             assert np.array_equal(gotp, np.tile(got[:160], Bp // 160 + 1)[:Bp], equal_nan=True), "producer waves p=%d q=%d" % (p, q)
+
+
+@pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
+def test_filter_of_many_models_in_one_launch(cpa, p):
+    """carma_kfilter_batch_carma (round 4): Filter() of B models on one series, one model per lane -- KalmanFilterp::Filter
+    (src/kfilter.cpp:19-48, 138-215) looped over posterior samples.  130 prior-like models per (p, q) (two waves and two lanes:
+    the last wave is mostly idle), an unsorted series with a duplicated time: every model's mean / variance vectors against
+    the oracle's filter -- variances to 1e-9 relative, means to 1e-9 of the data's scale, or no further from the
+    quad-precision filter than the oracle is -- and against the one-model entry point."""
+    for q in range(p):
+        t, y, yerr = irregular_series(120, seed=500 * p + q)
+        rng = np.random.default_rng(4000 + 10 * p + q)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(130)])
+        roots = np.array([orc.ar_roots(x, p) for x in th])
+        ma = np.array([orc.ma_coefs(x, p, q) for x in th])[:, : q + 1]
+        sig2 = np.array([x[0] ** 2 / orc.variance(r, m) for x, r, m in zip(th, roots, ma)])
+        # per-model measurement-error scaling is theta[1]; the batched entry point takes ONE series, so hold it at 1
+        perm = rng.permutation(t.size)
+        tt, yy, ee = np.r_[t[perm], t[perm[3]]], np.r_[y[perm], 5.0], np.r_[yerr[perm], 1.0]
+        mean, var, sing = cpa.kfilter_carma_batch(tt, yy, ee, sig2, roots, ma, mu=th[:, 2])
+        assert mean.shape == (130, t.size) and var.shape == (130, t.size) and not sing.any()
+        nworse = 0
+        for i in range(130):
+            om, ov = orc.kfilter_carma(t, y - th[i, 2], yerr, sig2[i], roots[i], ma[i])
+            sc = np.abs(y - th[i, 2]).max()
+            dev = max(np.max(np.abs(mean[i] - th[i, 2] - om)) / sc, np.max(np.abs(var[i] - ov) / ov))
+            if dev > 1e-9:
+                thx = th[i].copy()
+                thx[1] = 1.0
+                tm, tv = orc.truth_filter(t, y, yerr, thx, p, q)
+                eg = max(np.max(np.abs(mean[i] - th[i, 2] - tm)) / sc, np.max(np.abs(var[i] - tv) / tv))
+                eo = max(np.max(np.abs(om - tm)) / sc, np.max(np.abs(ov - tv) / tv))
+                nworse += 1
+                assert eg <= max(1e-9, 1.25 * eo), (p, q, i, eg, eo)
+        assert nworse <= 13, nworse
+        for i in (0, 64, 129):
+            m1, v1 = cpa.kfilter_carma(t, y - th[i, 2], yerr, sig2[i], roots[i], ma[i])
+            np.testing.assert_allclose(var[i], v1, rtol=1e-9)
+            np.testing.assert_allclose(mean[i] - th[i, 2], m1, rtol=0, atol=1e-9 * np.abs(y - th[i, 2]).max())
+    with pytest.raises(ValueError):
+        cpa.kfilter_carma_batch(t, y, yerr, sig2[:3], roots, ma)
+    # a model whose roots are not closed under conjugation is rejected, and named
+    bad = roots.copy()
+    bad[7, 0] = -0.3 + 0.2j
+    bad[7, 1:] = -0.1 * np.arange(1, p)
+    with pytest.raises(ValueError, match="model 7"):
+        cpa.kfilter_carma_batch(t, y, yerr, sig2, bad, ma)
