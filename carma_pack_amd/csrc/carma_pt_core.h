@@ -150,8 +150,10 @@ CARMA_DEV void exchange_sweep(int T, int d, int stride, double* th, double* lp, 
 // src[] (src[i] = which chain's theta ends up at temperature i) and the chains copy their new theta
 // afterwards, in parallel.  u < min(exp(a), 1)  <=>  log u < a  (a NaN -> reject, as steps.hpp:336-338).
 // dbeta[i] = 1/T_i - 1/T_{i-1}, so a = (lp[i-1] - lp[i]) * dbeta[i]   (steps.hpp:331-332).
-CARMA_DEV void exchange_decide(int T, double* lp, const double* dbeta, const double* logu, int* src, unsigned* nswap)
+// Returns the accepted swaps as a mask (bit i: temperatures i and i - 1 exchanged) -- the caller counts them.
+CARMA_DEV unsigned long long exchange_decide_mask(int T, double* lp, const double* dbeta, const double* logu, int* src)
 {
+    unsigned long long mask = 0;
     double hot = lp[T - 1];
     int hot_src = src[T - 1];
     for (int i = T - 1; i > 0; i--) {
@@ -161,7 +163,7 @@ CARMA_DEV void exchange_decide(int T, double* lp, const double* dbeta, const dou
         if (logu[i] < a) {
             lp[i] = cold;            // temperature i now holds the colder chain's state
             src[i] = cold_src;
-            nswap[i]++;
+            mask |= 1ull << i;
             // `hot` (the state that moved down) is what temperature i-1 now holds
         } else {
             lp[i] = hot;
@@ -172,6 +174,13 @@ CARMA_DEV void exchange_decide(int T, double* lp, const double* dbeta, const dou
     }
     lp[0] = hot;
     src[0] = hot_src;
+    return mask;
+}
+CARMA_DEV void exchange_decide(int T, double* lp, const double* dbeta, const double* logu, int* src, unsigned* nswap)
+{
+    const unsigned long long mask = exchange_decide_mask(T, lp, dbeta, logu, src);
+    for (int i = 1; i < T; i++)
+        if ((mask >> i) & 1ull) nswap[i]++;
 }
 
 }  // namespace carma

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, cons
     __shared__ double s_vec[256 * RAM_DS];                   // staging of the lanes' current values for the sweep
     __shared__ double s_lp[256], s_logu[256], s_dbeta[256];
     __shared__ int s_src[256];
+    __shared__ unsigned long long s_mask[256];
     const RamLane x = ram_lane(L);
     constexpr int d = D, NT = D * (D + 1) / 2;
     const int T = L.T, tid = threadIdx.x;
@@ -168,18 +169,44 @@ __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, cons
     double* vec = s_vec + tid * RAM_DS;
     const int wbase = tid & ~63;                             // this wave's first slot
     const bool adapt = (long)iter < (long)L.maxiter;
+    // (the three scalars FIRST: loads return in order, and whatever is computed from them early then waits for them alone)
+    const double ll_in = S.ll[x.gi];
+    const double lp_in = S.lp[x.gi], z2_in = adapt ? S.z2[x.gi] : 1.0;
+    // (the counters too: an increment behind the factor's stores would wait for all of them -- loads and stores share a counter)
+    const bool exch = L.do_exchange && L.T > 1;
+    const unsigned nacc_in = naccept[x.gi], nswap_in = exch ? nswap[x.gi] : 0u;
     // the factor and v: requested up front (independent loads), used by the adaptation below (and by the next proposal)
     double Rr[NT], v[D];
     if (adapt || NEXT) {
 #pragma unroll
         for (int i = 0; i < NT; i++) Rr[i] = S.R[(long)i * S.nc + x.gi];
     }
-    if (adapt) {
+    // v = R^T z of this iteration's proposal and the current value: the proposal K1 evaluated is th + v, bit for bit (the
+    // sum k_ram_propose / the NEXT block below stored as thn[chain][.] -- re-formed here from two coalesced rows instead of a
+    // strided read of that batch)
+    double th[D];
 #pragma unroll
-        for (int j = 0; j < D; j++) v[j] = S.v[(long)j * S.nc + x.gi];
+    for (int j = 0; j < D; j++) v[j] = S.v[(long)j * S.nc + x.gi];
+#pragma unroll
+    for (int j = 0; j < D; j++) th[j] = S.th[(long)j * S.nc + x.gi];
+    // NEXT: the draws of the following proposal depend on nothing but the key -- they run HERE, while the loads above are in
+    // flight (a wave of this kernel has its SIMD to itself up to 65 536 chains: nothing else hides that latency)
+    double z[NEXT ? D : 1];
+    double znorm2_next = 0.0;
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int i = 0; i < D; i++) z[i] = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < D; k++) {
+            const double zk = rng_student_t8(key, iter + 1, (uint32_t)k);
+            // (z[k] with a run-time k: a chain of selects instead of a copy of the generator per component)
+#pragma unroll
+            for (int i = 0; i < D; i++) z[i] = i == k ? zk : z[i];
+            znorm2_next += zk * zk;
+        }
     }
-    const double ll = S.ll[x.gi];
-    double lp = S.lp[x.gi];
+    const double ll = ll_in;
+    double lp = lp_in;
     double alpha = (ll - lp) / temps[x.c];
     bool accept = false;
     if (!((alpha - alpha) == 0.0)) {
@@ -189,17 +216,16 @@ __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, cons
         alpha = fmin(exp(alpha), 1.0);
         accept = u < alpha;
     }
-    if (accept && x.active) {                                // parameter_.Save(new_value) (steps.cpp:77)
+    if (accept) {                                            // parameter_.Save(new_value) (steps.cpp:77)
         lp = ll;
-        S.lp[x.gi] = ll;
-        naccept[x.gi]++;
 #pragma unroll
-        for (int j = 0; j < D; j++) S.th[(long)j * S.nc + x.gi] = S.thn[x.gi * D + j];
+        for (int j = 0; j < D; j++) th[j] += v[j];
+        if (x.active) naccept[x.gi] = nacc_in + 1u;
     }
     // ---- adaptation while niter < maxiter (ram_finish / chol_update_r1 of carma_pt_core.h, steps.cpp:82-99, 111-131)
     if (adapt) {
         const double step = fmin(1.0, (double)d / pow((double)iter, 2.0 / 3.0));   // iter = 0 -> 1
-        const double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(S.z2[x.gi]);
+        const double fac = sqrt(step * fabs(alpha - 0.25)) / sqrt(z2_in);
         const double sign = alpha < 0.25 ? -1.0 : 1.0;
 #pragma unroll
         for (int j = 0; j < D; j++) v[j] *= fac;
@@ -227,68 +253,50 @@ __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, cons
             for (int i = 0; i < NT; i++) S.R[(long)i * S.nc + x.gi] = Rr[i];
         }
     }
-    // ---- ExchangeStep sweep hot -> cold over the ladder's T lanes
-    const bool exch = L.do_exchange && T > 1;
+    // ---- ExchangeStep sweep hot -> cold over the ladder's T lanes: the lanes' values are staged in LDS, one lane per ladder
+    // replays the serial decisions, every lane fetches the vector the sweep assigned to its temperature
     const bool save = L.save_thin > 0 && x.active && x.c0 == 0 && L.save_offset < L.sample_cap;
+    bool moved = accept;                                     // the lane's value in global memory is out of date
     if (exch) {
-#pragma unroll 1
-        for (int j = 0; j < d; j++) vec[j] = S.th[(long)j * S.nc + x.gi];      // staging of the lane's current value
+#pragma unroll
+        for (int j = 0; j < D; j++) vec[j] = th[j];
         s_lp[tid] = lp;
         s_src[tid] = x.c0;
         s_dbeta[tid] = x.c > 0 ? 1.0 / temps[x.c] - 1.0 / temps[x.c - 1] : 0.0;
         s_logu[tid] = x.c > 0 ? log(rng_uniform(key, iter, RNG_SWAP, 0)) : 0.0;   // keyed by the hotter chain's global slot
         wave_sync();
         const int lb = wbase + x.lbase;
-        if (x.active && x.c0 == 0) exchange_decide(T, s_lp + lb, s_dbeta + lb, s_logu + lb, s_src + lb, nswap + x.lad * T);
+        if (x.active && x.c0 == 0) s_mask[lb] = exchange_decide_mask(T, s_lp + lb, s_dbeta + lb, s_logu + lb, s_src + lb);
         wave_sync();
+        if (x.active && ((s_mask[lb] >> x.c0) & 1ull)) nswap[x.gi] = nswap_in + 1u;   // ExchangeStep's count, per hotter temperature
         const int from = s_src[tid];
         const double* src = s_vec + (lb + from) * RAM_DS;
-        if (x.active && from != x.c0) {
-            S.lp[x.gi] = s_lp[tid];
-#pragma unroll 1
-            for (int j = 0; j < d; j++) S.th[(long)j * S.nc + x.gi] = src[j];
-        }
-        if (save) {
-#pragma unroll 1
-            for (int j = 0; j < d; j++) samples[(x.lad * L.sample_cap + L.save_offset) * d + j] = src[j];
-            sample_lp[x.lad * L.sample_cap + L.save_offset] = s_lp[tid];
-        }
-    } else if (save) {
-#pragma unroll 1
-        for (int j = 0; j < d; j++) samples[(x.lad * L.sample_cap + L.save_offset) * d + j] = S.th[(long)j * S.nc + x.gi];
+        moved = moved || from != x.c0;
+        lp = s_lp[tid];
+#pragma unroll
+        for (int j = 0; j < D; j++) th[j] = src[j];
+    }
+    if (moved && x.active) {
+        S.lp[x.gi] = lp;
+#pragma unroll
+        for (int j = 0; j < D; j++) S.th[(long)j * S.nc + x.gi] = th[j];
+    }
+    if (save) {                                              // Sampler::SaveValues: the coldest chain's value and log-posterior
+#pragma unroll
+        for (int j = 0; j < D; j++) samples[(x.lad * L.sample_cap + L.save_offset) * d + j] = th[j];
         sample_lp[x.lad * L.sample_cap + L.save_offset] = lp;
     }
     if constexpr (NEXT) {
-        // ---- the next iteration's proposal (k_ram_propose): the current value is what the sweep assigned to this lane
-        double cur[D];
-        if (exch) {
-            const double* src = s_vec + (wbase + x.lbase + s_src[tid]) * RAM_DS;
-#pragma unroll
-            for (int j = 0; j < D; j++) cur[j] = src[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < D; j++) cur[j] = S.th[(long)j * S.nc + x.gi];
-        }
-        double z[D];
-#pragma unroll
-        for (int i = 0; i < D; i++) z[i] = 0.0;
-        double znorm2 = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < D; k++) {
-            const double zk = rng_student_t8(key, iter + 1, (uint32_t)k);
-#pragma unroll
-            for (int i = 0; i < D; i++) z[i] = i == k ? zk : z[i];
-            znorm2 += zk * zk;
-        }
+        // ---- the next iteration's proposal (k_ram_propose) from the value the sweep left in this lane
         if (!x.active) return;
-        S.z2[x.gi] = znorm2;
+        S.z2[x.gi] = znorm2_next;
 #pragma unroll
         for (int j = 0; j < D; j++) {
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k <= j; k++) acc += Rr[k * D - k * (k - 1) / 2 + (j - k)] * z[k];
             S.v[(long)j * S.nc + x.gi] = acc;
-            S.thn[x.gi * D + j] = cur[j] + acc;
+            S.thn[x.gi * D + j] = th[j] + acc;
         }
     }
 }
