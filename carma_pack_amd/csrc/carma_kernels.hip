@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
 
 // Throughput regime proper (tens of thousands of evaluations): ONE EVALUATION PER LANE (carma_lane.h) -- nothing crosses
 // lanes, all 64 lanes work; a wave per 64 evaluations.
-template <int P>
+// REPDT (here and below): the variant for series with repeated time steps (carma_lane.h, lane_filter)
+template <int P, bool REPDT = false>
 __global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restrict__ theta, int B, int d, int q,
                                                           const double4* __restrict__ series, int n, Prior pr,
                                                           int ignore_prior, double* __restrict__ out)
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restr
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e < B;
     if (!live) e = B - 1;
-    const double ll = logdensity_lane<P>(theta + e * d, q, series, n, pr, ignore_prior, s_tab);
+    const double ll = logdensity_lane<P, REPDT>(theta + e * d, q, series, n, pr, ignore_prior, s_tab);
     if (live) out[e] = ll;
 }
 
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restr
 // Which wave plays which part rotates with the round of workgroups (blockIdx against the CU count): the waves of the
 // workgroups that share a CU land on its SIMDs in a fixed pattern (tools/ubench/wave_placement.hip), and two consumers
 // on one SIMD would wait for each other.
-template <int P, int NP>
+template <int P, int NP, bool REPDT = false>
 __global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restrict__ theta, int B, int d, int q,
                                                            const double4* __restrict__ series, int n, Prior pr,
                                                            int ignore_prior, double* __restrict__ out, int ncu, int rot)
@@ -197,10 +198,10 @@ __global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restr
     math_tab_fill(s_tab);
     __syncthreads();
     if (part >= Geo::NC) {
-        lane_produce<P, NP>((part - Geo::NC) % NP, theta + e * d, ring, series, n, s_tab);
+        lane_produce<P, NP, REPDT>((part - Geo::NC) % NP, theta + e * d, ring, series, n, s_tab);
         return;
     }
-    const double ll = logdensity_lane_ring<P, NP>(theta + e * d, q, series, n, pr, ignore_prior, ring);
+    const double ll = logdensity_lane_ring<P, NP, REPDT>(theta + e * d, q, series, n, pr, ignore_prior, ring);
     if (live) out[e] = ll;
 }
 
@@ -473,14 +474,22 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
         case LdShape::LANE:
             // (half-filled waves -- 32 evaluations per wave, twice the waves -- are no faster per wave: an FP64 instruction
             // takes its four cycles whatever the execution mask; 65 536 evaluations 344 vs 233 us)
-            hipLaunchKernelGGL((k_logdens_carma_lane<P>), dim3((unsigned)(((long)B + 63) / 64)), dim3(64), 0, st, theta, B, d, q, series,
-                               n, pr, ignore_prior, out);
+            if (repeated_dt)
+                hipLaunchKernelGGL((k_logdens_carma_lane<P, true>), dim3((unsigned)(((long)B + 63) / 64)), dim3(64), 0, st, theta, B, d, q,
+                                   series, n, pr, ignore_prior, out);
+            else
+                hipLaunchKernelGGL((k_logdens_carma_lane<P>), dim3((unsigned)(((long)B + 63) / 64)), dim3(64), 0, st, theta, B, d, q,
+                                   series, n, pr, ignore_prior, out);
             return hipGetLastError();
         case LdShape::LPC: {
             using Geo = LaneRingGeom<P, 3>;
             static_assert(Geo::BYTES <= 64 * 1024, "within the LDS a launch may ask for without raising the kernel's limit");
-            hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta, B, d, q,
-                               series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
+            if (repeated_dt)
+                hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3, true>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta,
+                                   B, d, q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
+            else
+                hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta, B, d,
+                                   q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
             return hipGetLastError();
         }
         case LdShape::PLAIN4:
@@ -506,8 +515,8 @@ static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
         case LdShape::PC2: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,2>", P, G);
         case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1%s>", P, G, dtc);
         case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4%s>", P, G, dtc);
-        case LdShape::LANE: return snprintf(buf, len, "k_logdens_carma_lane<%d>", P);
-        case LdShape::LPC: return snprintf(buf, len, "k_logdens_carma_lpc<%d,3>", P);
+        case LdShape::LANE: return snprintf(buf, len, "k_logdens_carma_lane<%d%s>", P, dtc);
+        case LdShape::LPC: return snprintf(buf, len, "k_logdens_carma_lpc<%d,3%s>", P, dtc);
     }
     return -1;
 }

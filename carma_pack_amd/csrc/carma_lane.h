@@ -190,6 +190,16 @@ struct LaneFactorsInline {
     CARMA_DEV void get(int, double dt, double (&cr)[P], double (&sr)[P]) const
     {
         lane_factors<P>(m.wre, m.wim, m.realpair, anyreal, dt, cr, sr, tab);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the factors enter the recursion as opaque values, as the producers' ring hands them to its consumer: what the
+        // compiler knows about them in line (c_{2k+1} = c_{2k}, s_{2k+1} = -s_{2k}) would contract the products of the step
+        // differently, and the two kernels are held to the same bits (test_launch_shapes_agree)
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            asm("" : "+v"(cr[r]));
+            asm("" : "+v"(sr[r]));
+        }
+#endif
     }
 };
 
@@ -231,7 +241,7 @@ struct LaneFactorsRing {
         }
     }
 };
-template <int P, int NP>
+template <int P, int NP, bool REPDT = true>
 __device__ __forceinline__ void lane_produce(int k, const double* theta, double* ring /* + lane */, const double4* __restrict__ series,
                                              int n, const double* tab)
 {
@@ -259,7 +269,7 @@ __device__ __forceinline__ void lane_produce(int k, const double* theta, double*
             if (kk >= n) break;
             const double dt = series[kk].x;
             // as the consumer decides: new factors unless the step repeats its predecessor's time step
-            if (kk == 1 || dt != series[kk - 1].x) {
+            if (!REPDT || kk == 1 || dt != series[kk - 1].x) {
                 double cr[P], sr[P];
                 lane_factors<P>(wre, wim, realpair, anyreal, dt, cr, sr, tab);
                 double* b = ring + (size_t)((c & 1) * Geo::CH + s) * Geo::NV * 64;
@@ -277,7 +287,11 @@ __device__ __forceinline__ void lane_produce(int k, const double* theta, double*
 // Reset + n - 1 Updates -> log-likelihood sum (no prior)
 // WRITE_MV: also store mean_k = h.z + mu and var_k of every datum (KalmanFilter::GetMean / GetVar,
 // src/include/kfilter.hpp:116-117) to mv[k * mv_stride] and mv[(n + k) * mv_stride]
-template <int P, class Src, bool WRITE_MV = false>
+// REPDT: the series has time steps that repeat their predecessor (regular cadence): such a step re-uses the factors (a
+// wave-uniform test).  Without (the launcher's choice for irregular series) a step is ONE basic block -- the factors' LDS
+// reads or exp / sincos chains interleave with the recursion: 122 -> 113 us with producer waves, 2 % for the lone wave
+// (profiles/r04/ab_lane_noskip_v1.txt).
+template <int P, class Src, bool WRITE_MV = false, bool REPDT = true>
 CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ series, int n, const Src& src, double* mv = nullptr,
                              long mv_stride = 0)
 {
@@ -307,8 +321,12 @@ CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ 
         const double4 rec = series[kk];
         // --- transition factors of this step; a repeated time step (wave-uniform: the series is shared) re-uses them
         src.step(kk);
-        if (rec.x != dt_prev) {
-            dt_prev = rec.x;
+        if constexpr (REPDT) {
+            if (rec.x != dt_prev) {
+                dt_prev = rec.x;
+                src.get(kk, rec.x, cr, sr);
+            }
+        } else {
             src.get(kk, rec.x, cr, sr);
         }
         // --- var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z   (kfilter.cpp:180-184, 207-213)
@@ -473,7 +491,7 @@ CARMA_DEV bool kfilter_lane(const double* om_re_im, const double* ma, double sig
 
 // CARMA_Base::LogDensity (carpack.hpp:131-176): -inf outside the prior bounds or on a repeated root, else
 // log-likelihood + log prior
-template <int P>
+template <int P, bool REPDT = true>
 CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __restrict__ series, int n, const Prior& pr,
                                  int ignore_prior, const double* tab)
 {
@@ -483,7 +501,7 @@ CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __re
 #pragma unroll
     for (int i = 0; i < P / 2; i++) anyreal = anyreal || m.realpair[i];
     const LaneFactorsInline<P> src{m, lane_any(anyreal), tab};
-    double ll = lane_filter<P>(m, series, n, src);
+    double ll = lane_filter<P, LaneFactorsInline<P>, false, REPDT>(m, series, n, src);
     ll += log_prior(m.scale, pr.measerr_dof);
     if (m.sing || !m.valid) ll = -1.0 / 0.0;
     return ll;
@@ -491,14 +509,14 @@ CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __re
 
 #if defined(__HIPCC__)
 // the same with the factors from the producer wave's ring (consumer side of k_logdens_carma_lpc)
-template <int P, int NP>
+template <int P, int NP, bool REPDT = true>
 __device__ __forceinline__ double logdensity_lane_ring(const double* theta, int q, const double4* __restrict__ series, int n,
                                                        const Prior& pr, int ignore_prior, const double* ring /* + lane */)
 {
     LaneModel<P> m;
     lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
     const LaneFactorsRing<P, NP> src{ring};
-    double ll = lane_filter<P>(m, series, n, src);
+    double ll = lane_filter<P, LaneFactorsRing<P, NP>, false, REPDT>(m, series, n, src);
     ll += log_prior(m.scale, pr.measerr_dof);
     if (m.sing || !m.valid) ll = -1.0 / 0.0;
     return ll;

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void k_ram_propose(PtLaunch L, RamState S)
 // CholUpdateR1 :111-131), the exchange sweep of the ladder (steps.hpp:318-362), Sampler::SaveValues (samplers.cpp:118-124)
 // NEXT: the proposal of the FOLLOWING iteration right behind (what k_ram_propose does, with the factor still in registers):
 // one launch and one pass over the factor less per iteration.
+// (one workgroup per CU's worth of registers: with the budget of two, D = 11 spills 836 bytes per lane)
 template <int D, bool NEXT>
 __global__ __launch_bounds__(256) void k_ram_finish(PtLaunch L, RamState S, const double* __restrict__ temps,
                                                     unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,

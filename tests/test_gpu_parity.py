@@ -683,6 +683,7 @@ def test_regular_cadence_series(cpa, p, q):
     BP = 20000 if p <= 4 else 12000                               # one evaluation per lane + producer waves
     assert ctx.kernel_name(BG).endswith(",true>") and ctx.kernel_name(70016).startswith("k_logdens_carma_lane<")
     assert ctx.kernel_name(BP).startswith("k_logdens_carma_lpc<")
+    assert ctx.kernel_name(BP).endswith(",true>") and ctx.kernel_name(70016).endswith(",true>")
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(32)])
     r1 = 10.0 ** rng.uniform(-2.0, -0.5, 8)
@@ -696,6 +697,23 @@ def test_regular_cadence_series(cpa, p, q):
     # an irregular series keeps the plain variant
     ti = np.cumsum(rng.uniform(1.0, 3.0, n))
     assert not cpa.Context(ti, y, yerr, p, q).kernel_name(BG).endswith(",true>")
+    # ... also when a FEW of its steps repeat (below the quarter that selects the re-using variant): the one-evaluation-per-lane
+    # kernels then evaluate the factors of every step, producers and consumer alike
+    dt = rng.uniform(1.0, 3.0, n)
+    dt[10:130:9] = dt[9:129:9]
+    tf = np.cumsum(dt)
+    cf = cpa.Context(tf, y, yerr, p, q)
+    assert cf.kernel_name(BP).startswith("k_logdens_carma_lpc<") and not cf.kernel_name(BP).endswith(",true>")
+    assert cf.kernel_name(70016).startswith("k_logdens_carma_lane<") and not cf.kernel_name(70016).endswith(",true>")
+    mf = orc.OracleModel(tf, y, yerr, p, q, max_stdev=cf.prior()[0])
+    thf = np.array([prior_like_theta(rng, p, q, tf, y) for _ in range(32)])
+    thf[:8, 3], thf[:8, 4] = np.log(r1 * r1 * 7.0), np.log(r1 * 8.0)
+    wantf = mf.logdensity_batch(thf, ignore_prior=True)
+    for B in (BP, 70016):
+        got = cf.logdensity(np.tile(thf, (B // 32, 1)), ignore_prior=True)
+        assert np.array_equal(got, np.tile(got[:32], B // 32), equal_nan=True), cf.kernel_name(B)
+        assert_parity(got[:32], wantf, RTOL, "a few repeated steps p=%d q=%d %s" % (p, q, cf.kernel_name(B)),
+                      arbiter=lambda i: loglik_truth(tf, y, yerr, thf[i], p, q)[0])
 
 
 @pytest.mark.parametrize("unit", [1e-60, 1e-7, 1e9, 1e45])
