@@ -55,7 +55,7 @@ def collect(kern, grid=None, per_iteration=0):
 
 
 for name, kern, grid, it in (("", "k_logdens_carma_p3l<5>", 65536, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),
-                             ("_tput", "k_logdens_carma_lane<5>", None, 0)):
+                             ("_tput", "k_logdens_carma_lane<5", None, 0)):
     r = collect(kern, grid, it)
     if r["_dispatch"] is None:
         print("no dispatches of", kern)
