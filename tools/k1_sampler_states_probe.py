@@ -62,6 +62,13 @@ for it in (0, 30, 200):
     real = timeit(flat, "sampler states after %3d iterations, lane order" % it)
     order = np.argsort(~real, kind="stable")
     timeit(flat[order], "  the same, chains with a real pair packed together")
+    blk = np.arange(flat.shape[0]) // 256
+    order_wg = np.lexsort((np.arange(flat.shape[0]), ~real, blk))
+    timeit(flat[order_wg], "  the same, packed inside blocks of 256 (4 waves)")
+    half = np.concatenate([flat[order][: BT // 2], flat[order][: BT // 2]])
+    timeit(half, "  the flagged-first half of the packed batch, twice")
+    tail = np.concatenate([flat[order][BT // 2:], flat[order][BT // 2:]])
+    timeit(tail, "  the unflagged half of the packed batch, twice")
     for k in (0, 8, 15):
         sub = th[:, k, :]
         c0, b0, c1, b1 = np.exp(sub[:, 3]), np.exp(sub[:, 4]), np.exp(sub[:, 5]), np.exp(sub[:, 6])
