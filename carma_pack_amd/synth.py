@@ -40,7 +40,9 @@ def prior_like_theta(rng, p, q, t, y, measerr_dof=50):
     loga = np.empty(p)
     if p % 2:
         cent[p // 2] = 0.0
-        width[p // 2] = np.exp(rng.uniform(np.log(min_freq), np.log(cent[p // 2 - 1])))
+        # (a two-point series has max_freq == min_freq, and exp(log(.)) may come back an ulp below: keep the interval ordered)
+        lo = np.log(min_freq)
+        width[p // 2] = np.exp(rng.uniform(lo, max(lo, np.log(cent[p // 2 - 1]))))
     for i in range(p // 2):
         re_, im_ = -2 * np.pi * width[i], 2 * np.pi * cent[i]
         loga[2 * i] = np.log(re_ * re_ + im_ * im_)

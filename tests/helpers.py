@@ -214,8 +214,15 @@ def assert_parity_states(got, want, thetas, p, q, rtol=1e-10, what="", arbiter=N
         assert in_zero_root_band(thetas[i], p, q), "%s: finite pattern differs at %d outside the zero-root band" % (what, i)
         v = got[i] if np.isfinite(got[i]) else want[i]
         truth = arbiter(int(i))
-        assert abs(v - truth) <= rtol * abs(truth), (what, i, v, truth)
-        print("%s: entry %d sits in the zero-root band (device %r, oracle %r, exact %r): excused" % (what, i, got[i], want[i], truth))
+        # (no second implementation to be "no further from the exact value than": where the modal basis is ill conditioned as
+        # well, the finite side is held to the forward-error bound of a backward-stable set-up, 4 eps cond(EigenMat) --
+        # tools/soak_pt_lane.py met a CARMA(7,6) state with three real roots within 1 % of each other, cond 7e9, on the band:
+        # device 2.3e-7 from the exact value, oracle NaN)
+        cond = cond_eigenmat(thetas[i], p) if p > 1 else 1.0
+        tol = max(rtol, 4.0 * np.finfo(float).eps * cond)
+        assert abs(v - truth) <= tol * abs(truth), (what, i, v, truth, cond)
+        print("%s: entry %d sits in the zero-root band (device %r, oracle %r, exact %r, cond(EigenMat) %.1e): excused" % (
+            what, i, got[i], want[i], truth, cond))
         keep[i] = False
     idx = np.flatnonzero(keep)
     return assert_parity(got[keep], want[keep], rtol, what, arbiter=(lambda k: arbiter(int(idx[k]))) if arbiter else None,

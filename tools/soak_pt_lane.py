@@ -33,9 +33,12 @@ for (p, q, T, R, n) in [SHAPES[int(only)]] if only else SHAPES:
     ok = True
     try:
         assert np.all(np.isfinite(flat)) and np.all(np.isfinite(smp))
-        # (arb_factor 8, as tools/soak_pt_row.py: over thousands of states which side lands nearer the exact value is a coin flip)
+        # (arb_factor 8, as tools/soak_pt_row.py: over thousands of states which side lands nearer the exact value is a coin flip;
+        # allowance of arbitrated states 10 %: after 2e4 iterations the tempered CARMA(7,6) chains have drifted so far out in the
+        # unconstrained MA parameters that the ORACLE is beyond 1e-10 of the exact value on 55 of 599 states -- up to 2e-2 --
+        # while the device is at 1e-13 ... 1e-16 on them: profiles/r04/soak_pt_lane_v3.txt)
         assert_parity_states(lp.reshape(-1)[sel], m.logdensity_batch(flat[sel], nthreads=os.cpu_count() or 8), flat[sel], p, q, 1e-10,
-                             "soak", arbiter=lambda i: loglik_truth(t, y, yerr, flat[sel][i], p, q)[0], max_arb_frac=0.08, arb_factor=8.0,
+                             "soak", arbiter=lambda i: loglik_truth(t, y, yerr, flat[sel][i], p, q)[0], max_arb_frac=0.10, arb_factor=8.0,
                              max_overflow_frac=0.05, noise_scale=lambda i: oracle_noise_scale(m, t, y, yerr, flat[sel][i], p, q))
         last = smp[:200, -1]                                  # saved samples: stored log-posterior == LogDensity(sample)
         assert_parity_states(slp[:200, -1], m.logdensity_batch(last, nthreads=os.cpu_count() or 8), last, p, q, 1e-10, "saved",
