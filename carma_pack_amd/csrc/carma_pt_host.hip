@@ -75,7 +75,7 @@ static int chunk_iters(const Ctx* c)
         const double est_us = std::max(1.0, 0.14 * c->n);
         return (int)std::max(1.0, std::min(16384.0, 500000.0 / est_us));
     }
-    if (c->pt && c->pt->use_lane) {                       // large ensembles: >= ~0.45 us per datum per iteration, 3 launches each
+    if (c->pt && c->pt->use_lane) {                       // large ensembles: >= ~0.45 us per datum per iteration, 2 launches each
         const double est_us = std::max(1.0, 0.45 * c->n);
         return (int)std::max(1.0, std::min(4096.0, 250000.0 / est_us));
     }

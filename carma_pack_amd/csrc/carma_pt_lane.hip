@@ -1,5 +1,5 @@
 // carma_pt_lane.hip -- the parallel-tempered Robust-Adaptive-Metropolis sampler for LARGE ENSEMBLES (round 4): one chain
-// per LANE, and an iteration as three launches instead of one persistent kernel:
+// per LANE, and an iteration as separate launches (two; three for the first of a chunk) instead of one persistent kernel:
 //
 //     k_ram_propose   t8 draws, thn = th + R^T z                          AdaptiveMetro::DoStep, src/steps.cpp:60-73
 //                     (a launch of its own for the first iteration of a chunk only: afterwards the proposal of iteration
@@ -19,7 +19,7 @@
 // that loop (477 instead of 235 us per iteration), and with a wave per SIMD to itself (no spills) the bookkeeping's memory
 // round trips and 11 Box-Muller draws sit on the lone wave's critical path (330 us).  Split, the bookkeeping runs as two
 // short, lean kernels with thousands of waves in flight (latency hidden, a few tens of registers), the filter is the tuned
-// K1 launch at ITS best occupancy, and three launch boundaries cost ~5 us of a >= 120 us iteration.  K1 improvements carry
+// K1 launch at ITS best occupancy, and a launch boundary costs ~2 us of a >= 120 us iteration.  K1 improvements carry
 // over for free.
 //
 // State.  A ladder's T <= 64 chains are T consecutive lanes of a wave, floor(64 / T) ladders per wave, so that the
@@ -337,7 +337,7 @@ static hipError_t ram_launch_d(int d, F&& f)
     }
 }
 
-// niter iterations of the sampler for large ensembles, enqueued on st: 3 launches per iteration + one conversion at
+// niter iterations of the sampler for large ensembles, enqueued on st: 2 launches per iteration (+ the first proposal) + one conversion at
 // either end.  The iterations, the save slots and the Philox keys are those of launch_pt for the same PtLaunch.
 hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const double4* series, const Prior& pr,
                           const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
