@@ -908,6 +908,13 @@ def test_filter_of_many_models_in_one_launch(cpa, p):
             m1, v1 = cpa.kfilter_carma(t, y - th[i, 2], yerr, sig2[i], roots[i], ma[i])
             np.testing.assert_allclose(var[i], v1, rtol=1e-9)
             np.testing.assert_allclose(mean[i] - th[i, 2], m1, rtol=0, atol=1e-9 * np.abs(y - th[i, 2]).max())
+    # a model with a repeated AR root is flagged (the reference's solve throws, kfilter.cpp:157-158), its neighbours are untouched
+    rep = roots.copy()
+    rep[5] = np.r_[[-0.2, -0.2], -0.1 * np.arange(1, p - 1)] if p > 2 else np.array([-0.2, -0.2])
+    m2, v2, s2 = cpa.kfilter_carma_batch(t, y, yerr, sig2, rep, ma, mu=th[:, 2])
+    assert s2[5] and not np.delete(s2, 5).any()
+    keep = np.delete(np.arange(130), 5)
+    assert np.array_equal(m2[keep], mean[keep]) and np.array_equal(v2[keep], var[keep])
     with pytest.raises(ValueError):
         cpa.kfilter_carma_batch(t, y, yerr, sig2[:3], roots, ma)
     # a model whose roots are not closed under conjugation is rejected, and named
