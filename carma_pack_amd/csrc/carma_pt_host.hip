@@ -344,16 +344,29 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     // Kernel choice.  The row variant needs every workgroup of the grid resident at the same time
     // (its swap step is a cross-workgroup rendezvous); otherwise one workgroup per ladder (k_pt).
     // CARMA_PT_KERNEL=ladder|row overrides (row only where it is safe).
-    // Large ensembles: ONE CHAIN PER LANE, an iteration as propose kernel + batched log-density launch + finish kernel
-    // (carma_pt_lane.hip).  From lane_min chains on the batched launch beats what the persistent kernels get out of a chain
-    // (measured: tools/mcmc_lane_probe.py, profiles/r04/).  CARMA_PT_KERNEL=lane forces it (T <= 64, p >= 2),
-    // CARMA_TUNE_PT_LANE_MIN moves the threshold.
+    // Large ensembles: ONE CHAIN PER LANE, an iteration as the batched log-density launch + a bookkeeping kernel
+    // (carma_pt_lane.hip).  Which path pays is measured, per order (tools/mcmc_lane_probe.py, profiles/r04/
+    // mcmc_lane_threshold_v*.txt; 16 temperatures, n = 270):
+    //   * the ladder kernel k_pt gives a ladder ceil(T G / 64) waves (G = 2 / 4 / 8 lanes per chain for p = 2 / 3-4 / 5-7); its
+    //     iteration takes twice as long once those are more than the chip has SIMDs -- p = 5: 8193 chains 245 us against 127,
+    //     p = 3: 32 768 chains 207 against 98 -- so from there on: one chain per lane;
+    //   * p = 2: from 16 x #CUs chains already (6144 ... 16 384 chains: 74-81 us against 95-96);
+    //   * p = 3, 4: also between 16 x and 32 x #CUs chains, where the batched launch is the consumer / producer pair kernel
+    //     (80-89 us against 103-116); from there up to the ladder kernel's 1024 waves the ladder kernel is the faster one
+    //     (103-117 against 116-129).
+    // CARMA_PT_KERNEL=lane forces it (T <= 64, p >= 2), CARMA_TUNE_PT_LANE_MIN = N replaces the table by "from N chains".
     const char* force = getenv("CARMA_PT_KERNEL");
     if (e == hipSuccess && c->p >= 2 && ntemps <= 64) {
         const char* tv = getenv("CARMA_TUNE_PT_LANE_MIN");
-        const long lane_min = tv ? atol(tv) : 48L * device_cus();             // 12 288 chains on 256 CUs
+        const long cus = device_cus();
+        const int G = c->p == 2 ? 2 : (c->p <= 4 ? 4 : 8);
+        const long ladder_waves = (long)nreplicas * ((ntemps * G + 63) / 64);
+        bool pays = ladder_waves > 4 * cus;
+        if (c->p == 2) pays = pays || (long)nchain > 16 * cus;
+        if (c->p == 3 || c->p == 4) pays = pays || ((long)nchain > 16 * cus && (long)nchain <= 32 * cus);
+        if (tv) pays = (long)nchain >= atol(tv);
         const bool forced = force && std::strcmp(force, "lane") == 0;
-        if (forced || (!force && (long)nchain >= lane_min)) {
+        if (forced || (!force && pays)) {
             s->use_lane = true;
             e = hipMalloc(&s->d_lane_scratch, sizeof(double) * pt_lane_scratch_doubles(d, (long)nchain));
         }

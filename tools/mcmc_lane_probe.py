@@ -12,14 +12,15 @@ if len(sys.argv) > 1:
     g = np.load(os.path.join(ROOT, 'tests/golden/carma53_readme.npz'))
     t, y, yerr = g['t'], g['y'], g['yerr']
     ms = 10 * np.sqrt(np.mean(y * y) - np.mean(y) ** 2)
-    ctx = cpa.Context(t, y, yerr, 5, 3, max_stdev=ms)
+    P_, Q_ = [int(x) for x in os.environ.get("LANE_PROBE_PQ", "5,3").split(",")]
+    ctx = cpa.Context(t, y, yerr, P_, Q_, max_stdev=ms)
     ctx.pt_create(16, R, adapt_iters=10 ** 9, seed=3)
     ctx.pt_start(None)
     ctx.pt_iterate(20)
     n = max(20, min(400, int(3e6 / (16 * R) * 40)))
     t0 = time.perf_counter(); ctx.pt_iterate(n); dt = time.perf_counter() - t0
     acc, swp = ctx.pt_stats()
-    print("kernel %-7s (%-6s) R=%5d chains=%7d: %8.1f it/s  %.3e chain-evals/s  %.1f us/iteration  accept %.2f swap %.2f" % (
+    print("CARMA(%d,%d) " % (P_, Q_) + "kernel %-7s (%-6s) R=%5d chains=%7d: %8.1f it/s  %.3e chain-evals/s  %.1f us/iteration  accept %.2f swap %.2f" % (
         kern, ctx.pt_kernel(), R, 16 * R, n / dt, n * 16 * R / dt, 1e6 * dt / n, acc.mean(), swp[:, 1:].mean()), flush=True)
     sys.exit(0)
 Rs = [int(x) for x in os.environ.get("LANE_PROBE_R", "256,512,768,1024,1536,2048,3072,4096,8192").split(",")]
