@@ -359,13 +359,17 @@ hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const doubl
         const bool save = L.save_thin > 0 && ((it + 1) % L.save_thin) == 0;
         Li.save_thin = save ? 1 : 0;
         Li.save_offset = save ? L.save_offset + (it + 1) / L.save_thin - 1 : 0;
-        if (it == 0)                                         // (later proposals ride on the finish kernel of the iteration before)
+        // (later proposals ride on the finish kernel of the iteration before -- where that kernel holds the factor, v, the value AND
+        // the draws in registers: d <= 12.  Beyond, the fused form spills -- 296 bytes per lane at d = 13, 1136 at d = 16, where it
+        // takes 88 us for 16 384 chains against 21 + 27 for the two kernels: profiles/r04/lane_sampler_kernels_p7_v1.txt)
+        const bool fused = L.d <= 12;
+        if (it == 0 || !fused)
             e = ram_launch_d(L.d, [&](auto dc) {
                 hipLaunchKernelGGL((k_ram_propose<decltype(dc)::value>), dim3(grid), dim3(256), 0, st, Li, S);
             });
         if (e == hipSuccess) e = launch_logdens_carma(p, S.thn, (int)nc, L.d, L.q, series, L.n, pr, 0, S.ll, st, repeated_dt);
         if (e == hipSuccess) {
-            const bool next = it + 1 < L.niter;
+            const bool next = fused && it + 1 < L.niter;
             e = ram_launch_d(L.d, [&](auto dc) {
                 if (next)
                     hipLaunchKernelGGL((k_ram_finish<decltype(dc)::value, true>), dim3(grid), dim3(256), 0, st, Li, S, temps, naccept,

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ml
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ml -o ml -- python3 "$ROOT/tools/mcmc_lane_probe.py" "$K" "$R" 2>&1 | grep "^kernel" > "$ROOT/gpurun_out/lane_sampler_kernels.txt"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ml -o ml -- python3 "$ROOT/tools/mcmc_lane_probe.py" "$K" "$R" 2>&1 | grep "kernel " > "$ROOT/gpurun_out/lane_sampler_kernels.txt"
 python3 - "$ROOT" <<'PY'
 import csv, glob, sys
 fs = glob.glob("/tmp/ml/**/*kernel_stats.csv", recursive=True)
