@@ -209,8 +209,14 @@ CARMA_DEV void model_from_theta(const GrpT& g, const double* theta, int q, const
     constexpr int MA0 = G - P;                   // MA roots held by the first pass
     Cx root1 = {-1.0, 0.0};
     if constexpr (NMA > MA0) {
-        const bool ma1 = MA0 + r < q;
-        root1 = poly_root(theta + 3 + P, q, ma1 ? MA0 + r : 0);
+        // (only when the second pass has a slot to fill: with q <= MA0 there is none, and with q = 0 there is no MA parameter to
+        // read at all -- the unconditional form read theta[d], theta[d + 1], i.e. past the END of the batch for its last
+        // evaluation: a memory fault when the array ends on a page boundary, tools/fuzz_dispatch.py seed 21: CARMA(5,0),
+        // 16 384 evaluations = exactly 1 MiB.  q is launch-uniform.)
+        if (q > MA0) {
+            const bool ma1 = MA0 + r < q;
+            root1 = poly_root(theta + 3 + P, q, ma1 ? MA0 + r : 0);
+        }
     }
     // --- b_r = beta(omega_r) = prod_k (mu_k - omega_r) / mu_k,  beta(-omega_r) = prod_k (mu_k + omega_r) / mu_k;
     //     prod_k mu_k is real (conjugate pairs and real roots)

@@ -364,13 +364,17 @@ static long p3l_max_rows()
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
 enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC };
 // smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
-static long lane_min_evals()
+static long lane_min_evals(int p = 5)
 {
     static const long tune = [] {
         const char* e = getenv("CARMA_TUNE_LANE_MIN");
         return e ? atol(e) : -1L;
     }();
-    return tune >= 0 ? tune : 64L * 4 * device_cus() * 3 / 8;  // 3/8 of a wave per SIMD (24 576 on 256 CUs): 206 vs 212-236 us there
+    if (tune >= 0) return tune;
+    // (p = 7, one producer-wave workgroup per CU: the lane-group kernel keeps 16 385 ... 28 671 evaluations -- 257 us at 24 576
+    // against 309 for the lone wave; 374 against 323 at 32 768: profiles/r04/lpc_orders_v1.txt)
+    if (p == 7) return 112L * device_cus();
+    return 64L * 4 * device_cus() * 3 / 8;  // 3/8 of a wave per SIMD (24 576 on 256 CUs): 206 vs 212-236 us there
 }
 // Launches (lpc_min, lpc_max] take the lane kernel with producer waves, k_logdens_carma_lpc<P,3> (measured per order:
 // tools/lpc_probe.sh, profiles/r03/lpc_orders_v1.txt).  Below, the lane-group kernels still have at most one wave per SIMD
@@ -392,9 +396,13 @@ static long lpc_min_evals()
 {
     static const long v = lpc_tune("CARMA_TUNE_LPC_MIN", -1);
     if (v >= 0) return v;
-    constexpr long EPW = 64 / GroupOf<P>::value;
-    const long one_wave_per_simd = EPW * 4 * device_cus(), one_wg_per_cu = 64L * device_cus();
-    return one_wave_per_simd < one_wg_per_cu ? one_wave_per_simd : one_wg_per_cu;
+    // Measured per order (profiles/r04/lpc_orders_v1.txt, round 4: with the table-based exp / sincos and the one-basic-block step
+    // the consumer's stream is short enough that for the low orders this kernel wins right above the wave pipeline's range):
+    //   p = 2, 3   from 12 x #CUs evaluations (3073):  50 / 62 us flat up to 16 384 against 62-68 / 67-89 (pair kernel, lane groups)
+    //   p = 4      from 32 x #CUs (8193):              88 us against 90-93
+    //   p >= 5     from 32 x #CUs (8193), as in round 3: below, the lane-group kernel's 104-112 us are ahead of 107-160
+    if (P <= 3) return 12L * device_cus();
+    return 32L * device_cus();
 }
 template <int P>
 static long lpc_max_evals()
@@ -427,7 +435,7 @@ static LdShape logdens_shape(long B, int n)
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
     if (B > lpc_min_evals<P>() && B <= lpc_max_evals<P>() && n >= 8) return LdShape::LPC;
-    if (B >= lane_min_evals()) return LdShape::LANE;
+    if (B >= lane_min_evals(P)) return LdShape::LANE;
     // few evaluations in flight: one wave's instruction stream is the run time, so split it (consumer + rho producer,
     // carma_ring.h).  Beyond 512 waves (two rounds of workgroups) the plain kernel with pair-shared exp/sincos is
     // ahead: 104 vs 111 us at 6144 evaluations (tools/midrange_probe.py)

@@ -349,11 +349,11 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     // mcmc_lane_threshold_v*.txt; 16 temperatures, n = 270):
     //   * the ladder kernel k_pt gives a ladder ceil(T G / 64) waves (G = 2 / 4 / 8 lanes per chain for p = 2 / 3-4 / 5-7); its
     //     iteration takes twice as long once those are more than the chip has SIMDs -- p = 5: 8193 chains 245 us against 127,
-    //     p = 3: 32 768 chains 207 against 98 -- so from there on: one chain per lane;
-    //   * p = 2: from 16 x #CUs chains already (6144 ... 16 384 chains: 74-81 us against 95-96);
-    //   * p = 3, 4: also between 16 x and 32 x #CUs chains, where the batched launch is the consumer / producer pair kernel
-    //     (80-89 us against 103-116); from there up to the ladder kernel's 1024 waves the ladder kernel is the faster one
-    //     (103-117 against 116-129).
+    //     p = 3: 32 768 chains 207 against 98 -- so from there on: one chain per lane, whatever the order;
+    //   * p <= 4, whose batched launch is the producer-wave kernel right above the wave pipeline's range (carma_kernels.hip,
+    //     lpc_min_evals): from 16 x #CUs chains (p = 3: 78 us flat up to 16 384 chains against 103-105, p = 4: 88-107 against
+    //     116; at 3200 ... 4096 chains the ladder kernel's 74 / 79 us are still ahead of 78 / 83), p = 2 from 12 x #CUs (64 us
+    //     flat against 73-96).
     // CARMA_PT_KERNEL=lane forces it (T <= 64, p >= 2), CARMA_TUNE_PT_LANE_MIN = N replaces the table by "from N chains".
     const char* force = getenv("CARMA_PT_KERNEL");
     if (e == hipSuccess && c->p >= 2 && ntemps <= 64) {
@@ -362,8 +362,8 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
         const int G = c->p == 2 ? 2 : (c->p <= 4 ? 4 : 8);
         const long ladder_waves = (long)nreplicas * ((ntemps * G + 63) / 64);
         bool pays = ladder_waves > 4 * cus;
-        if (c->p == 2) pays = pays || (long)nchain > 16 * cus;
-        if (c->p == 3 || c->p == 4) pays = pays || ((long)nchain > 16 * cus && (long)nchain <= 32 * cus);
+        if (c->p == 2) pays = pays || (long)nchain > 12 * cus;
+        if (c->p == 3 || c->p == 4) pays = pays || (long)nchain > 16 * cus;
         if (tv) pays = (long)nchain >= atol(tv);
         const bool forced = force && std::strcmp(force, "lane") == 0;
         if (forced || (!force && pays)) {

@@ -502,9 +502,11 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
     ctx = cpa.Context(t, y, yerr, p, q)
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     from helpers import loglik_truth
-    B = 12000 if p <= 4 else 8000                               # lane-group throughput kernel
+    B = 8000                                                    # lane-group throughput kernel (p <= 4: its consumer / producer pair form --
+                                                                # from 8193 / 3073 evaluations those orders are on producer waves since round 4)
     BL, BP = 60000, (20000 if p <= 4 else 12000)                # one evaluation per lane: in line / with producer waves
-    assert ctx.kernel_name(B).startswith("k_logdens_carma<") and ctx.kernel_name(BL).startswith("k_logdens_carma_lane<")
+    assert ctx.kernel_name(B).startswith("k_logdens_carma<" if p >= 5 else "k_logdens_carma_pc<")
+    assert ctx.kernel_name(BL).startswith("k_logdens_carma_lane<")
     assert ctx.kernel_name(BP).startswith("k_logdens_carma_lpc<")
     res = {}
     for name, pool in (("complex", cplx), ("real", real), ("mixed", np.concatenate([cplx, real])[rng.permutation(64)])):
@@ -664,7 +666,7 @@ def test_up_to_the_overflow_of_the_ma_coefficients(cpa, p, q):
             ctx.kernel_name(reps * B), over.sum(), fo.sum(), fd.sum(), (fo & fd).sum()))
 
 
-@pytest.mark.parametrize("p,q", [(4, 1), (5, 3), (7, 4)])
+@pytest.mark.parametrize("p,q", [(4, 1), (5, 3), (6, 2), (7, 4)])
 def test_regular_cadence_series(cpa, p, q):
     """A regularly sampled series (constant dt, two gaps, a stretch of alternating steps): the throughput kernels run
     the variant that re-uses the transition factors of steps whose dt repeats (carma_core.h, RhoInline / RhoPair DTC).
@@ -679,9 +681,11 @@ def test_regular_cadence_series(cpa, p, q):
     y = 5.0 + np.sin(t / 9.0) + 0.3 * rng.standard_normal(n)
     yerr = np.full(n, 0.3) * rng.uniform(0.8, 1.2, n)
     ctx = cpa.Context(t, y, yerr, p, q)
-    BG = {4: 12000, 5: 8000, 7: 20000}[p]                          # what still takes the lane-group throughput kernels
+    BG = {4: 8000, 5: 8000, 6: 8000, 7: 20000}[p]                  # what still takes the lane-group throughput kernels (p = 4: their
+                                                                  # pair form, which has no re-using variant)
     BP = 20000 if p <= 4 else 12000                               # one evaluation per lane + producer waves
-    assert ctx.kernel_name(BG).endswith(",true>") and ctx.kernel_name(70016).startswith("k_logdens_carma_lane<")
+    assert (ctx.kernel_name(BG).endswith(",true>") if p >= 5 else ctx.kernel_name(BG).startswith("k_logdens_carma_pc<"))
+    assert ctx.kernel_name(70016).startswith("k_logdens_carma_lane<")
     assert ctx.kernel_name(BP).startswith("k_logdens_carma_lpc<")
     assert ctx.kernel_name(BP).endswith(",true>") and ctx.kernel_name(70016).endswith(",true>")
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
@@ -697,6 +701,7 @@ def test_regular_cadence_series(cpa, p, q):
     # an irregular series keeps the plain variant
     ti = np.cumsum(rng.uniform(1.0, 3.0, n))
     assert not cpa.Context(ti, y, yerr, p, q).kernel_name(BG).endswith(",true>")
+    assert not cpa.Context(ti, y, yerr, p, q).kernel_name(BP).endswith(",true>")
     # ... also when a FEW of its steps repeat (below the quarter that selects the re-using variant): the one-evaluation-per-lane
     # kernels then evaluate the factors of every step, producers and consumer alike
     dt = rng.uniform(1.0, 3.0, n)
@@ -923,3 +928,71 @@ def test_filter_of_many_models_in_one_launch(cpa, p):
     bad[7, 1:] = -0.1 * np.arange(1, p)
     with pytest.raises(ValueError, match="model 7"):
         cpa.kfilter_carma_batch(t, y, yerr, sig2, bad, ma)
+
+
+def test_lane_group_kernels_of_the_low_orders():
+    """k_logdens_carma<P,G,W> for p <= 4 (and the pair form k_logdens_carma_pc up to 512 waves): since round 4 the default
+    dispatch hands those orders to the producer-wave kernel right above the wave pipeline's range, so these kernels are
+    reached through CARMA_TUNE_LPC_MIN / CARMA_TUNE_LANE_MIN only (read once per process: a process of its own).  Same bar
+    as everywhere: the oracle to 1e-10 or no further from the quad-precision value, copies of a vector give the same bits."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import carma_pack_amd as cpa
+import oracle as orc
+from helpers import assert_parity, irregular_series, prior_like_theta, loglik_truth
+for p, q in ((2, 1), (3, 1), (4, 2)):
+    t, y, yerr = irregular_series(130, seed=40 + p)
+    rng = np.random.default_rng(77 + p)
+    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(40)])
+    ctx = cpa.Context(t, y, yerr, p, q)
+    m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+    want = m.logdensity_batch(th)
+    names = set()
+    for B in (3500, 9000, 12000, 20000, 40000):
+        names.add(ctx.kernel_name(B).split("<")[0])
+        got = ctx.logdensity(np.tile(th, (B // 40, 1)))
+        assert np.array_equal(got, np.tile(got[:40], B // 40), equal_nan=True), ctx.kernel_name(B)
+        assert_parity(got[:40], want, 1e-10, "%s p=%d q=%d" % (ctx.kernel_name(B), p, q),
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0])
+    assert names == {"k_logdens_carma_pc", "k_logdens_carma"}, names
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CARMA_TUNE_LPC_MIN="999999999", CARMA_TUNE_LANE_MIN="999999999")
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_no_read_past_the_end_of_the_batch():
+    """The lane-group kernels' second pass over the MA slots read theta[d], theta[d + 1] of every evaluation when q = 0 --
+    for the last evaluation of a batch that is past the END of the array, and a memory fault when the array ends on a
+    page boundary: CARMA(5,0) (d = 8), 16 384 evaluations = exactly 1 MiB, a series too short for the producer-wave
+    kernel (found by tools/fuzz_dispatch.py, seed 21, in round 4; the read was there since round 2).  A fault takes the
+    process down, so the case runs in one of its own, together with its neighbours in (order, batch size)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import carma_pack_amd as cpa
+import oracle as orc
+from helpers import irregular_series, prior_like_theta
+for p, q, n, B in ((5, 0, 5, 16384), (5, 0, 7, 16384), (5, 0, 5, 8192), (3, 0, 6, 16384), (7, 0, 5, 16384), (2, 0, 5, 32768), (4, 0, 7, 65536)):
+    t, y, yerr = irregular_series(n, seed=3)
+    ctx = cpa.Context(t, y, yerr, p, q)
+    rng = np.random.default_rng(1)
+    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(37)])
+    got = ctx.logdensity(np.tile(th, (B // 37 + 1, 1))[:B], ignore_prior=True)
+    want = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0]).logdensity_batch(th, ignore_prior=True)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got[:37]), fin) and np.all(np.abs(got[:37][fin] - want[fin]) <= 1e-9 * np.abs(want[fin])), (p, q, n, B)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]

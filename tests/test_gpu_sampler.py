@@ -214,15 +214,14 @@ def test_lane_kernel_is_the_choice_for_large_ensembles(cpa, monkeypatch):
     ctx = cpa.Context(t, y, yerr, 3, 1, max_stdev=ms)
     ctx.pt_create(8, 16, adapt_iters=50, seed=3)
     assert ctx.pt_kernel() in ("row", "ladder")
-    # p = 3: one chain per lane where the batched launch is the pair kernel (4097 ... 8192 chains on 256 CUs) and beyond the
-    # ladder kernel's one wave per SIMD (8 temperatures x 4 lanes: a wave per two ladders); the ladder kernel in between
+    # p = 3: one chain per lane from 16 x #CUs chains (its batched launch is the producer-wave kernel from 3073 evaluations)
     ncu = 256                                                # (MI355X)
+    ctx.pt_create(8, 2 * ncu, adapt_iters=50, seed=3)        # 4096 chains
+    assert ctx.pt_kernel() in ("row", "ladder")
     ctx.pt_create(8, 3 * ncu, adapt_iters=50, seed=3)        # 6144 chains
     assert ctx.pt_kernel() == "lane"
-    ctx.pt_create(8, 6 * ncu, adapt_iters=50, seed=3)        # 12 288 chains, 1536 ladder-kernel waves
+    ctx.pt_create(16, 3 * ncu, adapt_iters=50, seed=3)       # 12 288 chains
     assert ctx.pt_kernel() == "lane"
-    ctx.pt_create(16, 3 * ncu, adapt_iters=50, seed=3)       # 12 288 chains as 768 ladder-kernel waves: the ladder kernel
-    assert ctx.pt_kernel() in ("row", "ladder")
     c5 = cpa.Context(t, y, yerr, 5, 2, max_stdev=ms)         # p = 5: 16 temperatures x 8 lanes = two waves per ladder
     c5.pt_create(16, 2 * ncu, adapt_iters=50, seed=3)        # 1024 waves: the ladder kernel's one round
     assert c5.pt_kernel() in ("row", "ladder")

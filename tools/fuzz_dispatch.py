@@ -34,6 +34,8 @@ for case in range(ncase):
     big = np.tile(th, (B // K + 1, 1))[:B]
     name = ctx.kernel_name(B)
     seen[name.split("<")[0]] = seen.get(name.split("<")[0], 0) + 1
+    if os.environ.get("FUZZ_VERBOSE"):                                # (a memory fault takes the process down: the case is on record first)
+        print("case %d: CARMA(%d,%d) n=%d B=%d ignore_prior=%s %s" % (case, p, q, n, B, ign, name), flush=True)
     try:
         got = ctx.logdensity(big, ignore_prior=ign) if p > 1 else ctx.logdensity(big)
         assert got.shape == (B,)
