@@ -996,3 +996,13 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_batches_at_the_end_of_their_allocation():
+    """tools/fuzz_guard.py: every order and launch shape with the parameter batch and the output at the very end of device
+    allocations of their own -- a read or write past the end faults (and ends the process: it runs as one)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_guard.py")], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
