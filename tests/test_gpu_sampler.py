@@ -383,3 +383,15 @@ def test_starting_values_follow_the_reference_distribution(cpa, golden_dir, p, q
     pv = [ks_2samp(th[:, j], ref[:, j]).pvalue for j in range(ctx.d)]
     print("p=%d q=%d KS p-values:" % (p, q), np.round(pv, 3))
     assert min(pv) > 1e-4, pv
+
+
+@pytest.mark.parametrize("kern", ["row", "ladder", "lane"])
+def test_chain_state_at_the_end_of_its_allocation(kern):
+    """tools/fuzz_guard_sampler.py: the chain state as caller-owned device buffers (carma_pt_bind_state) at the very end of
+    allocations of their own -- a sampler kernel reading or writing past them faults -- and the same chains as with the
+    library's own buffers.  One sampler path per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_guard_sampler.py"), kern], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
