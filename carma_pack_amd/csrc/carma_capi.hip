@@ -15,6 +15,89 @@
 #include "../../include/carma_mi355.h"
 #include "carma_host.h"
 
+// ---- device allocations (carma_host.h) -------------------------------------------------------------------------
+#undef hipMalloc
+#undef hipFree
+#include <map>
+#include <mutex>
+namespace {
+struct GuardAlloc {
+    hipMemGenericAllocationHandle_t handle;
+    void* base;
+    size_t reserved, mapped;
+};
+std::mutex g_guard_mu;
+std::map<void*, GuardAlloc> g_guard;      // user pointer -> mapping
+bool guard_mode()
+{
+    static const bool on = [] {
+        const char* e = getenv("CARMA_DEBUG_GUARD");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+}  // namespace
+hipError_t carma_dev_malloc(void** p, size_t n)
+{
+    if (!guard_mode()) return hipMalloc(p, n);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran == 0) gran = 2u << 20;
+    const size_t need = n ? n : 1;
+    GuardAlloc a{};
+    a.mapped = (need + gran - 1) / gran * gran;
+    a.reserved = a.mapped + gran;                             // one granule of address space behind the buffer stays unmapped
+    e = hipMemAddressReserve(&a.base, a.reserved, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&a.handle, a.mapped, &prop, 0);
+    if (e == hipSuccess) e = hipMemMap(a.base, a.mapped, 0, a.handle, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(a.base, a.mapped, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemAddressFree(a.base, a.reserved);
+        return e;
+    }
+    // the buffer ENDS where the mapping ends (16-byte alignment: up to 15 bytes of slack behind odd sizes)
+    const size_t user = (need + 15) / 16 * 16;
+    *p = static_cast<char*>(a.base) + (a.mapped - user);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[*p] = a;
+    return hipSuccess;
+}
+hipError_t carma_dev_free(void* p)
+{
+    if (!p) return hipSuccess;
+    if (!guard_mode()) return hipFree(p);
+    GuardAlloc a{};
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guard.find(p);
+        if (it == g_guard.end()) return hipErrorInvalidValue;
+        a = it->second;
+        g_guard.erase(it);
+    }
+    (void)hipDeviceSynchronize();                             // (hipFree's implicit synchronisation)
+    hipError_t e = hipMemUnmap(a.base, a.mapped);
+    if (e == hipSuccess) e = hipMemRelease(a.handle);
+    // (the address range stays reserved for the life of the process: an address is never handed out twice, so a pointer
+    // used after its buffer was freed faults as well)
+    return e;
+}
+#define hipMalloc(p, n) carma_dev_malloc_t((p), (n))
+#define hipFree(p) carma_dev_free((void*)(p))
+
 namespace carma {
 
 static thread_local char g_err[512] = "";

@@ -8,6 +8,21 @@
 #include "carma_launch.h"
 #include "carma_types.h"
 
+// Device allocations of the library go through these two.  CARMA_DEBUG_GUARD=1 (read once; a test switch, off by default)
+// gives every allocation a virtual-memory mapping of its own whose END is the end of the buffer, with unmapped address space
+// behind it: a kernel that reads or writes past a buffer faults instead of getting away with it (round 4: a read of two
+// doubles past the parameter batch had lived in the lane-group kernels for two rounds, caught only when a batch happened to
+// end on a page boundary).  tests/test_gpu_parity.py runs a cross-section of the entry points in that mode.
+hipError_t carma_dev_malloc(void** p, size_t n);
+hipError_t carma_dev_free(void* p);
+template <class T>
+static inline hipError_t carma_dev_malloc_t(T** p, size_t n)
+{
+    return carma_dev_malloc(reinterpret_cast<void**>(p), n);
+}
+#define hipMalloc(p, n) carma_dev_malloc_t((p), (n))
+#define hipFree(p) carma_dev_free((void*)(p))
+
 namespace carma {
 
 // Parallel-tempering sampler state of one context (carma_pt_host.hip, carma_shard.hip)

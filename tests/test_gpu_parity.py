@@ -1006,3 +1006,24 @@ def test_batches_at_the_end_of_their_allocation():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_guard.py")], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("CARMA_DEBUG_GUARD") == "1", reason="this IS the guarded run")
+def test_suite_cross_section_with_guarded_allocations():
+    """CARMA_DEBUG_GUARD=1 (carma_host.h): every device buffer of the library is a virtual-memory mapping of its own that ENDS
+    where the buffer ends, with unmapped address space behind it and an address range that is never handed out twice -- a kernel
+    reading or writing past a buffer (or through a stale pointer) faults.  The entry points' tests -- log-density of every launch
+    shape, Filter / Predict / Simulate, the three sampler paths, post-processing, the batched optimiser -- run once more in that
+    mode, in a process of their own.  (Round 4: the whole -m gpu suite passes in it; the library as it was before the fix of the
+    read past the parameter batch faults in it at any batch size.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CARMA_DEBUG_GUARD="1")
+    files = [os.path.join(root, "tests", f) for f in ("test_gpu_api.py", "test_gpu_post.py", "test_gpu_sampler.py")]
+    sel = ["tests/test_gpu_parity.py::test_launch_shapes_agree", "tests/test_gpu_parity.py::test_predict_orders",
+           "tests/test_gpu_parity.py::test_filter_of_many_models_in_one_launch", "tests/test_gpu_parity.py::test_regular_cadence_series",
+           "tests/test_gpu_parity.py::test_edge_cases_nan_inf_tiny_series", "tests/test_gpu_parity.py::test_ragged_and_empty_batches"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + files + sel,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
