@@ -139,10 +139,15 @@ def parity_census(got, want, thetas, p, labels, bounds, arbiter, rtol=1e-10, wha
     return out
 
 
-def assert_same_evaluation(a, b, thetas, p, what="", rtol=1e-8, cond_min=1e5, ceiling=1e-6):
+def assert_same_evaluation(a, b, thetas, p, what="", rtol=1e-8, cond_min=1e5, ceiling=1e-6, thetas_b=None, max_moved_frac=0.02):
     """Two launch shapes of the same evaluation (a, b: log-posteriors of the states `thetas`): within rtol of each other -- the
     bar for WELL-CONDITIONED states, kept as it was --; an entry beyond it must be a flagged ill-conditioned state
-    (cond(EigenMat) >= cond_min, where rounding is amplified on both sides) and still within `ceiling`."""
+    (cond(EigenMat) >= cond_min, where rounding is amplified on both sides) and still within `ceiling`.
+    thetas_b: the states b was evaluated at, when the two sides are two sampler kernels' chains.  The kernels round the rank-1
+    update of the proposal factor differently and a chain amplifies that from iteration to iteration (a 64-temperature ladder,
+    40 iterations: 1.8e-7 in a hot chain's theta, tools/fuzz_sampler.py seed 13) -- where the two states differ by more than
+    1e-10 the two log-posteriors are values at DIFFERENT points (each is held to the oracle at its own point elsewhere) and are
+    compared through `ceiling` only; at most max_moved_frac of the entries."""
     a, b = np.ravel(np.asarray(a, dtype=float)), np.ravel(np.asarray(b, dtype=float))
     th = np.asarray(thetas, dtype=float).reshape(a.size, -1)
     fin = np.isfinite(a)
@@ -151,6 +156,15 @@ def assert_same_evaluation(a, b, thetas, p, what="", rtol=1e-8, cond_min=1e5, ce
     rel[fin] = np.abs(b[fin] - a[fin]) / np.abs(a[fin])
     bad = np.flatnonzero(rel > rtol)
     assert rel.max() <= ceiling, "%s: %.2e apart" % (what, rel.max())
+    if thetas_b is not None and bad.size:
+        thb = np.asarray(thetas_b, dtype=float).reshape(a.size, -1)
+        moved = np.max(np.abs(thb - th) / (1.0 + np.abs(th)), axis=1) > 1e-10
+        nm = int(moved[bad].sum())
+        assert nm <= max(2, int(max_moved_frac * a.size)), "%s: %d states moved apart between the kernels" % (what, nm)
+        if nm:
+            print("%s: %d of %d states differ between the two kernels' chains by more than 1e-10 (rounding, amplified): their "
+                  "log-posteriors, up to %.1e apart, are values at different points" % (what, nm, a.size, rel[bad][moved[bad]].max()))
+        bad = bad[~moved[bad]]
     for i in bad:
         c = cond_eigenmat(th[i], p)
         assert c >= cond_min, "%s: a well-conditioned state (cond(EigenMat) %.1e) differs by %.2e between the kernels" % (what, c, rel[i])

@@ -163,8 +163,8 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
     # WELL-CONDITIONED states (the bar of round 2, kept); what exceeds it must be a flagged ill-conditioned state a hot
     # chain visits (cond(EigenMat) >= 1e5), and stays within 1e-6
     from helpers import assert_same_evaluation
-    assert_same_evaluation(a[1], b[1], b[0], p, "chain states, row vs ladder kernel")
-    assert_same_evaluation(a[3], b[3], b[2], p, "saved samples, row vs ladder kernel")
+    assert_same_evaluation(a[1], b[1], a[0], p, "chain states, row vs ladder kernel", thetas_b=b[0])
+    assert_same_evaluation(a[3], b[3], a[2], p, "saved samples, row vs ladder kernel", thetas_b=b[2])
     np.testing.assert_array_equal(b[4], a[4])
     np.testing.assert_array_equal(b[5], a[5])
 
@@ -200,8 +200,8 @@ def test_lane_kernel_walks_the_ladder_kernels_trajectory(cpa, p, q, T, R, kern, 
     np.testing.assert_allclose(b[0], a[0], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-9)
     from helpers import assert_same_evaluation
-    assert_same_evaluation(a[1], b[1], b[0], p, "chain states, lane vs ladder kernel")
-    assert_same_evaluation(a[3], b[3], b[2], p, "saved samples, lane vs ladder kernel")
+    assert_same_evaluation(a[1], b[1], a[0], p, "chain states, lane vs ladder kernel", thetas_b=b[0])
+    assert_same_evaluation(a[3], b[3], a[2], p, "saved samples, lane vs ladder kernel", thetas_b=b[2])
 
 
 def test_lane_kernel_is_the_choice_for_large_ensembles(cpa, monkeypatch):

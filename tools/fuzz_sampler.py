@@ -81,7 +81,7 @@ if __name__ == "__main__":
             fin = np.isfinite(b["lp"])
             assert np.array_equal(np.isfinite(a["lp"]), fin)
             from helpers import assert_same_evaluation
-            assert_same_evaluation(b["lp"], a["lp"], a["th"], p, "states")
+            assert_same_evaluation(b["lp"], a["lp"], b["th"], p, "states", thetas_b=a["th"])
             assert np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["swp"], b["swp"])
             t, y, yerr = irregular_series(n, seed=sd)
             m = orc.OracleModel(t, y, yerr, p, q, max_stdev=10.0 * y.std())
