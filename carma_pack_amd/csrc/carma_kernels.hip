@@ -246,6 +246,145 @@ __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ 
     if (e < B) out[e] = logdensity_car1(theta + 4 * e, series, n, pr);
 }
 
+// CAR(1), PARALLEL IN TIME (round 4): one evaluation per WAVE, for launches whose evaluations do not fill the lanes.
+// With one evaluation per lane the n - 1 steps of a series are one lane's dependent chain -- 44 us for 270 data whatever the
+// batch, slower than any CARMA(p >= 2) order at the same size.  But both recursions of KalmanFilter1 (kfilter.cpp:19-48) are
+// compositions of maps that can be multiplied out in any grouping:
+//   * the predicted process variance pv_k = var_k - e_k follows  pv_k = S (1 - rho^2) + rho^2 pv e / (pv + e)
+//     (S = sigsqr / 2 omega, rho = exp(-omega dt_k), e = scale yerr_{k-1}^2, pv = pv_{k-1}) -- a MOEBIUS map of pv,
+//     [[S (1 - rho^2) + rho^2 e, S (1 - rho^2) e], [1, e]]; all four entries are >= 0, so products of these matrices have no
+//     cancellation and compose to rounding;
+//   * given the variances, the mean follows the AFFINE map  mean_k = rho (1 - r) mean + rho r (y_{k-1} - mu),  r = pv / var.
+// So: lane l takes a block of ceil((n - 1) / 64) consecutive steps; exponentials and the block's matrix product in the lanes
+// side by side; an exclusive scan of the 64 block products across the wave (six shuffle stages, matrices renormalised by a
+// power of two); every lane then walks its block from the exact starting value with the reference's own step formulas, which
+// gives var_k, r_k and the block's affine map; a second scan for the mean; a last walk for the innovations.  The steps
+// inside a block are the reference's arithmetic; only the values at the 63 block boundaries come out of the scans.
+// rho_k and pv_k of the block live in LDS between the phases (2 (n - 1) doubles: n <= CAR1_SCAN_MAXN).
+constexpr int CAR1_SCAN_MAXN = 3072;
+struct M22 {
+    double a, b, c, d;
+};
+__device__ __forceinline__ M22 m22_mul(const M22& x, const M22& y)      // x after y
+{
+    return M22{fma(x.a, y.a, x.b * y.c), fma(x.a, y.b, x.b * y.d), fma(x.c, y.a, x.d * y.c), fma(x.c, y.b, x.d * y.d)};
+}
+__device__ __forceinline__ M22 m22_norm(const M22& x)                   // the map does not change under a common factor
+{
+    const double mx = fmax(fmax(fabs(x.a), fabs(x.b)), fmax(fabs(x.c), fabs(x.d)));
+    int e;
+    (void)frexp(mx, &e);
+    if (!(mx > 0.0 && mx < 1.0 / 0.0)) e = 0;
+    return M22{ldexp(x.a, -e), ldexp(x.b, -e), ldexp(x.c, -e), ldexp(x.d, -e)};
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restrict__ theta, int B,
+                                                          const double4* __restrict__ series, int n, Prior pr,
+                                                          double* __restrict__ out)
+{
+    extern __shared__ double car1_lds[];                      // rho[n], pv[n]
+    double* s_rho = car1_lds;
+    double* s_pv = car1_lds + n;
+    const int lane = threadIdx.x;
+    const long ev = blockIdx.x;
+    const double* th = theta + 4 * ev;
+    const double ysigma = th[0], ms = th[1], mu = th[2];
+    const double omega = exp(th[3]);
+    const double sigsqr = 2.0 * ysigma * ysigma * exp(th[3]);
+    const bool ok = !((omega > pr.max_freq) || (omega < pr.min_freq) || (ysigma > pr.max_stdev) || (ysigma < 0) || (ms < 0.5) ||
+                      (ms > 2.0));
+    const double S = sigsqr / (2.0 * omega);
+    const int m = n - 1;                                      // steps 1 .. m
+    const int c = (m + 63) / 64;                              // steps per lane
+    const int k0 = 1 + lane * c, k1 = (k0 + c - 1 < m) ? k0 + c - 1 : m;      // this lane's steps (none when k0 > m)
+    // ---- phase A: transition factors and the block's Moebius product
+    M22 L{1.0, 0.0, 0.0, 1.0};
+    for (int k = k0; k <= k1; k++) {
+        const double rho = exp_neg(-1.0 * omega * series[k].x);
+        s_rho[k] = rho;
+        const double e = series[k - 1].z * ms;
+        const double g = S * (1.0 - rho * rho), r2 = rho * rho;
+        const M22 Mk{fma(r2, e, g), g * e, 1.0, e};
+        L = m22_norm(m22_mul(Mk, L));
+    }
+    // ---- phase B: exclusive scan across the lanes (Kogge-Stone: lane l ends up with the product of the blocks of lanes < l)
+    M22 P = L;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        M22 Q{__shfl_up(P.a, o, 64), __shfl_up(P.b, o, 64), __shfl_up(P.c, o, 64), __shfl_up(P.d, o, 64)};
+        if (lane >= o) P = m22_norm(m22_mul(P, Q));
+    }
+    M22 E{__shfl_up(P.a, 1, 64), __shfl_up(P.b, 1, 64), __shfl_up(P.c, 1, 64), __shfl_up(P.d, 1, 64)};
+    if (lane == 0) E = M22{1.0, 0.0, 0.0, 1.0};
+    // ---- phase C: the block's variances by the reference's step, from the exact value at its start; the block's affine map
+    double pv = fma(E.a, S, E.b) * recip(fma(E.c, S, E.d));   // pv_{k0 - 1}  (pv_0 = S)
+    double al = 1.0, be = 0.0;                                // mean_{k1} = al mean_{k0 - 1} + be
+    LogLikAcc acc;
+    acc.init();
+    if (lane == 0) {
+        acc.add_var(S + series[0].z * ms);                    // var_0 (kfilter.cpp:21-26)
+        s_pv[0] = S;
+    }
+    for (int k = k0; k <= k1; k++) {
+        const double4 rp = series[k - 1];
+        const double e_prev = rp.z * ms;
+        const double var_prev = pv + e_prev;
+        const double r = pv * recip(var_prev);                // var_ratio
+        const double rho = s_rho[k];
+        pv = S * (1.0 - rho * rho) + rho * rho * pv * (1.0 - r);     // previous_var of the next step (kfilter.cpp:36-44)
+        s_pv[k] = pv;
+        acc.add_var(pv + series[k].z * ms);
+        const double a_k = rho * (1.0 - r), b_k = rho * r * (rp.y - mu);
+        be = fma(a_k, be, b_k);
+        al = a_k * al;
+    }
+    __syncthreads();                                          // (one wave: pv of the step before a block is its neighbour's)
+    // ---- phase D: scan of the affine maps; mean at the start of the block
+    double pa = al, pb = be;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double qa = __shfl_up(pa, o, 64), qb = __shfl_up(pb, o, 64);
+        if (lane >= o) {
+            pb = fma(pa, qb, pb);
+            pa = pa * qa;
+        }
+    }
+    double mean = __shfl_up(pb, 1, 64);                       // mean_{k0 - 1}  (mean_0 = 0)
+    if (lane == 0) mean = 0.0;
+    // ---- phase E: innovations
+    if (lane == 0) {
+        const double i0 = series[0].y - mu;
+        acc.chi2 += i0 * (i0 * recip(S + series[0].z * ms));
+    }
+    for (int k = k0; k <= k1; k++) {
+        const double4 rp = series[k - 1];
+        const double pvp = s_pv[k - 1];
+        const double r = pvp * recip(pvp + rp.z * ms);
+        const double rho = s_rho[k];
+        mean = rho * mean + rho * r * ((rp.y - mu) - mean);   // kfilter.cpp:40
+        const double4 rk = series[k];
+        const double innov = (rk.y - mu) - mean;
+        acc.chi2 += innov * (innov * recip(s_pv[k] + rk.z * ms));
+    }
+    // ---- phase F: the wave's sums
+    const double lg = wave_sum(log(acc.prod) + (double)acc.esum * LN2);
+    const double chi = wave_sum(acc.chi2);
+    double vmin = acc.vmin;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmin = fmin(vmin, __shfl_xor(vmin, o, 64));
+    if (lane == 0) {
+        double ll = -0.5 * lg - 0.5 * chi;
+        if (!(vmin > 0.0)) ll = (vmin - vmin) / (vmin - vmin);
+        ll += log_prior(ms, pr.measerr_dof);
+        out[ev] = ok ? ll : -1.0 / 0.0;
+    }
+}
+
 template <int P, int G>
 __global__ __launch_bounds__(64) void k_kfilter_carma(const double* __restrict__ om_re_im, const double* __restrict__ ma,
                                                       double sigsqr, const double4* __restrict__ series, int n,
@@ -532,7 +671,7 @@ static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
 int logdens_kernel_name(int p, long B, int n, char* buf, int len, bool repeated_dt)
 {
     switch (p) {
-        case 1: return snprintf(buf, len, "k_logdens_car1");
+        case 1: return snprintf(buf, len, "k_logdens_car1");     // (or its parallel-in-time form: launch_logdens_car1)
         case 2: return logdens_name_p<2>(B, n, buf, len, repeated_dt);
         case 3: return logdens_name_p<3>(B, n, buf, len, repeated_dt);
         case 4: return logdens_name_p<4>(B, n, buf, len, repeated_dt);
@@ -562,6 +701,18 @@ hipError_t launch_logdens_car1(const double* theta, int B, const double4* series
                                hipStream_t st)
 {
     (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
+    // up to 64 evaluations per CU the series is cut across a wave's lanes (k_logdens_car1_scan); beyond, the lanes are worth more
+    // as evaluations (CARMA_TUNE_CAR1_SCAN_MAX overrides: measured, tools/car1_probe.py)
+    static const long scan_max = [] {
+        const char* e = getenv("CARMA_TUNE_CAR1_SCAN_MAX");
+        return e ? atol(e) : -1L;
+    }();
+    const long smax = scan_max >= 0 ? scan_max : 64L * device_cus();
+    if (B <= smax && n >= 64 && n <= CAR1_SCAN_MAXN) {
+        hipLaunchKernelGGL(k_logdens_car1_scan, dim3((unsigned)B), dim3(64), sizeof(double) * 2 * (size_t)n, st, theta, B, series, n, pr,
+                           out);
+        return hipGetLastError();
+    }
     const unsigned blocks = (unsigned)(((long)B + 63) / 64);
     hipLaunchKernelGGL(k_logdens_car1, dim3(blocks), dim3(64), 0, st, theta, B, series, n, pr, out);
     return hipGetLastError();

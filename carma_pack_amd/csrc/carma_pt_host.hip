@@ -354,14 +354,19 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     //     lpc_min_evals): from 16 x #CUs chains (p = 3: 78 us flat up to 16 384 chains against 103-105, p = 4: 88-107 against
     //     116; at 3200 ... 4096 chains the ladder kernel's 74 / 79 us are still ahead of 78 / 83), p = 2 from 12 x #CUs (64 us
     //     flat against 73-96).
-    // CARMA_PT_KERNEL=lane forces it (T <= 64, p >= 2), CARMA_TUNE_PT_LANE_MIN = N replaces the table by "from N chains".
+    // CARMA_PT_KERNEL=lane forces it (T <= 64), CARMA_TUNE_PT_LANE_MIN = N replaces the table by "from N chains".
     const char* force = getenv("CARMA_PT_KERNEL");
-    if (e == hipSuccess && c->p >= 2 && ntemps <= 64) {
+    if (e == hipSuccess && ntemps <= 64) {
         const char* tv = getenv("CARMA_TUNE_PT_LANE_MIN");
         const long cus = device_cus();
         const int G = c->p == 2 ? 2 : (c->p <= 4 ? 4 : 8);
         const long ladder_waves = (long)nreplicas * ((ntemps * G + 63) / 64);
         bool pays = ladder_waves > 4 * cus;
+        // CAR(1): k_pt gives a chain ONE lane for the whole series (44 us per iteration at n = 270 whatever the ensemble), the batched
+        // launch cuts the series across a wave (k_logdens_car1_scan: 8 us for 1024 chains) -- 18.6 against 43.8 us per iteration
+        // at 16 x 64, 24.8 against 44.1 at 16 x 256, 59.7 against 73.9 at 16 x 2048; only where the parallel-in-time launch has
+        // just run out of waves (48 ... 64 x #CUs chains) the ladder kernel is ahead, 46.9 against 51.4 (car1_sampler_v1.txt)
+        if (c->p == 1) pays = !((long)nchain > 48 * cus && (long)nchain <= 64 * cus);
         if (c->p == 2) pays = pays || (long)nchain > 12 * cus;
         if (c->p == 3 || c->p == 4) pays = pays || (long)nchain > 16 * cus;
         if (tv) pays = (long)nchain >= atol(tv);

@@ -323,14 +323,14 @@ static RamState ram_state(double* scratch, int d, long nc)
     return S;
 }
 
-// f(std::integral_constant<int, d>) for the run-time d (5 <= d <= 16: p >= 2)
+// f(std::integral_constant<int, d>) for the run-time d (4: CAR(1); 5 <= d <= 16: p >= 2)
 template <class F>
 static hipError_t ram_launch_d(int d, F&& f)
 {
     switch (d) {
 #define CARMA_RAM_D(N) \
     case N: f(std::integral_constant<int, N>{}); return hipGetLastError();
-        CARMA_RAM_D(5) CARMA_RAM_D(6) CARMA_RAM_D(7) CARMA_RAM_D(8) CARMA_RAM_D(9) CARMA_RAM_D(10) CARMA_RAM_D(11)
+        CARMA_RAM_D(4) CARMA_RAM_D(5) CARMA_RAM_D(6) CARMA_RAM_D(7) CARMA_RAM_D(8) CARMA_RAM_D(9) CARMA_RAM_D(10) CARMA_RAM_D(11)
         CARMA_RAM_D(12) CARMA_RAM_D(13) CARMA_RAM_D(14) CARMA_RAM_D(15) CARMA_RAM_D(16)
 #undef CARMA_RAM_D
         default: return hipErrorInvalidValue;
@@ -344,7 +344,7 @@ hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const doubl
                           unsigned* nswap, double* samples, double* sample_lp, bool repeated_dt, hipStream_t st)
 {
     (void)hipGetLastError();
-    if (p < 2 || L.T < 1 || L.T > 64 || L.d < 5 || L.d > RAM_DMAX) return hipErrorInvalidValue;
+    if (p < 1 || L.T < 1 || L.T > 64 || L.d < 4 || L.d > RAM_DMAX || (p == 1) != (L.d == 4)) return hipErrorInvalidValue;
     const long nc = (long)L.R * L.T;
     const RamState S = ram_state(scratch, L.d, nc);
     const int LPW = 64 / L.T;
@@ -367,7 +367,9 @@ hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const doubl
             e = ram_launch_d(L.d, [&](auto dc) {
                 hipLaunchKernelGGL((k_ram_propose<decltype(dc)::value>), dim3(grid), dim3(256), 0, st, Li, S);
             });
-        if (e == hipSuccess) e = launch_logdens_carma(p, S.thn, (int)nc, L.d, L.q, series, L.n, pr, 0, S.ll, st, repeated_dt);
+        if (e == hipSuccess)
+            e = p == 1 ? launch_logdens_car1(S.thn, (int)nc, series, L.n, pr, S.ll, st)
+                       : launch_logdens_carma(p, S.thn, (int)nc, L.d, L.q, series, L.n, pr, 0, S.ll, st, repeated_dt);
         if (e == hipSuccess) {
             const bool next = fused && it + 1 < L.niter;
             e = ram_launch_d(L.d, [&](auto dc) {

@@ -104,6 +104,36 @@ def test_car1_golden(cpa, golden_dir):
     assert_parity(ctx.logdensity(th), m.logdensity_batch(th), RTOL, "car1 batch")
 
 
+@pytest.mark.parametrize("n", [64, 65, 127, 128, 129, 270, 1000, 3072, 3073])
+def test_car1_parallel_in_time(cpa, n):
+    """k_logdens_car1_scan (round 4): CAR(1) with the series cut across a wave's lanes -- the variance recursion as a scan of
+    Moebius maps, the mean recursion as a scan of affine maps (kfilter.cpp:19-48 inside every lane's block of steps) -- against
+    the oracle and against the one-evaluation-per-lane kernel, which launches beyond 64 evaluations per CU (and series
+    longer than 3072 data, or shorter than 64) still take.  Prior-like draws, bound violations, measurement errors from 1e-6 to
+    1e3 of the signal, a stretch of repeated time steps, series lengths around the block boundaries."""
+    rng = np.random.default_rng(600 + n)
+    t = np.cumsum(rng.uniform(0.2, 3.0, n))
+    t[n // 3: n // 3 + 7] = t[n // 3] + 0.5 * np.arange(7)            # regular stretch
+    t = np.sort(t) + np.arange(n) * 1e-9
+    y = 10.0 + np.cumsum(rng.standard_normal(n)) * 0.3
+    yerr = 0.05 * 10.0 ** rng.uniform(-4.0, 3.0, n)
+    ctx = cpa.Context(t, y, yerr, 1, 0)
+    m = orc.OracleModel(t, y, yerr, 1)
+    th = np.array([prior_like_theta(rng, 1, 0, t, y) for _ in range(200)])
+    th[::9, 3] = np.log(ctx.prior()[1] * 1.5)                          # omega > max_freq -> -inf
+    th[1::9, 1] = 2.5                                                  # measurement-error scale out of bounds
+    th[2::9, 3] = np.log(ctx.prior()[2] * 1.0001)                      # omega right at the lower bound: the slowest decay
+    want = m.logdensity_batch(th)
+    small = ctx.logdensity(th)                                         # 200 evaluations: one per wave
+    big = ctx.logdensity(np.tile(th, (90, 1)))[:200]                   # 18 000: one per lane
+    assert_parity(small, want, RTOL, "CAR(1) parallel in time, n=%d" % n)
+    assert_parity(big, want, RTOL, "CAR(1) one evaluation per lane, n=%d" % n)
+    fin = np.isfinite(want)
+    assert np.max(np.abs(small[fin] - big[fin]) / np.abs(big[fin])) <= 1e-11
+    one = ctx.logdensity(th[:1])
+    assert one[0] == small[0]
+
+
 def test_cpp_fixture(cpa, golden_dir):
     g = np.load(os.path.join(golden_dir, "cpp_carma_test300.npz"))
     mean, var = cpa.kfilter_carma(g["t"], g["y"], g["yerr"], float(g["sigsqr"]), g["omega"], g["ma"])

@@ -170,7 +170,8 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
 
 
 @pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1), (3, 1, 1, 5), (4, 2, 17, 2),
-                                     (2, 0, 33, 1), (3, 2, 64, 1), (5, 3, 16, 9), (6, 2, 7, 40), (5, 0, 16, 130)])
+                                     (2, 0, 33, 1), (3, 2, 64, 1), (5, 3, 16, 9), (6, 2, 7, 40), (5, 0, 16, 130),
+                                     (1, 0, 8, 5), (1, 0, 16, 64)])
 @pytest.mark.parametrize("kern", ["lane"])
 def test_lane_kernel_walks_the_ladder_kernels_trajectory(cpa, p, q, T, R, kern, monkeypatch):
     """The sampler for large ensembles (carma_pt_lane.hip: one chain per LANE, an iteration = propose kernel + batched

@@ -17,7 +17,7 @@ for B in (64, 1024, 16384, 65536, 262144):
     for _ in range(50): ctx.logdensity_dev(d.data_ptr(), B, out.data_ptr(), stream=st)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
     print("B=%7d  %7.1f us/launch  %.3e evals/s  finite %d" % (B, 1e6 * dt, B / dt, int(np.isfinite(out.cpu().numpy()).sum())), flush=True)
-for R in (64, 1024):
+for R in [int(x) for x in os.environ.get("CAR1_PROBE_R", "64,1024").split(",")]:
     ctx.pt_create(16, R, adapt_iters=10 ** 9, seed=3); ctx.pt_start(None); ctx.pt_iterate(50)
     t0 = time.perf_counter(); ctx.pt_iterate(400); dt = time.perf_counter() - t0
     print("sampler 16 x %4d (%s): %8.1f it/s  %.1f us/iteration" % (R, ctx.pt_kernel(), 400 / dt, 1e6 * dt / 400), flush=True)

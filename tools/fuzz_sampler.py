@@ -13,8 +13,8 @@ def cases(ncase, seed):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(ncase):
-        p = int(rng.integers(2, 8))
-        q = int(rng.integers(0, p))
+        p = int(rng.integers(1, 8))                                  # (1: CAR(1), on the large-ensemble path since round 4)
+        q = int(rng.integers(0, p)) if p > 1 else 0
         T = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 20, 33, 64, 65, 70]))
         wg = (T + 3) // 4
         rows = int(rng.choice([1, 2, 255, 256, 257, 511, 512, 513, 767, 768, 769, 1000])) if rng.random() < 0.6 else int(rng.integers(1, 900))
