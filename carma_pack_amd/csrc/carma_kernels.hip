@@ -260,8 +260,9 @@ __global__ __launch_bounds__(64) void k_logdens_car1(const double* __restrict__ 
 // power of two); every lane then walks its block from the exact starting value with the reference's own step formulas, which
 // gives var_k, r_k and the block's affine map; a second scan for the mean; a last walk for the innovations.  The steps
 // inside a block are the reference's arithmetic; only the values at the 63 block boundaries come out of the scans.
-// rho_k and pv_k of the block live in LDS between the phases (2 (n - 1) doubles: n <= CAR1_SCAN_MAXN).
-constexpr int CAR1_SCAN_MAXN = 3072;
+// Nothing is kept between the walks but the block's starting values -- the transition factors are evaluated once per walk
+// (three exponentials per step instead of one: 0.5 us of 8 at n = 270) -- so the series may be of any length: 10^5 data in
+// 0.5 ms where a lane of its own takes 16.
 struct M22 {
     double a, b, c, d;
 };
@@ -287,9 +288,6 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
                                                           const double4* __restrict__ series, int n, Prior pr,
                                                           double* __restrict__ out)
 {
-    extern __shared__ double car1_lds[];                      // rho[n], pv[n]
-    double* s_rho = car1_lds;
-    double* s_pv = car1_lds + n;
     const int lane = threadIdx.x;
     const long ev = blockIdx.x;
     const double* th = theta + 4 * ev;
@@ -306,7 +304,6 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
     M22 L{1.0, 0.0, 0.0, 1.0};
     for (int k = k0; k <= k1; k++) {
         const double rho = exp_neg(-1.0 * omega * series[k].x);
-        s_rho[k] = rho;
         const double e = series[k - 1].z * ms;
         const double g = S * (1.0 - rho * rho), r2 = rho * rho;
         const M22 Mk{fma(r2, e, g), g * e, 1.0, e};
@@ -322,28 +319,24 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
     M22 E{__shfl_up(P.a, 1, 64), __shfl_up(P.b, 1, 64), __shfl_up(P.c, 1, 64), __shfl_up(P.d, 1, 64)};
     if (lane == 0) E = M22{1.0, 0.0, 0.0, 1.0};
     // ---- phase C: the block's variances by the reference's step, from the exact value at its start; the block's affine map
-    double pv = fma(E.a, S, E.b) * recip(fma(E.c, S, E.d));   // pv_{k0 - 1}  (pv_0 = S)
+    const double pv_start = fma(E.a, S, E.b) * recip(fma(E.c, S, E.d));   // pv_{k0 - 1}  (pv_0 = S)
+    double pv = pv_start;
     double al = 1.0, be = 0.0;                                // mean_{k1} = al mean_{k0 - 1} + be
     LogLikAcc acc;
     acc.init();
-    if (lane == 0) {
-        acc.add_var(S + series[0].z * ms);                    // var_0 (kfilter.cpp:21-26)
-        s_pv[0] = S;
-    }
+    if (lane == 0) acc.add_var(S + series[0].z * ms);         // var_0 (kfilter.cpp:21-26)
     for (int k = k0; k <= k1; k++) {
         const double4 rp = series[k - 1];
         const double e_prev = rp.z * ms;
         const double var_prev = pv + e_prev;
         const double r = pv * recip(var_prev);                // var_ratio
-        const double rho = s_rho[k];
+        const double rho = exp_neg(-1.0 * omega * series[k].x);
         pv = S * (1.0 - rho * rho) + rho * rho * pv * (1.0 - r);     // previous_var of the next step (kfilter.cpp:36-44)
-        s_pv[k] = pv;
         acc.add_var(pv + series[k].z * ms);
         const double a_k = rho * (1.0 - r), b_k = rho * r * (rp.y - mu);
         be = fma(a_k, be, b_k);
         al = a_k * al;
     }
-    __syncthreads();                                          // (one wave: pv of the step before a block is its neighbour's)
     // ---- phase D: scan of the affine maps; mean at the start of the block
     double pa = al, pb = be;
 #pragma unroll
@@ -361,15 +354,16 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
         const double i0 = series[0].y - mu;
         acc.chi2 += i0 * (i0 * recip(S + series[0].z * ms));
     }
+    pv = pv_start;                                            // the same walk once more (same operations: same values)
     for (int k = k0; k <= k1; k++) {
         const double4 rp = series[k - 1];
-        const double pvp = s_pv[k - 1];
-        const double r = pvp * recip(pvp + rp.z * ms);
-        const double rho = s_rho[k];
-        mean = rho * mean + rho * r * ((rp.y - mu) - mean);   // kfilter.cpp:40
+        const double r = pv * recip(pv + rp.z * ms);
         const double4 rk = series[k];
+        const double rho = exp_neg(-1.0 * omega * rk.x);
+        mean = rho * mean + rho * r * ((rp.y - mu) - mean);   // kfilter.cpp:40
+        pv = S * (1.0 - rho * rho) + rho * rho * pv * (1.0 - r);
         const double innov = (rk.y - mu) - mean;
-        acc.chi2 += innov * (innov * recip(s_pv[k] + rk.z * ms));
+        acc.chi2 += innov * (innov * recip(pv + rk.z * ms));
     }
     // ---- phase F: the wave's sums
     const double lg = wave_sum(log(acc.prod) + (double)acc.esum * LN2);
@@ -701,16 +695,16 @@ hipError_t launch_logdens_car1(const double* theta, int B, const double4* series
                                hipStream_t st)
 {
     (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
-    // up to 64 evaluations per CU the series is cut across a wave's lanes (k_logdens_car1_scan); beyond, the lanes are worth more
+    // up to 48 evaluations per CU the series is cut across a wave's lanes (k_logdens_car1_scan); beyond, the lanes are worth more
     // as evaluations (CARMA_TUNE_CAR1_SCAN_MAX overrides: measured, tools/car1_probe.py)
     static const long scan_max = [] {
         const char* e = getenv("CARMA_TUNE_CAR1_SCAN_MAX");
         return e ? atol(e) : -1L;
     }();
-    const long smax = scan_max >= 0 ? scan_max : 64L * device_cus();
-    if (B <= smax && n >= 64 && n <= CAR1_SCAN_MAXN) {
-        hipLaunchKernelGGL(k_logdens_car1_scan, dim3((unsigned)B), dim3(64), sizeof(double) * 2 * (size_t)n, st, theta, B, series, n, pr,
-                           out);
+    const long smax = scan_max >= 0 ? scan_max : 48L * device_cus();   // (n = 270: 39 against 45 us at 12 288, 52 against 45 at 16 384)
+    // (both forms' times are proportional to the series' length: the break-even does not move with it)
+    if (B <= smax && n >= 64) {
+        hipLaunchKernelGGL(k_logdens_car1_scan, dim3((unsigned)B), dim3(64), 0, st, theta, B, series, n, pr, out);
         return hipGetLastError();
     }
     const unsigned blocks = (unsigned)(((long)B + 63) / 64);

@@ -104,12 +104,12 @@ def test_car1_golden(cpa, golden_dir):
     assert_parity(ctx.logdensity(th), m.logdensity_batch(th), RTOL, "car1 batch")
 
 
-@pytest.mark.parametrize("n", [64, 65, 127, 128, 129, 270, 1000, 3072, 3073])
+@pytest.mark.parametrize("n", [64, 65, 127, 128, 129, 270, 1000, 3072, 3073, 20000])
 def test_car1_parallel_in_time(cpa, n):
     """k_logdens_car1_scan (round 4): CAR(1) with the series cut across a wave's lanes -- the variance recursion as a scan of
     Moebius maps, the mean recursion as a scan of affine maps (kfilter.cpp:19-48 inside every lane's block of steps) -- against
     the oracle and against the one-evaluation-per-lane kernel, which launches beyond 64 evaluations per CU (and series
-    longer than 3072 data, or shorter than 64) still take.  Prior-like draws, bound violations, measurement errors from 1e-6 to
+    shorter than 64 data) still take.  Prior-like draws, bound violations, measurement errors from 1e-6 to
     1e3 of the signal, a stretch of repeated time steps, series lengths around the block boundaries."""
     rng = np.random.default_rng(600 + n)
     t = np.cumsum(rng.uniform(0.2, 3.0, n))
