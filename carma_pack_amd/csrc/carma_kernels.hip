@@ -284,18 +284,13 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restrict__ theta, int B,
-                                                          const double4* __restrict__ series, int n, Prior pr,
-                                                          double* __restrict__ out)
+// The wave-wide part: acc holds the lane's share of the log-likelihood sums afterwards.  MV: mean_k and var_k of every datum are
+// stored as well (KalmanFilter1::Filter + GetMean / GetVar, kfilter.hpp:116-117, 222-245).
+template <bool MV>
+__device__ __forceinline__ void car1_scan_wave(double sigsqr, double omega, double mu, double ms, const double4* __restrict__ series,
+                                               int n, LogLikAcc& acc, double* __restrict__ mean_out, double* __restrict__ var_out)
 {
-    const int lane = threadIdx.x;
-    const long ev = blockIdx.x;
-    const double* th = theta + 4 * ev;
-    const double ysigma = th[0], ms = th[1], mu = th[2];
-    const double omega = exp(th[3]);
-    const double sigsqr = 2.0 * ysigma * ysigma * exp(th[3]);
-    const bool ok = !((omega > pr.max_freq) || (omega < pr.min_freq) || (ysigma > pr.max_stdev) || (ysigma < 0) || (ms < 0.5) ||
-                      (ms > 2.0));
+    const int lane = threadIdx.x & 63;
     const double S = sigsqr / (2.0 * omega);
     const int m = n - 1;                                      // steps 1 .. m
     const int c = (m + 63) / 64;                              // steps per lane
@@ -322,7 +317,6 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
     const double pv_start = fma(E.a, S, E.b) * recip(fma(E.c, S, E.d));   // pv_{k0 - 1}  (pv_0 = S)
     double pv = pv_start;
     double al = 1.0, be = 0.0;                                // mean_{k1} = al mean_{k0 - 1} + be
-    LogLikAcc acc;
     acc.init();
     if (lane == 0) acc.add_var(S + series[0].z * ms);         // var_0 (kfilter.cpp:21-26)
     for (int k = k0; k <= k1; k++) {
@@ -353,6 +347,10 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
     if (lane == 0) {
         const double i0 = series[0].y - mu;
         acc.chi2 += i0 * (i0 * recip(S + series[0].z * ms));
+        if constexpr (MV) {
+            mean_out[0] = 0.0;
+            var_out[0] = S + series[0].z * ms;
+        }
     }
     pv = pv_start;                                            // the same walk once more (same operations: same values)
     for (int k = k0; k <= k1; k++) {
@@ -364,7 +362,27 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
         pv = S * (1.0 - rho * rho) + rho * rho * pv * (1.0 - r);
         const double innov = (rk.y - mu) - mean;
         acc.chi2 += innov * (innov * recip(pv + rk.z * ms));
+        if constexpr (MV) {
+            mean_out[k] = mean;
+            var_out[k] = pv + rk.z * ms;
+        }
     }
+}
+
+__global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restrict__ theta, int B,
+                                                          const double4* __restrict__ series, int n, Prior pr,
+                                                          double* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const long ev = blockIdx.x;
+    const double* th = theta + 4 * ev;
+    const double ysigma = th[0], ms = th[1], mu = th[2];
+    const double omega = exp(th[3]);
+    const double sigsqr = 2.0 * ysigma * ysigma * exp(th[3]);
+    const bool ok = !((omega > pr.max_freq) || (omega < pr.min_freq) || (ysigma > pr.max_stdev) || (ysigma < 0) || (ms < 0.5) ||
+                      (ms > 2.0));
+    LogLikAcc acc;
+    car1_scan_wave<false>(sigsqr, omega, mu, ms, series, n, acc, nullptr, nullptr);
     // ---- phase F: the wave's sums
     const double lg = wave_sum(log(acc.prod) + (double)acc.esum * LN2);
     const double chi = wave_sum(acc.chi2);
@@ -377,6 +395,15 @@ __global__ __launch_bounds__(64) void k_logdens_car1_scan(const double* __restri
         ll += log_prior(ms, pr.measerr_dof);
         out[ev] = ok ? ll : -1.0 / 0.0;
     }
+}
+
+// KalmanFilter1(time, y, yerr, sigsqr, omega).Filter(): mean[n], var[n] of one model, the series cut across ONE wave's lanes
+// (round 4; a lane of its own took 0.16 us per datum: 1.6 ms for 10^4 data)
+__global__ __launch_bounds__(64) void k_kfilter_car1_scan(double sigsqr, double omega, const double4* __restrict__ series, int n,
+                                                          double* __restrict__ mean, double* __restrict__ var)
+{
+    LogLikAcc acc;
+    car1_scan_wave<true>(sigsqr, omega, 0.0, 1.0, series, n, acc, mean, var);
 }
 
 template <int P, int G>
@@ -832,7 +859,10 @@ hipError_t launch_kfilter_car1(double sigsqr, double omega, const double4* serie
                                hipStream_t st)
 {
     (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
-    hipLaunchKernelGGL(k_kfilter_car1, dim3(1), dim3(64), 0, st, sigsqr, omega, series, n, mean, var);
+    if (n >= 64)
+        hipLaunchKernelGGL(k_kfilter_car1_scan, dim3(1), dim3(64), 0, st, sigsqr, omega, series, n, mean, var);
+    else
+        hipLaunchKernelGGL(k_kfilter_car1, dim3(1), dim3(64), 0, st, sigsqr, omega, series, n, mean, var);
     return hipGetLastError();
 }
 

@@ -132,6 +132,14 @@ def test_car1_parallel_in_time(cpa, n):
     assert np.max(np.abs(small[fin] - big[fin]) / np.abs(big[fin])) <= 1e-11
     one = ctx.logdensity(th[:1])
     assert one[0] == small[0]
+    # KalmanFilter1::Filter's mean[n] / var[n] through the same scans (k_kfilter_car1_scan)
+    for x in th[3:6]:
+        om = np.exp(x[3])
+        sig2 = 2.0 * x[0] ** 2 * om
+        mean, var = cpa.kfilter_car1(t, y - x[2], np.sqrt(x[1]) * yerr, sig2, om)
+        om_, ov_ = orc.kfilter_car1(t, y - x[2], np.sqrt(x[1]) * yerr, sig2, om)
+        np.testing.assert_allclose(var, ov_, rtol=1e-10)
+        np.testing.assert_allclose(mean, om_, rtol=0, atol=1e-10 * np.abs(y - x[2]).max())
 
 
 def test_cpp_fixture(cpa, golden_dir):
