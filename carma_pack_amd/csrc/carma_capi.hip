@@ -16,8 +16,6 @@
 #include "carma_host.h"
 
 // ---- device allocations (carma_host.h) -------------------------------------------------------------------------
-#undef hipMalloc
-#undef hipFree
 #include <map>
 #include <mutex>
 namespace {
@@ -39,7 +37,7 @@ bool guard_mode()
 }  // namespace
 hipError_t carma_dev_malloc(void** p, size_t n)
 {
-    if (!guard_mode()) return hipMalloc(p, n);
+    if (!guard_mode()) return ::hipMalloc(p, n);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -79,7 +77,7 @@ hipError_t carma_dev_malloc(void** p, size_t n)
 hipError_t carma_dev_free(void* p)
 {
     if (!p) return hipSuccess;
-    if (!guard_mode()) return hipFree(p);
+    if (!guard_mode()) return ::hipFree(p);
     GuardAlloc a{};
     {
         std::lock_guard<std::mutex> lk(g_guard_mu);
@@ -95,8 +93,6 @@ hipError_t carma_dev_free(void* p)
     // used after its buffer was freed faults as well)
     return e;
 }
-#define hipMalloc(p, n) carma_dev_malloc_t((p), (n))
-#define hipFree(p) carma_dev_free((void*)(p))
 
 namespace carma {
 
@@ -242,16 +238,16 @@ int select_device(int device)
 int Ctx::ensure_staging(int B)
 {
     if (B <= cap) return CARMA_OK;
-    if (d_theta) (void)hipFree(d_theta);
-    if (d_out) (void)hipFree(d_out);
+    if (d_theta) (void)dev_free(d_theta);
+    if (d_out) (void)dev_free(d_out);
     if (h_stage) (void)hipHostFree(h_stage);
     d_theta = d_out = h_stage = nullptr;
     cap = 0;
     int newcap = std::max(B, 1024);
-    hipError_t e = hipMalloc(&d_theta, sizeof(double) * (size_t)newcap * d);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(theta)");
-    e = hipMalloc(&d_out, sizeof(double) * (size_t)newcap);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(out)");
+    hipError_t e = dev_malloc(&d_theta, sizeof(double) * (size_t)newcap * d);
+    if (e != hipSuccess) return hip_fail(e, "dev_malloc(theta)");
+    e = dev_malloc(&d_out, sizeof(double) * (size_t)newcap);
+    if (e != hipSuccess) return hip_fail(e, "dev_malloc(out)");
     // pinned, so that both copies are real asynchronous DMA transfers ordered on the stream (a copy from pageable memory
     // is staged by the runtime and synchronises)
     e = hipHostMalloc(reinterpret_cast<void**>(&h_stage), sizeof(double) * (size_t)newcap * (d + 1), hipHostMallocDefault);
@@ -315,7 +311,7 @@ carma_ctx* carma_ctx_create(const double* time, const double* y, const double* y
         for (int k = 2; k < c->n; k++) rep += (s[4 * (size_t)k] == s[4 * (size_t)(k - 1)]);
         c->repeated_dt = c->n > 8 && 4 * rep >= c->n;
     }
-    hipError_t e = hipMalloc(&c->d_series, sizeof(double) * s.size());
+    hipError_t e = dev_malloc(&c->d_series, sizeof(double) * s.size());
     if (e == hipSuccess) e = hipMemcpy(c->d_series, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -332,9 +328,9 @@ void carma_ctx_destroy(carma_ctx* h)
     Ctx* c = reinterpret_cast<Ctx*>(h);
     (void)hipSetDevice(c->device);
     if (c->pt) pt_state_free(c);
-    if (c->d_series) (void)hipFree(c->d_series);
-    if (c->d_theta) (void)hipFree(c->d_theta);
-    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_series) (void)dev_free(c->d_series);
+    if (c->d_theta) (void)dev_free(c->d_theta);
+    if (c->d_out) (void)dev_free(c->d_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -471,10 +467,10 @@ struct Kf {
     int ensure_io(size_t nd)
     {
         if (nd <= io_cap) return CARMA_OK;
-        if (d_io) (void)hipFree(d_io);
+        if (d_io) (void)dev_free(d_io);
         d_io = nullptr;
         io_cap = 0;
-        hipError_t e = hipMalloc(&d_io, sizeof(double) * nd);
+        hipError_t e = dev_malloc(&d_io, sizeof(double) * nd);
         if (e != hipSuccess) return hip_fail(e, "carma_kf: hipMalloc");
         io_cap = nd;
         return CARMA_OK;
@@ -485,10 +481,10 @@ static void kf_free(Kf* k)
 {
     if (!k) return;
     (void)hipSetDevice(k->device);
-    if (k->d_series) (void)hipFree(k->d_series);
-    if (k->d_par) (void)hipFree(k->d_par);
-    if (k->d_io) (void)hipFree(k->d_io);
-    if (k->d_sing) (void)hipFree(k->d_sing);
+    if (k->d_series) (void)dev_free(k->d_series);
+    if (k->d_par) (void)dev_free(k->d_par);
+    if (k->d_io) (void)dev_free(k->d_io);
+    if (k->d_sing) (void)dev_free(k->d_sing);
     if (k->stream) (void)hipStreamDestroy(k->stream);
     delete k;
 }
@@ -528,9 +524,9 @@ static Kf* kf_make(const double* time, const double* y, const double* yerr, int 
     k->n = (int)t.size();
     k->sigsqr = sigsqr;
     k->car1_omega = car1_omega;
-    hipError_t e = hipMalloc(&k->d_series, sizeof(double) * s.size());
-    if (e == hipSuccess) e = hipMalloc(&k->d_par, sizeof(double) * par.size());
-    if (e == hipSuccess) e = hipMalloc(&k->d_sing, sizeof(int));
+    hipError_t e = dev_malloc(&k->d_series, sizeof(double) * s.size());
+    if (e == hipSuccess) e = dev_malloc(&k->d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = dev_malloc(&k->d_sing, sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(k->d_series, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(k->d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking);
@@ -685,12 +681,12 @@ int carma_kfilter_batch_carma(const double* time, const double* y, const double*
     double *d_s = nullptr, *d_par = nullptr, *d_mv = nullptr, *d_mean = nullptr, *d_var = nullptr;
     int* d_sing = nullptr;
     const size_t nmv = (size_t)2 * m * ((size_t)nmodels + 64), nout = (size_t)nmodels * m;
-    hipError_t e = hipMalloc(&d_s, sizeof(double) * s.size());
-    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
-    if (e == hipSuccess) e = hipMalloc(&d_mv, sizeof(double) * nmv);
-    if (e == hipSuccess) e = hipMalloc(&d_mean, sizeof(double) * nout);
-    if (e == hipSuccess) e = hipMalloc(&d_var, sizeof(double) * nout);
-    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int) * nmodels);
+    hipError_t e = dev_malloc(&d_s, sizeof(double) * s.size());
+    if (e == hipSuccess) e = dev_malloc(&d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = dev_malloc(&d_mv, sizeof(double) * nmv);
+    if (e == hipSuccess) e = dev_malloc(&d_mean, sizeof(double) * nout);
+    if (e == hipSuccess) e = dev_malloc(&d_var, sizeof(double) * nout);
+    if (e == hipSuccess) e = dev_malloc(&d_sing, sizeof(int) * nmodels);
     if (e == hipSuccess) e = hipMemcpy(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess)
@@ -699,7 +695,7 @@ int carma_kfilter_batch_carma(const double* time, const double* y, const double*
     if (e == hipSuccess) e = hipMemcpy(var, d_var, sizeof(double) * nout, hipMemcpyDeviceToHost);
     if (e == hipSuccess && singular) e = hipMemcpy(singular, d_sing, sizeof(int) * nmodels, hipMemcpyDeviceToHost);
     for (void* q : {(void*)d_s, (void*)d_par, (void*)d_mv, (void*)d_mean, (void*)d_var, (void*)d_sing})
-        if (q) (void)hipFree(q);
+        if (q) (void)dev_free(q);
     if (e != hipSuccess) return hip_fail(e, "carma_kfilter_batch_carma");
     return CARMA_OK;
 }
@@ -766,10 +762,10 @@ static int simulate_common(const double* time, int n, int p, double sigsqr, cons
     double *d_t = nullptr, *d_par = nullptr, *d_out = nullptr;
     int* d_sing = nullptr;
     const size_t nout = (size_t)npaths * n;
-    hipError_t e = hipMalloc(&d_t, sizeof(double) * n);
-    if (e == hipSuccess) e = hipMalloc(&d_par, sizeof(double) * par.size());
-    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(double) * nout);
-    if (e == hipSuccess) e = hipMalloc(&d_sing, sizeof(int));
+    hipError_t e = dev_malloc(&d_t, sizeof(double) * n);
+    if (e == hipSuccess) e = dev_malloc(&d_par, sizeof(double) * par.size());
+    if (e == hipSuccess) e = dev_malloc(&d_out, sizeof(double) * nout);
+    if (e == hipSuccess) e = dev_malloc(&d_sing, sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_t, t.data(), sizeof(double) * n, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_sing, 0, sizeof(int));
@@ -783,10 +779,10 @@ static int simulate_common(const double* time, int n, int p, double sigsqr, cons
     int sing = 0;
     if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&sing, d_sing, sizeof(int), hipMemcpyDeviceToHost);
-    if (d_t) (void)hipFree(d_t);
-    if (d_par) (void)hipFree(d_par);
-    if (d_out) (void)hipFree(d_out);
-    if (d_sing) (void)hipFree(d_sing);
+    if (d_t) (void)dev_free(d_t);
+    if (d_par) (void)dev_free(d_par);
+    if (d_out) (void)dev_free(d_out);
+    if (d_sing) (void)dev_free(d_sing);
     if (e != hipSuccess) return hip_fail(e, "carma_simulate");
     return sing ? 1 : CARMA_OK;
 }

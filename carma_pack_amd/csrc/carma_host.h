@@ -16,12 +16,11 @@
 hipError_t carma_dev_malloc(void** p, size_t n);
 hipError_t carma_dev_free(void* p);
 template <class T>
-static inline hipError_t carma_dev_malloc_t(T** p, size_t n)
+static inline hipError_t dev_malloc(T** p, size_t n)          // (typed front end: dev_malloc(&d_x, bytes))
 {
     return carma_dev_malloc(reinterpret_cast<void**>(p), n);
 }
-#define hipMalloc(p, n) carma_dev_malloc_t((p), (n))
-#define hipFree(p) carma_dev_free((void*)(p))
+static inline hipError_t dev_free(void* p) { return carma_dev_free(p); }
 
 namespace carma {
 

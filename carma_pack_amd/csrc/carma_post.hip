@@ -270,13 +270,13 @@ struct DevBufs {                                              // frees what it h
     ~DevBufs()
     {
         for (void* q : p)
-            if (q) (void)hipFree(q);
+            if (q) (void)dev_free(q);
     }
     template <class T>
     hipError_t alloc(T** out, size_t n)
     {
         void* q = nullptr;
-        const hipError_t e = hipMalloc(&q, n * sizeof(T) ? n * sizeof(T) : sizeof(T));
+        const hipError_t e = dev_malloc(&q, n * sizeof(T) ? n * sizeof(T) : sizeof(T));
         if (e == hipSuccess) p.push_back(q);
         *out = reinterpret_cast<T*>(q);
         return e;

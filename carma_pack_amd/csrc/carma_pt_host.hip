@@ -22,24 +22,24 @@ void pt_state_free(Ctx* c)
 {
     PtState* s = c->pt;
     if (!s) return;
-    if (s->d_temps) (void)hipFree(s->d_temps);
+    if (s->d_temps) (void)dev_free(s->d_temps);
     if (!s->ext_state) {
-        if (s->d_theta) (void)hipFree(s->d_theta);
-        if (s->d_lp) (void)hipFree(s->d_lp);
+        if (s->d_theta) (void)dev_free(s->d_theta);
+        if (s->d_lp) (void)dev_free(s->d_lp);
     }
-    if (s->d_chol) (void)hipFree(s->d_chol);
-    if (s->d_nacc) (void)hipFree(s->d_nacc);
-    if (s->d_nswap) (void)hipFree(s->d_nswap);
-    if (s->d_samples) (void)hipFree(s->d_samples);
-    if (s->d_slp) (void)hipFree(s->d_slp);
-    if (s->d_stage) (void)hipFree(s->d_stage);
-    if (s->d_abort) (void)hipFree(s->d_abort);
-    if (s->d_backup) (void)hipFree(s->d_backup);
-    if (s->d_lane_scratch) (void)hipFree(s->d_lane_scratch);
-    if (s->d_send) (void)hipFree(s->d_send);
-    if (s->d_recv) (void)hipFree(s->d_recv);
-    if (s->d_bnd_swaps) (void)hipFree(s->d_bnd_swaps);
-    if (s->d_checksum) (void)hipFree(s->d_checksum);
+    if (s->d_chol) (void)dev_free(s->d_chol);
+    if (s->d_nacc) (void)dev_free(s->d_nacc);
+    if (s->d_nswap) (void)dev_free(s->d_nswap);
+    if (s->d_samples) (void)dev_free(s->d_samples);
+    if (s->d_slp) (void)dev_free(s->d_slp);
+    if (s->d_stage) (void)dev_free(s->d_stage);
+    if (s->d_abort) (void)dev_free(s->d_abort);
+    if (s->d_backup) (void)dev_free(s->d_backup);
+    if (s->d_lane_scratch) (void)dev_free(s->d_lane_scratch);
+    if (s->d_send) (void)dev_free(s->d_send);
+    if (s->d_recv) (void)dev_free(s->d_recv);
+    if (s->d_bnd_swaps) (void)dev_free(s->d_bnd_swaps);
+    if (s->d_checksum) (void)dev_free(s->d_checksum);
     delete s;
     c->pt = nullptr;
 }
@@ -331,12 +331,12 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     R0[(size_t)2 * d + 2] = std::sqrt(var / c->n);
     std::vector<double> chol(nchain * d * d);
     for (size_t k = 0; k < nchain; k++) std::memcpy(&chol[k * d * d], R0.data(), sizeof(double) * d * d);
-    e = hipMalloc(&s->d_temps, sizeof(double) * ntemps);
-    if (e == hipSuccess) e = hipMalloc(&s->d_theta, sizeof(double) * nchain * d);
-    if (e == hipSuccess) e = hipMalloc(&s->d_lp, sizeof(double) * nchain);
-    if (e == hipSuccess) e = hipMalloc(&s->d_chol, sizeof(double) * nchain * d * d);
-    if (e == hipSuccess) e = hipMalloc(&s->d_nacc, sizeof(unsigned) * nchain);
-    if (e == hipSuccess) e = hipMalloc(&s->d_nswap, sizeof(unsigned) * nchain);
+    e = dev_malloc(&s->d_temps, sizeof(double) * ntemps);
+    if (e == hipSuccess) e = dev_malloc(&s->d_theta, sizeof(double) * nchain * d);
+    if (e == hipSuccess) e = dev_malloc(&s->d_lp, sizeof(double) * nchain);
+    if (e == hipSuccess) e = dev_malloc(&s->d_chol, sizeof(double) * nchain * d * d);
+    if (e == hipSuccess) e = dev_malloc(&s->d_nacc, sizeof(unsigned) * nchain);
+    if (e == hipSuccess) e = dev_malloc(&s->d_nswap, sizeof(unsigned) * nchain);
     if (e == hipSuccess) e = hipMemcpy(s->d_temps, s->temps.data(), sizeof(double) * ntemps, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_chol, chol.data(), sizeof(double) * chol.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_nacc, 0, sizeof(unsigned) * nchain);
@@ -373,7 +373,7 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
         const bool forced = force && std::strcmp(force, "lane") == 0;
         if (forced || (!force && pays)) {
             s->use_lane = true;
-            e = hipMalloc(&s->d_lane_scratch, sizeof(double) * pt_lane_scratch_doubles(d, (long)nchain));
+            e = dev_malloc(&s->d_lane_scratch, sizeof(double) * pt_lane_scratch_doubles(d, (long)nchain));
         }
     }
     if (e == hipSuccess && c->p >= 2 && !s->use_lane) {
@@ -385,11 +385,11 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
             s->wpl = wpl;
             // tagged staging: two buffers x two copies of (theta[d], log-posterior) per chain; zeroed once (an all-zero
             // pair of words never validates)
-            e = hipMalloc(&s->d_stage, sizeof(unsigned long long) * 4 * nchain * (d + 1));
+            e = dev_malloc(&s->d_stage, sizeof(unsigned long long) * 4 * nchain * (d + 1));
             if (e == hipSuccess) e = hipMemset(s->d_stage, 0, sizeof(unsigned long long) * 4 * nchain * (d + 1));
-            if (e == hipSuccess) e = hipMalloc(&s->d_abort, sizeof(unsigned));
+            if (e == hipSuccess) e = dev_malloc(&s->d_abort, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(s->d_abort, 0, sizeof(unsigned));
-            if (e == hipSuccess) e = hipMalloc(&s->d_backup, sizeof(double) * nchain * (d + 1 + (size_t)d * d));
+            if (e == hipSuccess) e = dev_malloc(&s->d_backup, sizeof(double) * nchain * (d + 1 + (size_t)d * d));
         }
     }
     if (e != hipSuccess) {
@@ -424,8 +424,8 @@ int carma_pt_bind_state(carma_ctx* h, double* d_theta, double* d_logpost)
     if (e == hipSuccess) e = hipMemcpy(d_logpost, s->d_lp, sizeof(double) * nchain, hipMemcpyDeviceToDevice);
     if (e != hipSuccess) return hip_fail(e, "carma_pt_bind_state");
     if (!s->ext_state) {
-        (void)hipFree(s->d_theta);
-        (void)hipFree(s->d_lp);
+        (void)dev_free(s->d_theta);
+        (void)dev_free(s->d_lp);
     }
     s->d_theta = d_theta;
     s->d_lp = d_logpost;
@@ -565,13 +565,13 @@ int carma_pt_sample(carma_ctx* h, int nsamples, int thin, double* samples, doubl
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     if (s->cap < nsamples) {
-        if (s->d_samples) (void)hipFree(s->d_samples);
-        if (s->d_slp) (void)hipFree(s->d_slp);
+        if (s->d_samples) (void)dev_free(s->d_samples);
+        if (s->d_slp) (void)dev_free(s->d_slp);
         s->d_samples = s->d_slp = nullptr;
         s->cap = 0;
-        e = hipMalloc(&s->d_samples, sizeof(double) * (size_t)s->R * nsamples * c->d);
-        if (e == hipSuccess) e = hipMalloc(&s->d_slp, sizeof(double) * (size_t)s->R * nsamples);
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc(samples)");
+        e = dev_malloc(&s->d_samples, sizeof(double) * (size_t)s->R * nsamples * c->d);
+        if (e == hipSuccess) e = dev_malloc(&s->d_slp, sizeof(double) * (size_t)s->R * nsamples);
+        if (e != hipSuccess) return hip_fail(e, "dev_malloc(samples)");
         s->cap = nsamples;
     }
     long off = 0;

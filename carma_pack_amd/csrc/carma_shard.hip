@@ -327,11 +327,11 @@ static int iterate_sharded(carma_ctx* const* shards, int nlocal, long niter, car
     for (int i = 0; i < nlocal; i++) {
         PtState* s = cs[i]->pt;
         if (!s->d_send) {
-            e = hipMalloc(&s->d_send, sizeof(double) * nbuf);
-            if (e == hipSuccess) e = hipMalloc(&s->d_recv, sizeof(double) * nbuf);
-            if (e == hipSuccess) e = hipMalloc(&s->d_bnd_swaps, sizeof(unsigned));
+            e = dev_malloc(&s->d_send, sizeof(double) * nbuf);
+            if (e == hipSuccess) e = dev_malloc(&s->d_recv, sizeof(double) * nbuf);
+            if (e == hipSuccess) e = dev_malloc(&s->d_bnd_swaps, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(s->d_bnd_swaps, 0, sizeof(unsigned));
-            if (e == hipSuccess) e = hipMalloc(&s->d_checksum, 4 * sizeof(unsigned long long));
+            if (e == hipSuccess) e = dev_malloc(&s->d_checksum, 4 * sizeof(unsigned long long));
             if (e == hipSuccess) e = hipMemset(s->d_checksum, 0, 4 * sizeof(unsigned long long));
             if (e != hipSuccess) return hip_fail(e, "carma_pt_iterate_sharded: boundary buffers");
         }
@@ -580,10 +580,10 @@ int carma_pt_sample_sharded(carma_ctx* const* shards, int nlocal, int nsamples, 
     const size_t R = (size_t)c0->pt->R, d = (size_t)c0->d;
     if (owner) {
         hipError_t e = hipSetDevice(c0->device);
-        if (e == hipSuccess) e = hipMalloc(&d_s, sizeof(double) * R * nsamples * d);
-        if (e == hipSuccess) e = hipMalloc(&d_l, sizeof(double) * R * nsamples);
+        if (e == hipSuccess) e = dev_malloc(&d_s, sizeof(double) * R * nsamples * d);
+        if (e == hipSuccess) e = dev_malloc(&d_l, sizeof(double) * R * nsamples);
         if (e != hipSuccess) {
-            if (d_s) (void)hipFree(d_s);
+            if (d_s) (void)dev_free(d_s);
             return hip_fail(e, "carma_pt_sample_sharded: sample buffers");
         }
     }
@@ -592,8 +592,8 @@ int carma_pt_sample_sharded(carma_ctx* const* shards, int nlocal, int nsamples, 
         hipError_t e = hipSuccess;
         if (rc == CARMA_OK) e = hipMemcpy(samples, d_s, sizeof(double) * R * nsamples * d, hipMemcpyDeviceToHost);
         if (rc == CARMA_OK && e == hipSuccess) e = hipMemcpy(logposts, d_l, sizeof(double) * R * nsamples, hipMemcpyDeviceToHost);
-        (void)hipFree(d_s);
-        (void)hipFree(d_l);
+        (void)dev_free(d_s);
+        (void)dev_free(d_l);
         if (e != hipSuccess) rc = hip_fail(e, "carma_pt_sample_sharded: D2H");
     }
     return rc;
