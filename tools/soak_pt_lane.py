@@ -13,7 +13,8 @@ from helpers import assert_parity_states, irregular_series, loglik_truth, oracle
 niter = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 fails = 0
 SHAPES = ((5, 3, 16, 1024, 270), (5, 3, 16, 4099, 150), (7, 6, 8, 2048, 120), (3, 1, 33, 500, 120), (2, 1, 64, 300, 100),
-          (4, 2, 10, 1300, 150), (6, 5, 12, 1100, 90), (2, 0, 1, 20000, 90), (5, 0, 7, 2341, 200))
+          (4, 2, 10, 1300, 150), (6, 5, 12, 1100, 90), (2, 0, 1, 20000, 90), (5, 0, 7, 2341, 200),
+          (1, 0, 16, 64, 270), (1, 0, 8, 1500, 120), (1, 0, 5, 4000, 70))          # CAR(1): the parallel-in-time launch / the lane form
 only = os.environ.get("SOAK_ONLY")
 for (p, q, T, R, n) in [SHAPES[int(only)]] if only else SHAPES:
     t, y, yerr = irregular_series(n, seed=11 * p + q)
