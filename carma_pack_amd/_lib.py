@@ -170,6 +170,9 @@ def _load():
     L.carma_pt_boundary_check.argtypes = [C.c_void_p]
     L.carma_pt_kernel_in_use.argtypes = [C.c_void_p]
     L.carma_pt_sweep.argtypes = [C.c_void_p]
+    L.carma_pt_debug_draws.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ulonglong, _dp, _dp, _dp]
+    L.carma_pt_get_factor.argtypes = [C.c_void_p, _dp]
+    L.carma_pt_set_factor.argtypes = [C.c_void_p, _dp]
     return L
 
 
@@ -185,7 +188,8 @@ EXPORTS = [
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_sample_sharded", "carma_pt_boundary_stats",
-    "carma_pt_boundary_check", "carma_pt_sweep", "carma_pt_kernel_in_use",
+    "carma_pt_boundary_check", "carma_pt_sweep", "carma_pt_kernel_in_use", "carma_pt_debug_draws", "carma_pt_get_factor",
+    "carma_pt_set_factor",
 ]
 
 
@@ -370,6 +374,26 @@ class Context:
         acc, swp = np.empty((R, T)), np.empty((R, T))
         check(lib.carma_pt_stats(self._h, ptr(acc), ptr(swp), int(bool(reset))), "carma_pt_stats")
         return acc, swp
+
+    def pt_get_factor(self):
+        """chol_factor_ of every chain, [R][T][d][d] (upper triangular; src/steps.cpp:32)."""
+        R, T = self._pt_shape
+        chol = np.empty((R, T, self.d, self.d))
+        check(lib.carma_pt_get_factor(self._h, ptr(chol)), "carma_pt_get_factor")
+        return chol
+
+    def pt_set_factor(self, chol):
+        R, T = self._pt_shape
+        chol = np.ascontiguousarray(chol, dtype=np.float64).reshape(R, T, self.d, self.d)
+        check(lib.carma_pt_set_factor(self._h, ptr(chol)), "carma_pt_set_factor")
+
+    def pt_debug_draws(self, replica, temperature, iteration):
+        """(z[d], u_accept, u_swap): the variates chain (replica, temperature) uses at `iteration`, from the device's own
+        generator (carma_pt_debug_draws)."""
+        z, ua, us = np.empty(self.d), np.empty(1), np.empty(1)
+        check(lib.carma_pt_debug_draws(self._h, int(replica), int(temperature), int(iteration), ptr(z), ptr(ua), ptr(us)),
+              "carma_pt_debug_draws")
+        return z, float(ua[0]), float(us[0])
 
     def pt_kernel(self):
         """"row" (k_pt_row), "ladder" (k_pt) or "lane" (k_pt_lane, large ensembles): the sampler kernel this context is on

@@ -605,6 +605,72 @@ int carma_pt_boundary_check(carma_ctx* h)
     return reinterpret_cast<Ctx*>(h)->pt->bnd_check;
 }
 
+// ---- debug pair for the deterministic sampler tests (tests/test_gpu_sampler_steps.py) -------------------------------
+// The sampler's variates come from a counter-based generator keyed by (seed, global chain slot, iteration, purpose), so
+// the numbers chain (replica, temperature) WILL use at iteration `iter` can be produced on demand -- by the device, with
+// the very functions the kernels call (the host's libm rounds log / sincos differently in the last place).
+__global__ void k_pt_debug_draws(unsigned seed0, unsigned seed1, unsigned chain, unsigned long long iter, int d, double* out)
+{
+    const RngKey key{seed0, seed1, chain};
+    const int j = threadIdx.x;
+    if (j < d) out[j] = rng_student_t8(key, iter, (uint32_t)j);          // unit proposal (steps.cpp:65-69)
+    if (j == d) out[d] = rng_uniform(key, iter, RNG_ACCEPT, 0);          // Metropolis uniform (steps.cpp:48)
+    if (j == d + 1) out[d + 1] = rng_uniform(key, iter, RNG_SWAP, 0);    // swap uniform of the pair (this, next colder) (steps.hpp:333)
+}
+
+int carma_pt_debug_draws(carma_ctx* h, int replica, int temperature, unsigned long long iter, double* z, double* u_accept,
+                         double* u_swap)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || !z) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    if (replica < 0 || replica >= s->R || temperature < 0 || temperature >= s->T) {
+        set_error("carma_pt_debug_draws: chain (%d, %d) outside %d x %d", replica, temperature, s->R, s->T);
+        return CARMA_EINVAL;
+    }
+    const int d = c->d;
+    hipError_t e = hipSetDevice(c->device);
+    double* dbuf = nullptr;
+    if (e == hipSuccess) e = dev_malloc(&dbuf, sizeof(double) * (d + 2));
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_debug_draws");
+    const unsigned chain = (s->replica0 + (unsigned)replica) * s->T_global + s->slot0 + (unsigned)temperature;
+    hipLaunchKernelGGL(k_pt_debug_draws, dim3(1), dim3(64), 0, c->stream, (unsigned)(s->seed & 0xffffffffu), (unsigned)(s->seed >> 32),
+                       chain, iter, d, dbuf);
+    std::vector<double> hb(d + 2);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(hb.data(), dbuf, sizeof(double) * (d + 2), hipMemcpyDeviceToHost);
+    (void)dev_free(dbuf);
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_debug_draws");
+    std::memcpy(z, hb.data(), sizeof(double) * d);
+    if (u_accept) *u_accept = hb[d];
+    if (u_swap) *u_swap = hb[d + 1];
+    return CARMA_OK;
+}
+
+// the Cholesky factors of the proposal scale matrices, [R][T][d*d] (upper triangular, row-major; AdaptiveMetro::chol_factor_)
+int carma_pt_get_factor(carma_ctx* h, double* chol)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || !chol) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(chol, s->d_chol, sizeof(double) * (size_t)s->T * s->R * c->d * c->d, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_get_factor");
+    return CARMA_OK;
+}
+
+int carma_pt_set_factor(carma_ctx* h, const double* chol)
+{
+    if (!h || !reinterpret_cast<Ctx*>(h)->pt || !chol) return CARMA_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    PtState* s = c->pt;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(s->d_chol, chol, sizeof(double) * (size_t)s->T * s->R * c->d * c->d, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "carma_pt_set_factor");
+    return CARMA_OK;
+}
+
 int carma_pt_sweep(carma_ctx* h)
 {
     if (!h || !reinterpret_cast<Ctx*>(h)->pt || !reinterpret_cast<Ctx*>(h)->pt->started || reinterpret_cast<Ctx*>(h)->pt->iter == 0) {

@@ -298,6 +298,20 @@ int carma_pt_boundary_check(carma_ctx* h);
  * the boundary chains themselves (carma_pack_amd/parallel.py over torch.distributed). */
 int carma_pt_sweep(carma_ctx* h);
 
+/* ---- debug pair: ties the device sampler step to the reference's arithmetic (tests only; no reference counterpart,
+ * the reference's generator is a time-seeded global, src/random.cpp:20) --------------------------------------------
+ * carma_pt_debug_draws: the variates chain (replica, temperature) of this block uses at iteration `iter` (counted as
+ * AdaptiveMetro::niter_, src/steps.cpp:101), computed on the device by the sampler kernels' own functions: z[d] = the
+ * unit proposal (proposal_.Draw, src/steps.cpp:65-69), *u_accept = the Metropolis uniform (src/steps.cpp:48),
+ * *u_swap = the uniform of the exchange between this chain and the next colder one (src/include/steps.hpp:333; keyed
+ * by the warmer chain's global slot).
+ * carma_pt_get_factor / carma_pt_set_factor: chol_factor_ of every chain (src/steps.cpp:32), [R][T][d*d] row-major
+ * upper triangular. */
+int carma_pt_debug_draws(carma_ctx* h, int replica, int temperature, unsigned long long iter, double* z, double* u_accept,
+                         double* u_swap);
+int carma_pt_get_factor(carma_ctx* h, double* chol);
+int carma_pt_set_factor(carma_ctx* h, const double* chol);
+
 #ifdef __cplusplus
 }
 #endif

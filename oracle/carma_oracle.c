@@ -526,6 +526,74 @@ void orc_chol_update_r1(int d, double *L, double *v, int downdate)
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * ONE AdaptiveMetro::DoStep and ONE ExchangeStep::DoStep with the random variates as INPUTS, so that a
+ * sampler with its own generator (the device's counter-based one) can be checked decision by decision
+ * and digit by digit against the reference's arithmetic.
+ *
+ * orc_ram_step: src/steps.cpp:60-107 (DoStep) with Accept :36-56 and CholUpdateR1 :111-131.
+ *   theta[d], *lp (stored log-posterior, Parameter::GetLogDensity), R[d*d] (upper-triangular factor,
+ *   row-major, Sigma = R^T R as arma::chol returns, :32) are updated in place.  z[d] = the unit proposal
+ *   (proposal_.Draw, :65-69), u = the Metropolis uniform (:48; not consumed when alpha is not finite,
+ *   :41-46), temperature = parameter_.GetTemperature(), niter = niter_ BEFORE the step, maxiter = maxiter_.
+ *   Returns 1 when the proposal was accepted; *lnew = LogDensity(new_value).                          */
+int orc_ram_step(const orc_model *m, double *theta, double *lp, double *R, const double *z, double u,
+                 double temperature, long niter, long maxiter, double *work, double *lnew)
+{
+    const int d = (m->p == 1) ? 4 : 3 + m->p + m->q;
+    double scaled[32], newv[32];
+    int accepted = 0;
+    /* scaled_proposal = chol_factor_.t() * unit_proposal ; new_value = old_value + scaled_proposal (:72-73) */
+    for (int j = 0; j < d; j++) {
+        double acc = 0.0;
+        for (int k = 0; k <= j; k++) acc += R[k * d + j] * z[k];
+        scaled[j] = acc;
+        newv[j] = theta[j] + acc;
+    }
+    /* Accept (:36-56) */
+    double l1 = (m->p == 1) ? orc_logdensity_car1(m, newv, work) : orc_logdensity_carma(m, newv, 0, work);
+    double alpha = (l1 - *lp) / temperature;
+    if (!isfinite(alpha)) {
+        alpha = 0.0;                                   /* :41-46: rejected, and alpha_ = 0 stays FINITE */
+    } else {
+        alpha = fmin(exp(alpha), 1.0);
+        if (u < alpha) accepted = 1;
+    }
+    if (accepted) {                                    /* parameter_.Save(new_value) (:77), carpack.hpp:90-108 */
+        memcpy(theta, newv, sizeof(double) * d);
+        *lp = l1;
+    }
+    if (niter < maxiter && isfinite(alpha)) {          /* :82 -- always finite here: a rejected -inf proposal downdates */
+        double step = fmin(1.0, (double)d / pow((double)niter, 2.0 / 3.0));   /* :87, niter_ = 0 -> 1 */
+        double nrm = 0.0;
+        for (int k = 0; k < d; k++) nrm += z[k] * z[k];
+        nrm = sqrt(nrm);                               /* arma::norm(unit_proposal, 2) (:89) */
+        double fac = sqrt(step * fabs(alpha - 0.25)) / nrm;                   /* :92 */
+        for (int k = 0; k < d; k++) scaled[k] *= fac;
+        orc_chol_update_r1(d, R, scaled, alpha < 0.25);                       /* :95-98 */
+    }
+    if (lnew) *lnew = l1;
+    return accepted;
+}
+
+/* orc_exchange: src/include/steps.hpp:318-362.  "this" = the warmer chain i, "other" = chain i-1.
+ * Swaps theta and the stored log-posteriors in place when accepted; returns 1 then.                   */
+int orc_exchange(int d, double *theta_this, double *lp_this, double temp_this, double *theta_other,
+                 double *lp_other, double temp_other, double u)
+{
+    double this_logpost = *lp_this, other_logpost = *lp_other;
+    double alpha = 1.0 / temp_this * (other_logpost - this_logpost) + 1.0 / temp_other * (this_logpost - other_logpost);
+    alpha = fmin(exp(alpha), 1.0);
+    if (!isfinite(alpha)) alpha = 0.0;
+    if (u < alpha) {
+        for (int k = 0; k < d; k++) { double tmp = theta_this[k]; theta_this[k] = theta_other[k]; theta_other[k] = tmp; }
+        *lp_this = other_logpost;                      /* SetLogDensity overrides (:343-350) */
+        *lp_other = this_logpost;
+        return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Prediction (interpolation / forecast / backcast) -- SURVEY.md §8(f) rank 1.
  * src/kfilter.cpp:218-286 KalmanFilterp::Predict with :290-337 InitializeCoefs / UpdateCoefs.
  * y centred, yerr as given.  Returns 0, or -1 on a singular Vandermonde solve.                    */

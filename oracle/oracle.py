@@ -68,6 +68,10 @@ def lib():
         L.orc_truth_filter.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
         L.orc_truth_filter.restype = C.c_int
         L.orc_sampler_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp]
+        L.orc_ram_step.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_long, C.c_long, _dp, _dp]
+        L.orc_ram_step.restype = C.c_int
+        L.orc_exchange.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, _dp, C.c_double, C.c_double]
+        L.orc_exchange.restype = C.c_int
         _lib = L
     return _lib
 
@@ -240,6 +244,25 @@ class OracleModel:
         if self.p == 1:
             return lib().orc_logdensity_car1(self._h, _p(theta), None)
         return lib().orc_logdensity_carma(self._h, _p(theta), int(ignore_prior), None)
+
+    def ram_step(self, theta, lp, R, z, u, temperature, niter, maxiter):
+        """One AdaptiveMetro::DoStep (src/steps.cpp:60-107) with the variates z (t_8 vector) and u (Metropolis uniform) as
+        inputs.  Returns (accepted, theta', lp', R', LogDensity(proposal)); the inputs are not modified."""
+        th, Rm = _a(theta).copy(), _a(R).copy()
+        lpv, lnew = np.array([float(lp)]), np.zeros(1)
+        work = np.empty(4 * self.n)
+        acc = lib().orc_ram_step(self._h, _p(th), _p(lpv), _p(Rm), _p(_a(z)), float(u), float(temperature), int(niter),
+                                 int(maxiter), _p(work), _p(lnew))
+        return bool(acc), th, float(lpv[0]), Rm, float(lnew[0])
+
+    @staticmethod
+    def exchange(theta_this, lp_this, temp_this, theta_other, lp_other, temp_other, u):
+        """One ExchangeStep::DoStep (src/include/steps.hpp:318-362): `this` is the warmer chain.  Returns
+        (swapped, theta_this', lp_this', theta_other', lp_other')."""
+        a, b = _a(theta_this).copy(), _a(theta_other).copy()
+        la, lb = np.array([float(lp_this)]), np.array([float(lp_other)])
+        sw = lib().orc_exchange(a.size, _p(a), _p(la), float(temp_this), _p(b), _p(lb), float(temp_other), float(u))
+        return bool(sw), a, float(la[0]), b, float(lb[0])
 
     def sampler_run(self, ntemps, sample_size, burnin, thin, seed, start):
         """Literal restatement of RunCarmaSampler/RunCar1Sampler (serial hot->cold sweep), own RNG.
