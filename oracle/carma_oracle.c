@@ -535,9 +535,9 @@ void orc_chol_update_r1(int d, double *L, double *v, int downdate)
  *   row-major, Sigma = R^T R as arma::chol returns, :32) are updated in place.  z[d] = the unit proposal
  *   (proposal_.Draw, :65-69), u = the Metropolis uniform (:48; not consumed when alpha is not finite,
  *   :41-46), temperature = parameter_.GetTemperature(), niter = niter_ BEFORE the step, maxiter = maxiter_.
- *   Returns 1 when the proposal was accepted; *lnew = LogDensity(new_value).                          */
+ *   Returns 1 when the proposal was accepted; *lnew = LogDensity(new_value).  lnew_rel_shift: 0 (see below).        */
 int orc_ram_step(const orc_model *m, double *theta, double *lp, double *R, const double *z, double u,
-                 double temperature, long niter, long maxiter, double *work, double *lnew)
+                 double temperature, long niter, long maxiter, double *work, double *lnew, double lnew_rel_shift)
 {
     const int d = (m->p == 1) ? 4 : 3 + m->p + m->q;
     double scaled[32], newv[32];
@@ -551,6 +551,9 @@ int orc_ram_step(const orc_model *m, double *theta, double *lp, double *R, const
     }
     /* Accept (:36-56) */
     double l1 = (m->p == 1) ? orc_logdensity_car1(m, newv, work) : orc_logdensity_carma(m, newv, 0, work);
+    /* (test instrument: the step's sensitivity to the log-density -- how far the factor may move when LogDensity(new_value)
+     * moves by the parity bar; 0 for the reference's step) */
+    if (lnew_rel_shift != 0.0 && isfinite(l1)) l1 += lnew_rel_shift * fabs(l1);
     double alpha = (l1 - *lp) / temperature;
     if (!isfinite(alpha)) {
         alpha = 0.0;                                   /* :41-46: rejected, and alpha_ = 0 stays FINITE */

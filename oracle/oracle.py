@@ -68,7 +68,7 @@ def lib():
         L.orc_truth_filter.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
         L.orc_truth_filter.restype = C.c_int
         L.orc_sampler_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp]
-        L.orc_ram_step.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_long, C.c_long, _dp, _dp]
+        L.orc_ram_step.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_long, C.c_long, _dp, _dp, C.c_double]
         L.orc_ram_step.restype = C.c_int
         L.orc_exchange.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, _dp, C.c_double, C.c_double]
         L.orc_exchange.restype = C.c_int
@@ -245,14 +245,16 @@ class OracleModel:
             return lib().orc_logdensity_car1(self._h, _p(theta), None)
         return lib().orc_logdensity_carma(self._h, _p(theta), int(ignore_prior), None)
 
-    def ram_step(self, theta, lp, R, z, u, temperature, niter, maxiter):
+    def ram_step(self, theta, lp, R, z, u, temperature, niter, maxiter, lnew_rel_shift=0.0):
         """One AdaptiveMetro::DoStep (src/steps.cpp:60-107) with the variates z (t_8 vector) and u (Metropolis uniform) as
-        inputs.  Returns (accepted, theta', lp', R', LogDensity(proposal)); the inputs are not modified."""
+        inputs.  Returns (accepted, theta', lp', R', LogDensity(proposal)); the inputs are not modified.
+        lnew_rel_shift moves LogDensity(proposal) by that fraction of its magnitude: the step's sensitivity to the
+        log-density, for tolerance bands (0 = the reference's step)."""
         th, Rm = _a(theta).copy(), _a(R).copy()
         lpv, lnew = np.array([float(lp)]), np.zeros(1)
         work = np.empty(4 * self.n)
         acc = lib().orc_ram_step(self._h, _p(th), _p(lpv), _p(Rm), _p(_a(z)), float(u), float(temperature), int(niter),
-                                 int(maxiter), _p(work), _p(lnew))
+                                 int(maxiter), _p(work), _p(lnew), float(lnew_rel_shift))
         return bool(acc), th, float(lpv[0]), Rm, float(lnew[0])
 
     @staticmethod

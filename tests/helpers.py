@@ -4,6 +4,22 @@ import numpy as np
 
 from carma_pack_amd.synth import irregular_series, log_quads_from_roots, prior_like_theta, theta_batch  # noqa: F401,E402
 
+# ---- the parity allowances a run CONSUMED ---------------------------------------------------------
+# Every clause below that lets an entry pass on something other than "within 1e-10 of the oracle" records its use here:
+# which clause, in which test, how many entries used it against how many were allowed, and the worst device / oracle
+# distance from the quad-precision value it saw.  tests/conftest.py writes the list to gpurun_out/parity_allowances.json at
+# the end of the session; tools/allowance_table.py prints the table DESIGN.md section 4 carries.
+ALLOWANCES = []
+
+
+def record_allowance(clause, what, used, allowed, population=None, worst_device=None, worst_oracle=None, cond=None):
+    import os
+    ALLOWANCES.append(dict(clause=clause, test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], what=str(what),
+                           used=int(used), allowed=int(allowed), population=None if population is None else int(population),
+                           worst_device=None if worst_device is None else float(worst_device),
+                           worst_oracle=None if worst_oracle is None else float(worst_oracle),
+                           cond=None if cond is None else float(cond)))
+
 
 def loglik_truth(t, y, yerr, theta, p, q):
     """(log-likelihood + log prior, log-likelihood) of the reference's formulas to > 20 digits: the arbiter of the parity
@@ -63,6 +79,7 @@ def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=N
             "%s: %d of %d finite entries differ from the oracle by more than %.0e and would need arbitration "
             "(allowed: %d); worst %.3e" % (what, bad.size, idx.size, rtol, limit, rel.max()))
         print("%s: %d of %d finite entries go to the arbiter (allowed %d)" % (what, bad.size, idx.size, limit))
+        wd, wo, nnoise = 0.0, 0.0, 0
         for i in bad:
             truth = arbiter(int(i))
             eg, eo = abs(got[i] - truth), abs(want[i] - truth)
@@ -73,12 +90,18 @@ def assert_parity(got, want, rtol=1e-10, what="", arbiter=None, max_arbitrated=N
                     what, i, eg / abs(truth), eo / abs(truth), ns))
                 # (twice the largest of 6 p neighbours: a handful of samples underestimates a scale)
                 eo = max(eo, 2.0 * ns * abs(truth) / max(arb_factor, 1e-300))
+                nnoise += 1
+            wd, wo = max(wd, eg / abs(truth)), max(wo, abs(want[i] - truth) / abs(truth))
             assert eg <= max(rtol * abs(truth), arb_factor * eo), (
                 "%s: entry %d differs from the oracle by %.2e and is further from the exact value "
                 "(gpu err %.2e, oracle err %.2e)" % (what, i, abs(got[i] - want[i]) / abs(want[i]),
                                                      eg / abs(truth), eo / abs(truth)))
             print("%s: entry %d arbitrated: gpu err %.2e, oracle err %.2e vs the exact (quad-precision) value" % (
                 what, i, eg / abs(truth), eo / abs(truth)))
+        record_allowance("arbiter (device no further from the exact value than %.2f x the oracle)" % arb_factor, what, bad.size,
+                         limit, idx.size, wd, wo)
+        if nnoise:
+            record_allowance("oracle noise scale (+-3 ulp of theta, doubled)", what, nnoise, limit, idx.size, wd, wo)
         ok = np.ones(rel.size, dtype=bool)
         ok[np.isin(idx, bad)] = False
         return float(rel[ok].max()) if ok.any() else 0.0
@@ -127,14 +150,20 @@ def parity_census(got, want, thetas, p, labels, bounds, arbiter, rtol=1e-10, wha
                   what, cls, bad.size, n, rtol, 100 * frac, 100 * bounds[cls], rel[bad].max() if bad.size else 0.0,
                   np.median(cb) if cb else 0.0, np.median(cr) if cr else 0.0))
         assert frac <= bounds[cls], "%s [%s]: %.2f %% of the entries beyond %.0e (allowed %.2f %%)" % (what, cls, 100 * frac, rtol, 100 * bounds[cls])
+        wd, wo, wratio = 0.0, 0.0, 0.0
         for i in bad:
             truth = arbiter(int(i))
             eg, eo = abs(got[i] - truth), abs(want[i] - truth)
+            wd, wo = max(wd, eg / abs(truth)), max(wo, eo / abs(truth))
+            if eg > rtol * abs(truth):
+                wratio = max(wratio, eg / max(eo, 1e-300))
             assert eg <= max(rtol * abs(truth), arb_factor * eo), (
                 "%s [%s]: entry %d is further from the exact value than the oracle (gpu err %.2e, oracle err %.2e)" % (
                     what, cls, i, eg / abs(truth), eo / abs(truth)))
             print("%s [%s]: entry %d: gpu %.2e, oracle %.2e from the exact value, cond(EigenMat) %.1e" % (
                 what, cls, i, eg / abs(truth), eo / abs(truth), cond_eigenmat(thetas[i], p)))
+        record_allowance("census [%s] (fraction beyond 1e-10 of the oracle; arb_factor %.2f, worst ratio used %.2f)" % (
+            cls, arb_factor, wratio), what, bad.size, int(bounds[cls] * n), n, wd, wo, np.median(cb) if cb else None)
         out[cls] = (bad.size, n)
     return out
 
@@ -164,7 +193,11 @@ def assert_same_evaluation(a, b, thetas, p, what="", rtol=1e-8, cond_min=1e5, ce
         if nm:
             print("%s: %d of %d states differ between the two kernels' chains by more than 1e-10 (rounding, amplified): their "
                   "log-posteriors, up to %.1e apart, are values at different points" % (what, nm, a.size, rel[bad][moved[bad]].max()))
+        record_allowance("states moved apart between two kernels' chains", what, nm, max(2, int(max_moved_frac * a.size)), a.size)
         bad = bad[~moved[bad]]
+    if bad.size:
+        record_allowance("kernel pair beyond %.0e on an ill-conditioned state (cond >= %.0e, ceiling %.0e)" % (rtol, cond_min, ceiling),
+                         what, bad.size, a.size, a.size, rel[bad].max())
     for i in bad:
         c = cond_eigenmat(th[i], p)
         assert c >= cond_min, "%s: a well-conditioned state (cond(EigenMat) %.1e) differs by %.2e between the kernels" % (what, c, rel[i])
@@ -217,6 +250,8 @@ def assert_parity_states(got, want, thetas, p, q, rtol=1e-10, what="", arbiter=N
     if over.any():
         assert over.sum() <= max(2, int(max_overflow_frac * got.size)), "%s: %d of %d states in the overflow region" % (what, over.sum(), got.size)
         print("%s: %d of %d states sit in the overflow region of the reference's MA coefficients: left out" % (what, over.sum(), got.size))
+        record_allowance("overflow region of the reference's MA coefficients (left out)", what, over.sum(),
+                         max(2, int(max_overflow_frac * got.size)), got.size)
         keep = np.flatnonzero(~over)
         return assert_parity_states(got[keep], want[keep], np.asarray(thetas)[keep], p, q, rtol, what,
                                     arbiter=(lambda k: arbiter(int(keep[k]))) if arbiter else None,
@@ -224,6 +259,8 @@ def assert_parity_states(got, want, thetas, p, q, rtol=1e-10, what="", arbiter=N
     diff = np.flatnonzero(np.isfinite(got) != np.isfinite(want))
     assert diff.size <= max(2, int(0.005 * got.size)), "%s: %d entries with a different finite pattern" % (what, diff.size)
     keep = np.ones(got.size, dtype=bool)
+    if diff.size:
+        record_allowance("zero-root band (finite pattern differs)", what, diff.size, max(2, int(0.005 * got.size)), got.size)
     for i in diff:
         assert in_zero_root_band(thetas[i], p, q), "%s: finite pattern differs at %d outside the zero-root band" % (what, i)
         v = got[i] if np.isfinite(got[i]) else want[i]
