@@ -24,6 +24,7 @@
 #include "carma_predict.h"
 #include "carma_simulate.h"
 #include "carma_pipe3l.h"
+#include "carma_pipew.h"
 #include "carma_lane.h"
 #include "carma_launch.h"
 
@@ -153,6 +154,52 @@ __global__ __launch_bounds__(256) void k_logdens_carma_p3l(const double* __restr
     if (live && g.lane() == 0) out[e] = ll;
     CARMA_MARK(4);
     CARMA_MARK_DUMP("mean", 0);
+}
+
+// The windowed wave pipeline (carma_pipew.h, round 5): recursion wave (covariance AND mean, a chunk of 16 - P data per
+// elimination) + set-up wave + two producer waves per 4 evaluations.  13-17 KiB of LDS.
+template <int P>
+__global__ __launch_bounds__(256) void k_logdens_carma_w(const double* __restrict__ theta, int B, int d, int q,
+                                                         const double4* __restrict__ series, int n, Prior pr,
+                                                         int ignore_prior, double* __restrict__ out, int ncu)
+{
+    extern __shared__ double4 smem4[];
+    const int tid = threadIdx.x, lane64 = tid & 63;
+    // which wave plays which part: as k_logdens_carma_p3l (0 recursion, 1 set-up, 2 / 3 producers)
+    const int round = (blockIdx.x >= (unsigned)ncu) + (blockIdx.x >= 2u * (unsigned)ncu);
+    const int wave = ((round == 0 ? 0xE4 : round == 1 ? 0xD2 : 0x36) >> (2 * (tid >> 6))) & 3;
+    Grp<16> g{nullptr, lane64, nullptr};
+    double2* ring = reinterpret_cast<double2*>(smem4);
+    long e = ((long)blockIdx.x * 64 + lane64) / 16;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    using Geo = PipeWGeom<P>;
+    math_tab_fill(reinterpret_cast<double*>(ring + Geo::TAB_OFF));      // (visible to the producers behind the first barrier)
+    if (wave >= 2) {
+        pipew_produce<P>(g, wave - 2, theta + e * d, series, n, ring, [](int) {});
+        return;
+    }
+    Model<P> m;
+    if (wave == 1) {
+        // prior bounds and log prior (carpack.hpp:118-126, 178-191; carpack.cpp:314-374), handed over through LDS; then this
+        // wave is the third producer
+        model_from_theta<P, 16, MODEL_FLAGS>(g, theta + e * d, q, pr, ignore_prior, m);
+        const double lpri = log_prior(m.scale, pr.measerr_dof);
+        if ((lane64 & 15) == 0) ring[Geo::OUT_OFF + (lane64 >> 4)] = make_double2(lpri, m.valid ? 1.0 : 0.0);
+        pipew_produce<P>(g, 2, theta + e * d, series, n, ring, [](int) {});
+        return;
+    }
+    model_from_theta<P, 16, MODEL_CONSTS>(g, theta + e * d, q, pr, ignore_prior, m);
+    FilterConsts<P> fc;
+    filter_reset<P, 16>(g, m, fc);
+    RowConsts<P> rc;
+    row_consts<P>(g, m, fc, rc);
+    double ll = pipew_recur<P>(g, rc, ring);
+    const double2 o = ring[Geo::OUT_OFF + (lane64 >> 4)];
+    ll += o.x;
+    const double ninf = -1.0 / 0.0;
+    if (m.sing || o.y == 0.0) ll = ninf;
+    if (live && g.lane() == 0) out[e] = ll;
 }
 
 // Throughput regime proper (tens of thousands of evaluations): ONE EVALUATION PER LANE (carma_lane.h) -- nothing crosses
@@ -522,7 +569,17 @@ static long p3l_max_rows()
 }
 
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
-enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC };
+enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC, WIN };
+// Largest launch (in workgroups of four evaluations) that takes the windowed wave pipeline (carma_pipew.h).
+// CARMA_TUNE_WIN_ROWS overrides (0 disables it); read once.
+static long win_max_rows()
+{
+    static const long tune = [] {
+        const char* e = getenv("CARMA_TUNE_WIN_ROWS");
+        return e ? atol(e) : -1L;
+    }();
+    return tune >= 0 ? tune : 0L;
+}
 // smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
 static long lane_min_evals(int p = 5)
 {
@@ -593,6 +650,7 @@ static LdShape logdens_shape(long B, int n)
     constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
+    if (rows <= win_max_rows() && n >= 8) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
     if (B > lpc_min_evals<P>() && B <= lpc_max_evals<P>() && n >= 8) return LdShape::LPC;
     if (B >= lane_min_evals(P)) return LdShape::LANE;
@@ -627,6 +685,10 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             // (carma_pipe3l.h); 42 KiB of LDS: up to three workgroups per CU
             hipLaunchKernelGGL((k_logdens_carma_p3l<P>), dim3((unsigned)rows), dim3(256), Pipe3LGeom<P>::BYTES, st, theta, B, d, q,
                                series, n + p3l_pad(n), pr, ignore_prior, out, device_cus(), p3l_pad(n));
+            return hipGetLastError();
+        case LdShape::WIN:
+            hipLaunchKernelGGL((k_logdens_carma_w<P>), dim3((unsigned)rows), dim3(256), PipeWGeom<P>::BYTES, st, theta, B, d, q,
+                               series, n, pr, ignore_prior, out, device_cus());
             return hipGetLastError();
         case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);
         case LdShape::PC2: return launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);
@@ -678,6 +740,7 @@ static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
     const char* dtc = repeated_dt ? ",true" : "";
     constexpr int G = GroupOf<P>::value;
     switch (logdens_shape<P>(B, n)) {
+        case LdShape::WIN: return snprintf(buf, len, "k_logdens_carma_w<%d>", P);
         case LdShape::P3L: return snprintf(buf, len, "k_logdens_carma_p3l<%d>", P);
         case LdShape::PC1: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,1>", P, G);
         case LdShape::PC2: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,2>", P, G);

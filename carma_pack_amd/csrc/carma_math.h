@@ -230,7 +230,9 @@ CARMA_DEV double exp_neg_tab(double x, const double* tab)
 // phases the table form reduces itself: |n| < 2^20 keeps n PI_32_1 and n PI_32_2 exact
 constexpr double CEXP_TAB_MAXPHASE = 98304.0;
 
-template <bool CHECK>
+// EXACT: the rounding of the products a dt and b dt is recovered with an FMA and added to the reduced arguments (as in
+// cexp_step_impl): the phase then stays good to 1e-16 rad at any |b dt| the reduction accepts.
+template <bool CHECK, bool EXACT = false>
 CARMA_DEV void cexp_step_tab_impl(double a, double b, double dt, double* re, double* im, const double* tab)
 {
     const double x = a * dt;
@@ -238,7 +240,13 @@ CARMA_DEV void cexp_step_tab_impl(double a, double b, double dt, double* re, dou
     if (CHECK && !(fabs(ph) < CEXP_TAB_MAXPHASE)) {
         // rare: library reduction for huge phases (NaN also lands here)
         const double e = exp_neg_tab(x, tab);
-        const SinCos sc = sincos_slow(ph);
+        SinCos sc = sincos_slow(ph);
+        if constexpr (EXACT) {
+            const double pl = fma3(b, dt, -ph);
+            const double c0 = sc.c, s0 = sc.s;
+            sc.c = fma3(-s0, pl, c0);
+            sc.s = fma3(c0, pl, s0);
+        }
         *re = e * sc.c;
         *im = e * sc.s;
         return;
@@ -250,6 +258,10 @@ CARMA_DEV void cexp_step_tab_impl(double a, double b, double dt, double* re, dou
     r = fma3(-n1, LN2_32_LO, r);
     t = fma3(-n2, PI_32_2, t);
     t = fma3(-n2, PI_32_3, t);
+    if constexpr (EXACT) {
+        r += fma3(a, dt, -x);
+        t += fma3(b, dt, -ph);
+    }
     const int i1 = (int)fmin(fmax(n1, -70400.0), 70400.0);
     const int i2 = (int)n2;
     const double e0 = tab[i1 & 31];
@@ -283,16 +295,15 @@ CARMA_DEV void cexp_step_tab_impl(double a, double b, double dt, double* re, dou
 template <bool EXACT = false>
 CARMA_DEV void cexp_step_tab(double a, double b, double dt, double* re, double* im, const double* tab)
 {
-    static_assert(!EXACT, "the table form has no residual-recovery variant");
 #if defined(__HIP_DEVICE_COMPILE__)
     const bool slow = !(fabs(b * dt) < CEXP_TAB_MAXPHASE);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {     // once per wave: see cexp_step
-        cexp_step_tab_impl<true>(a, b, dt, re, im, tab);
+        cexp_step_tab_impl<true, EXACT>(a, b, dt, re, im, tab);
         return;
     }
-    cexp_step_tab_impl<false>(a, b, dt, re, im, tab);
+    cexp_step_tab_impl<false, EXACT>(a, b, dt, re, im, tab);
 #else
-    cexp_step_tab_impl<true>(a, b, dt, re, im, tab);
+    cexp_step_tab_impl<true, EXACT>(a, b, dt, re, im, tab);
 #endif
 }
 

@@ -1,0 +1,379 @@
+// carma_pipew.h -- the WINDOWED wave pipeline (round 5, gfx950 only): the co-rotating-frame recursion of carma_pipe3l.h
+// applied a CHUNK of data at a time instead of one datum at a time -- a chunk is one symmetric elimination (LDL^T of the
+// chunk's predictive covariance; numpy prototype tests/tools/proto/blocked_window.py, loglik_window) -- and with the mean
+// recursion riding in the same instructions, so that there is no mean wave and no link ring.
+//
+// One evaluation per 16-lane DPP row, four per workgroup.  In the recursion wave the lanes of a row are
+//     lanes 0 .. ND-1 (ND = 16 - P)   the data of the chunk:  hh[r] = h~_r, kk[r] = would-be gain (S h~ + c~)_r,
+//                                     m = would-be variance, nu = would-be innovation            (kfilter.cpp:191, 209-213)
+//     lanes ND .. 15                  the P columns of S ("virtual data": hh = e_s, kk[r] = S_rs, nu = -z~_s)
+// and pivot j (the datum in lane j, its m and nu now final: var_j, innov_j) does, in every later lane,
+//     G = kk@j . hh ;  t = -G / m@j ;  m += G t ;  kk += kk@j t ;  nu += nu@j t                  (x@j: DPP row broadcast)
+// which for a data lane is the elimination step of the chunk's covariance and for a virtual lane IS the rank-1 downdate
+// of its column of S (kfilter.cpp:197) and the update of z~_s (kfilter.cpp:194): S and z~ never leave the lanes.  The next
+// chunk starts from  kk' = c~' + sum_s kk@v_s hh'_s ,  nu' = (y' - mu) + sum_s nu@v_s hh'_s ,  m' = scale yerr'^2 + hh'.kk'
+// (s0 = h~.c~ comes in through c~).  19 + 2 P instructions per datum for covariance AND mean (the one-datum pass of
+// carma_pipe3l.h: 30 for the covariance alone); measured in isolation 145-153 cycles per datum at P = 5 against 198
+// (tools/ubench/gen_ub11.py, profiles/r05/ub11_window_v1.txt).
+//
+// Frame and re-base as in carma_pipe3l.h (dyadic time grid per evaluation, frame half a window ahead, coordinates
+// rescaled by exact powers of two), with one difference: a chunk ENDS in front of a re-base datum, so a re-base is always
+// the first thing of a chunk (S <- A S A^T, z~ <- A z~ on the virtual lanes, then the start above).  Every evaluation
+// has its own chunk schedule -- a row whose next datum is a re-base datum completes its chunk with NEUTRAL slots
+// (h~ = c~ = 0, variance 1, innovation 0: the state does not move, the sums get exactly 0) -- so an evaluation's result
+// does not depend on its neighbours in the workgroup; the workgroup runs until its slowest row is through.
+//
+//   waves P0, P1 (producers)   per chunk and row: schedule, exp / sincos, entries {h~_r, c~_r}, {scale yerr^2, y - mu}
+//   wave A (recursion)         [re-base]; start of the chunk; ND pivots; log-likelihood terms of the chunk
+//   wave B (set-up)            prior bounds and log prior, then it ends
+// One __syncthreads() per chunk: after barrier c chunk c is in ring buffer c % 2.  The recursion wave loads chunk c + 1
+// into registers while it eliminates chunk c.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "carma_core.h"
+#include "grp_device.h"
+#include "carma_pipe3l.h"
+#include "carma_win_asm.h"
+
+namespace carma {
+
+template <int P>
+struct PipeWGeom {
+    static constexpr int ND = 16 - P;                         // data lanes of a row
+    static constexpr int NB = 2;                              // ring buffers
+    static constexpr int ENT = P + 1;                         // double2 per lane: {h~_r, c~_r}, r < P; {scale yerr^2, y - mu}
+    static constexpr int RING_OFF = 0;                        // double2[NB][ENT][64]
+    static constexpr int ROT_OFF = NB * ENT * 64;             // double2[NB][P][4]: (c_r, s_r) of the re-base rotation, per row
+    static constexpr int HDR_OFF = ROT_OFF + NB * P * 4;      // u64[NB]: bits 0-3 rows that re-base, bit 8 last chunk
+    static constexpr int CONST_OFF = HDR_OFF + NB;            // double2 {h_r, c_r}[64]
+    static constexpr int OUT_OFF = CONST_OFF + 64;            // double2 {log prior, valid}[4] from the set-up wave
+    static constexpr int TAB_OFF = OUT_OFF + 4;               // double[MATH_TAB_N]: tables of the short exp / sincos (carma_math.h)
+    static constexpr int ENTRIES = TAB_OFF + MATH_TAB_N / 2;
+    static constexpr int NPROD = 3;                           // producer waves: P0, P1 and the set-up wave once it is through
+    static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(double2);
+    static constexpr double LIM_RE = Pipe3LGeom<P>::LIM_RE, LIM_IM = Pipe3LGeom<P>::LIM_IM;
+};
+
+// producer waves (pw = 0 .. NPROD - 1).  `tail(pw)` runs once all chunks are produced (the sampler kernel draws there).
+template <int P, class Tail>
+__device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
+                                              const double4* __restrict__ series, int n, double2* __restrict__ ring, Tail&& tail)
+{
+    using Geo = PipeWGeom<P>;
+    constexpr int ND = Geo::ND, NB = Geo::NB, ENT = Geo::ENT;
+    if (CARMA_PRIO_P != 0) __builtin_amdgcn_s_setprio(CARMA_PRIO_P);
+    // a lane works on a conjugate PAIR of roots (jr, jr + 1) of one slot: both share |E|, cos and sin
+    constexpr int NPAIR = (P + 1) / 2, PPL = 16 / NPAIR;
+    constexpr int NPROD = Geo::NPROD;
+    constexpr int NIT = (ND + 1 + NPROD * PPL - 1) / (NPROD * PPL);   // slot ND is the re-base rotation
+    const double* tab = reinterpret_cast<const double*>(ring + Geo::TAB_OFF);
+    const int lane = g.lane64, l = lane & 15, rowb = lane & ~15, q = lane >> 4;
+    const int sub = l / NPAIR, jr = 2 * (l - sub * NPAIR);
+    const bool worker = sub < PPL, two = jr + 1 < P;
+    const Cx w = own_ar_root<P>(theta, jr);
+    const Cx w1 = two ? own_ar_root<P>(theta, jr + 1) : w;
+    int esig = 0;                                             // binary exponent of sigma_y (rescaling, carma_pipe3l.h)
+    {
+        const double sg = fabs(theta[0]);
+        (void)frexp(sg, &esig);
+        if (!(sg > 0.0 && sg < 1.0 / 0.0)) esig = 0;
+    }
+    const double mu = theta[2], scale = theta[1];
+    const bool realpair = two && w.im == 0.0;
+    // the virtual lanes' entries never change: hh = e_s, c~ = 0, {1, 0} in the data slot
+    if (pw == 0 && l >= ND) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int r = 0; r < P; r++) ring[Geo::RING_OFF + (b * ENT + r) * 64 + lane] = make_double2(r == l - ND ? 1.0 : 0.0, 0.0);
+            ring[Geo::RING_OFF + (b * ENT + P) * 64 + lane] = make_double2(1.0, 0.0);
+        }
+    }
+    // grid of this evaluation's re-base schedule (carma_pipe3l.h): cells of width 2^-ex
+    double wl = fmax(fmax(fabs(w.re), fabs(w1.re)) * (1.0 / Geo::LIM_RE), fabs(w.im) * (1.0 / Geo::LIM_IM));
+    wl = (wl < 1e12) ? wl : ((wl == wl && wl < 1.0 / 0.0) ? 1e12 : 0.0);
+    wl = Grp<16>::max(wl);
+    int wex;
+    (void)frexp(wl, &wex);
+    const double sc = wl > 0.0 ? ldexp(1.0, wex) : 0.0;
+    const double halfw = sc > 0.0 ? 0.5 / sc : 0.0;
+    const double rg0 = exp_neg(w.re * halfw), g0 = recip(rg0);
+    double rg1 = rg0, g1 = g0;
+    if (realpair) {
+        rg1 = exp_neg(w1.re * halfw);
+        g1 = recip(rg1);
+    }
+    // schedule state of this row (row-uniform)
+    int j0 = 0;
+    double base = series[0].w, t_before = base;
+    // The chunk schedule is data dependent (a chunk ends in front of a re-base datum), so the records of a chunk cannot be
+    // requested by index a chunk ahead as in carma_pipe3l.h -- and a global load at the head of every chunk would put an L2
+    // round trip on every chunk (measured: 45 us per launch instead of 22).  So each row keeps a WINDOW of 64 records in
+    // registers, lane l holding records jw + l, jw + 16 + l, jw + 32 + l, jw + 48 + l; a chunk's sixteen records lie in the
+    // first two and are fetched from their lanes (ds_bpermute); when the row has moved past the first sixteen the window
+    // shifts and the next sixteen are requested, two shifts before they are needed.
+    int jw = 0;
+    auto recat = [series, n](int j) { return series[j < n ? j : n - 1]; };
+    double4 rw0 = recat(l), rw1 = recat(16 + l), rw2 = recat(32 + l), rw3 = recat(48 + l);
+    __syncthreads();                                          // the recursion wave has published (h_r, c_r)
+    double2 hc_own, hc_par;
+    {
+        const double2* cst = ring + Geo::CONST_OFF + rowb;
+        hc_own = cst[jr];
+        hc_par = cst[jr + 1 < 16 ? jr + 1 : 15];
+        // every coordinate rescaled by an exact power of two so that |h_r| ~ sigma_y (carma_pipe3l.h)
+        const double m0 = fmax(fabs(hc_own.x), realpair ? 0.0 : fabs(hc_par.x)), m1 = realpair ? fabs(hc_par.x) : m0;
+        int e0, e1x;
+        (void)frexp(m0, &e0);
+        (void)frexp(m1, &e1x);
+        if (!(m0 > 0.0 && m0 < 1.0 / 0.0)) e0 = 0;
+        if (!(m1 > 0.0 && m1 < 1.0 / 0.0)) e1x = 0;
+        hc_own = make_double2(ldexp(hc_own.x, esig - e0), ldexp(hc_own.y, e0 - esig));
+        hc_par = make_double2(ldexp(hc_par.x, esig - e1x), ldexp(hc_par.y, e1x - esig));
+    }
+#if defined(CARMA_WIN_STAMPS)
+    unsigned long long ps_work = 0, ps_wait = 0, ps_t0 = 0, ps_t1 = 0;
+    int ps_n = 0;
+#define WIN_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#endif
+    for (int c = 0;; c++) {
+        const int b = c % NB;
+#if defined(CARMA_WIN_STAMPS)
+        WIN_STAMP(ps_t0);
+#endif
+        // --- schedule of this row's chunk: lane s looks at datum j0 + s
+        const int jl = j0 + l;
+        double4 rec;
+        {
+            const int pos = jl - jw, src = rowb + (pos & 15);
+            const bool hi = pos >= 16;
+            // (both fetches by every lane: a ds_bpermute under a divergent branch would read inactive lanes)
+            const double y0 = __shfl(rw0.y, src, 64), y1 = __shfl(rw1.y, src, 64);
+            const double z0 = __shfl(rw0.z, src, 64), z1 = __shfl(rw1.z, src, 64);
+            const double w0 = __shfl(rw0.w, src, 64), w1_ = __shfl(rw1.w, src, 64);
+            rec.x = 0.0;
+            rec.y = hi ? y1 : y0;
+            rec.z = hi ? z1 : z0;
+            rec.w = hi ? w1_ : w0;
+        }
+        const double tj = rec.w;
+        const double tprev = dpp_mov_old<0x111>(t_before, tj);                // row_shr:1, lane 0 <- the datum before the chunk
+        const bool fl = jl > 0 && jl < n && floor(tj * sc) != floor(tprev * sc);
+        const unsigned long long flb = __ballot(fl);
+        const unsigned rowbits = (unsigned)(flb >> (16 * q)) & 0xffffu;
+        const bool rot = rowbits & 1u;                                        // the chunk opens with a re-base datum
+        const unsigned cut = (rowbits >> 1) & ((1u << (ND - 1)) - 1u);        // a re-base datum further on ends the chunk
+        int len = cut ? __builtin_ctz(cut) + 1 : ND;
+        const int left = n - j0;
+        len = len < left ? len : (left > 0 ? left : 0);
+        const double t0 = __shfl(tj, rowb, 64);
+        const double base_old = base;
+        base = rot ? t0 : base;
+        // (the difference of two time stamps is exact unless the base is much the smaller of the two: carma_pipe3l.h)
+        const double dta_l = tj - base;
+        const bool row_done = j0 + len >= n;
+        const bool last = __ballot(!row_done) == 0ull;
+        if (pw == 0) {
+            const unsigned long long rb = __ballot(rot);
+            if (lane == 0)
+                reinterpret_cast<unsigned long long*>(ring + Geo::HDR_OFF)[b] =
+                    ((rb & 1ull) | ((rb >> 15) & 2ull) | ((rb >> 30) & 4ull) | ((rb >> 45) & 8ull)) | (last ? 256ull : 0ull);
+            if (l < ND)
+                ring[Geo::RING_OFF + (b * ENT + P) * 64 + lane] = l < len ? make_double2(rec.z * scale, rec.y - mu) : make_double2(1.0, 0.0);
+        }
+        // --- entries
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int slot = it * NPROD * PPL + pw * PPL + sub;
+            const bool is_rot = slot == ND;
+            const double dts = __shfl(dta_l, rowb + (slot < ND ? slot : 0), 64);
+            const double dt = is_rot ? t0 - base_old : dts;
+            const bool live = worker && (is_rot ? rot : slot < len);
+            double ec = 1.0, es = 0.0, e1 = 1.0;
+            if (live) cexp_step_tab<true>(w.re, w.im, dt, &ec, &es, tab);
+            e1 = ec;
+            if (realpair && live) e1 = exp_neg_tab(w1.re * dt, tab);
+            if (worker && slot < ND) {
+                // h~_r = (A^T h)_r = E (cos h_r + sin h_partner) ;  c~_r = (A^-1 c)_r = (cos c_r + sin c_partner) / E
+                const double gc = ec * g0, gs = es * g0;
+                const double inv = recip(fma(gc, gc, gs * gs));
+                const double ht = fma(gc, hc_own.x, gs * hc_par.x);
+                const double ct = fma(gc, hc_own.y, gs * hc_par.y) * inv;
+                double2* dst = ring + Geo::RING_OFF + (b * ENT + jr) * 64 + rowb + slot;
+                dst[0] = live ? make_double2(ht, ct) : make_double2(0.0, 0.0);
+                if (two) {
+                    const double gc1 = e1 * g1, gs1 = es * g1;
+                    const double inv1 = realpair ? recip(gc1 * gc1) : inv;
+                    const double hp = fma(gc1, hc_par.x, -gs1 * hc_own.x);
+                    const double cp = fma(gc1, hc_par.y, -gs1 * hc_own.y) * inv1;
+                    dst[64] = live ? make_double2(hp, cp) : make_double2(0.0, 0.0);
+                }
+            }
+            if (worker && is_rot) {                           // rotation over the closing window (identity when there is none)
+                double2* dst = ring + Geo::ROT_OFF + (b * P + jr) * 4 + q;
+                dst[0] = make_double2(ec, es);
+                if (two) dst[4] = make_double2(e1, -es);
+            }
+        }
+        if (len > 0) t_before = __shfl(tj, rowb + len - 1, 64);
+        j0 += len;
+        if (j0 - jw >= 16) {                                  // (at most one shift per chunk: len < 16)
+            rw0 = rw1;
+            rw1 = rw2;
+            rw2 = rw3;
+            jw += 16;
+            rw3 = recat(jw + 48 + l);
+        }
+#if defined(CARMA_WIN_STAMPS)
+        WIN_STAMP(ps_t1);
+        ps_work += ps_t1 - ps_t0;
+#endif
+        __syncthreads();                                      // barrier c: chunk c is in the ring
+#if defined(CARMA_WIN_STAMPS)
+        WIN_STAMP(ps_t0);
+        ps_wait += ps_t0 - ps_t1;
+        ps_n++;
+#endif
+        if (last) break;
+    }
+#if defined(CARMA_WIN_STAMPS)
+    if (blockIdx.x == 0 && lane == 0)
+        printf("window pipeline, producer %d: %d chunks, per chunk %llu cycles of work, %llu at the barrier\n", pw, ps_n,
+               ps_work / (unsigned long long)ps_n, ps_wait / (unsigned long long)ps_n);
+#endif
+    tail(pw);
+    __syncthreads();                                          // the recursion wave's barrier in front of its last chunk
+}
+
+// wave A.  Returns the log-likelihood of the row's evaluation (row-uniform).
+template <int P>
+__device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<P>& rc, double2* __restrict__ ring)
+{
+    using Geo = PipeWGeom<P>;
+    using WA = WinAsm<P>;
+    constexpr int ND = Geo::ND, NB = Geo::NB, ENT = Geo::ENT;
+    const int lane = g.lane64, l = lane & 15, q = lane >> 4;
+    __builtin_amdgcn_s_setprio(CARMA_PRIO_A);
+    const bool act = l < P;
+    ring[Geo::CONST_OFF + lane] = make_double2(act ? rc.h_own : 0.0, act ? rc.c_own : 0.0);
+    __syncthreads();                                          // the producers take the constants from here
+    double kk[P], hh[P], kn[P], hn[P];
+#pragma unroll
+    for (int r = 0; r < P; r++) kk[r] = hh[r] = 0.0;
+    double mA = 1.0, mB = 1.0, nuA = 0.0, nuB = 0.0;
+    LogLikAcc acc;
+    acc.init();
+    const bool data = l < ND, evn = (l & 1) == 0;
+    double2 en[ENT];
+    unsigned long long hdr = 0;
+    auto load = [&](int b, double2(&e)[ENT], unsigned long long& h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < ENT; r++) e[r] = ring[Geo::RING_OFF + (b * ENT + r) * 64 + lane];
+        h = reinterpret_cast<const unsigned long long*>(ring + Geo::HDR_OFF)[b];
+    };
+    // start of a chunk from the columns of S in the virtual lanes (all zero in front of the first chunk)
+    auto start = [&](int b) __attribute__((always_inline)) {
+        double nuF = (ND & 1) ? nuB : nuA;                    // virtual lanes: what the last pivot wrote
+        if (__builtin_expect((hdr & 0xfull) != 0ull, 0)) {
+            // re-base: S <- A S A^T, z~ <- A z~ with the rotation accumulated over the closing window (kfilter.cpp:200-204
+            // for the whole window); a row without a re-base of its own gets the identity
+            double cr[P], sr[P];
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                const double2 v = ring[Geo::ROT_OFF + (b * P + r) * 4 + q];
+                cr[r] = v.x;
+                sr[r] = v.y;
+            }
+            const int s = l - ND;
+            double cs_own = 1.0, ss_own = 0.0;
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                cs_own = s == r ? cr[r] : cs_own;
+                ss_own = s == r ? sr[r] : ss_own;
+            }
+            const int sp = s ^ 1;
+            const bool paired = s >= 0 && sp < P;
+            if (!paired) ss_own = 0.0;
+            const int plane = paired ? lane - s + sp : lane;
+            double tmp[P];
+#pragma unroll
+            for (int r = 0; r < P; r++) tmp[r] = cs_own * kk[r] - ss_own * __shfl(kk[r], plane, 64);      // S A^T
+            nuF = cs_own * nuF - ss_own * __shfl(nuF, plane, 64);
+#pragma unroll
+            for (int r = 0; r < P; r++) {                     // A (S A^T)
+                const int rp = (r ^ 1) < P ? (r ^ 1) : r;     // (an odd order's last root is real: s_r = 0)
+                kk[r] = cr[r] * tmp[r] - ((r ^ 1) < P ? sr[r] : 0.0) * tmp[rp];
+            }
+        }
+        double nun = en[P].y, mn = en[P].x;
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            hn[r] = en[r].x;
+            kn[r] = en[r].y;
+        }
+        WA::init(kn, nun, mn, kk, nuF, hn);
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            kk[r] = kn[r];
+            hh[r] = hn[r];
+        }
+        mA = mB = mn;
+        nuA = nuB = nun;
+    };
+    __syncthreads();                                          // barrier 0
+    load(0, en, hdr);
+    start(0);
+#if defined(CARMA_WIN_STAMPS)
+    unsigned long long rs_bar = 0, rs_piv = 0, rs_fin = 0, rs_t0 = 0, rs_t1 = 0, rs_t2 = 0, rs_t3 = 0;
+    int rs_n = 0;
+#endif
+    for (int c = 0;; c++) {
+        const bool last = (hdr & 256ull) != 0ull;
+#if defined(CARMA_WIN_STAMPS)
+        WIN_STAMP(rs_t0);
+#endif
+        __syncthreads();                                      // barrier c + 1: chunk c + 1 is in the ring
+#if defined(CARMA_WIN_STAMPS)
+        WIN_STAMP(rs_t1);
+#endif
+        double2 en2[ENT];
+        unsigned long long hdr2 = 0;
+        if (!last) load((c + 1) % NB, en2, hdr2);
+        __builtin_amdgcn_sched_barrier(0);                    // requested HERE, a chunk ahead
+        WA::chunk(kk, hh, mA, mB, nuA, nuB);
+#if defined(CARMA_WIN_STAMPS)
+        __builtin_amdgcn_sched_barrier(0);
+        WIN_STAMP(rs_t2);
+#endif
+        // log-likelihood terms of the chunk (carpack.hpp:167-171): a data lane's variance and innovation are in the register its
+        // own pivot read
+        {
+            const double varF = data ? (evn ? mA : mB) : 1.0, innF = data ? (evn ? nuA : nuB) : 0.0;
+            acc.add_var(varF);
+            acc.chi2 += innF * (recip(varF) * innF);
+        }
+        if (last) break;
+#pragma unroll
+        for (int r = 0; r < ENT; r++) en[r] = en2[r];
+        hdr = hdr2;
+        start((c + 1) % NB);
+#if defined(CARMA_WIN_STAMPS)
+        __builtin_amdgcn_sched_barrier(0);
+        WIN_STAMP(rs_t3);
+        rs_bar += rs_t1 - rs_t0;
+        rs_piv += rs_t2 - rs_t1;
+        rs_fin += rs_t3 - rs_t2;
+        rs_n++;
+#endif
+    }
+#if defined(CARMA_WIN_STAMPS)
+    if (blockIdx.x == 0 && lane == 0)
+        printf("window pipeline, recursion wave: %d chunks, per chunk %llu cycles at the barrier, %llu loads + pivots, %llu terms + start of the next\n",
+               rs_n, rs_bar / (unsigned long long)(rs_n ? rs_n : 1), rs_piv / (unsigned long long)(rs_n ? rs_n : 1),
+               rs_fin / (unsigned long long)(rs_n ? rs_n : 1));
+#endif
+    return Grp<16>::sum(acc.total());
+}
+
+}  // namespace carma

@@ -1,0 +1,71 @@
+"""The windowed wave pipeline (carma_pipew.h, k_logdens_carma_w<P>; opt-in through CARMA_TUNE_WIN_ROWS -- round 5's blocked form
+of kfilter.cpp:189-215, measured and NOT made the default: profiles/r05/window_pipeline_v1.txt) against the oracle, so that the
+path stays correct while it waits for a cheaper producer: every order, posterior-like and prior-like parameters (re-base data
+open chunks, rows of a workgroup end at different chunk counts), a series long enough for hundreds of chunks, the prior's -inf
+pattern.  The tuning variable is read once per process, hence the child process."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import carma_pack_amd as cpa
+d = np.load(sys.argv[1])
+ctx = cpa.Context(d["t"], d["y"], d["e"], int(d["p"]), int(d["q"]), max_stdev=float(d["ms"]))
+th = d["th"]
+out = ctx.logdensity(th, ignore_prior=bool(d["ip"]))
+np.save(sys.argv[1] + ".out.npy", out)
+print(json.dumps(dict(name=ctx.kernel_name(th.shape[0]))))
+'''
+
+
+def _window(t, y, e, p, q, ms, th, ignore_prior):
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "in.npz")
+        np.savez(f, t=t, y=y, e=e, p=p, q=q, ms=ms, th=th, ip=ignore_prior)
+        r = subprocess.run([sys.executable, "-c", CHILD % ROOT, f], env=dict(os.environ, CARMA_TUNE_WIN_ROWS="4096"),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert json.loads(r.stdout.strip().splitlines()[-1])["name"] == "k_logdens_carma_w<%d>" % p
+        return np.load(f + ".out.npy")
+
+
+@pytest.mark.parametrize("p,q", [(2, 1), (3, 0), (4, 3), (5, 3), (6, 2), (7, 6)])
+def test_window_pipeline_vs_oracle(golden_dir, p, q):
+    from helpers import assert_parity, loglik_truth, prior_like_theta, theta_batch
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    t, y, e = g["t"], g["y"], g["yerr"]
+    ms = 10.0 * y.std()
+    rng = np.random.default_rng(500 + 10 * p + q)
+    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(101)])
+    if (p, q) == (5, 3):
+        th = np.concatenate([th, theta_batch(rng, 64, p, q, t, y, theta_center=g["theta"][0], frac_post=1.0)])
+    m = orc.OracleModel(t, y, e, p, q, max_stdev=ms)
+    for ip in (True, False):
+        got = _window(t, y, e, p, q, ms, th, ip)
+        assert_parity(got, m.logdensity_batch(th, ignore_prior=ip), 1e-10, "window pipeline (%d,%d) ignore_prior=%d" % (p, q, ip),
+                      arbiter=lambda k: loglik_truth(t, y, e, th[k], p, q)[0] if not ip else
+                      loglik_truth(t, y, e, th[k], p, q)[0], arb_factor=1.25, max_arb_frac=0.04)
+
+
+def test_window_pipeline_long_series():
+    from helpers import assert_parity, irregular_series, loglik_truth, prior_like_theta
+    t, y, e = irregular_series(3000, seed=12)
+    ms = 10.0 * y.std()
+    rng = np.random.default_rng(8)
+    th = np.array([prior_like_theta(rng, 5, 2, t, y) for _ in range(37)])
+    m = orc.OracleModel(t, y, e, 5, 2, max_stdev=ms)
+    got = _window(t, y, e, 5, 2, ms, th, True)
+    assert_parity(got, m.logdensity_batch(th, ignore_prior=True), 1e-10, "window pipeline, n = 3000",
+                  arbiter=lambda k: loglik_truth(t, y, e, th[k], 5, 2)[0], arb_factor=1.25, max_arb_frac=0.06)
