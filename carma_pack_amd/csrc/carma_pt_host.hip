@@ -366,7 +366,10 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
         // launch cuts the series across a wave (k_logdens_car1_scan: 8 us for 1024 chains) -- 18.6 against 43.8 us per iteration
         // at 16 x 64, 24.8 against 44.1 at 16 x 256, 59.7 against 73.9 at 16 x 2048; only where the parallel-in-time launch has
         // just run out of waves (48 ... 64 x #CUs chains) the ladder kernel is ahead, 46.9 against 51.4 (car1_sampler_v1.txt)
-        if (c->p == 1) pays = !((long)nchain > 48 * cus && (long)nchain <= 64 * cus);
+        // (evidence: n = 270, ensembles from 16 x 64.  Below 64 data the batched launch has no parallel-in-time scan -- one
+        // evaluation per lane, launch_logdens_car1 -- and a small ladder such as run_mcmc_car1's default ~10 chains would pay 2-3
+        // launches per iteration with nothing parallel to hide them: those keep the persistent k_pt.)
+        if (c->p == 1) pays = c->n >= 64 && (long)nchain >= 64 && !((long)nchain > 48 * cus && (long)nchain <= 64 * cus);
         if (c->p == 2) pays = pays || (long)nchain > 12 * cus;
         if (c->p == 3 || c->p == 4) pays = pays || (long)nchain > 16 * cus;
         if (tv) pays = (long)nchain >= atol(tv);

@@ -20,5 +20,6 @@ from .oracle import (  # noqa: F401
     sort_dedup,
     truth_filter,
     truth_logdensity,
+    truth_variance,
     variance,
 )

@@ -210,3 +210,29 @@ int orc_truth_filter(int n, const double* t, const double* y, const double* yerr
     double out[2];
     return truth_run(n, t, y, yerr, p, q, theta, out, mean, var);
 }
+
+/* CARp::Variance(omega, ma, sigma = 1, lag 0) (src/carpack.cpp:377-409; CarmaSample._sigma_noise, carma_pack.py:513-546, forms the
+ * same sum) in quad precision, from roots and MA coefficients GIVEN AS DOUBLES: the arbiter of carma_sigma_noise_batch.
+ * nma coefficients (nma <= p).  Returns 0; *out = the variance for unit driving noise (sigma_noise = sqrt(var / *out)).          */
+int orc_truth_variance(int p, const double* om_re, const double* om_im, const double* ma, int nma, double* out)
+{
+    if (p < 1 || p >= PMAXQ || nma < 1 || nma > p) return -1;
+    QC om[PMAXQ];
+    for (int k = 0; k < p; k++) om[k] = qc((Q)om_re[k], (Q)om_im[k]);
+    QC var1 = qc(0, 0);
+    for (int k = 0; k < p; k++) {
+        QC dp = qc(1, 0);
+        for (int l = 0; l < p; l++)
+            if (l != k) dp = qmul(dp, qmul(qsub(om[l], om[k]), qadd(qconj(om[l]), om[k])));
+        const QC den = qscale(dp, -2 * om[k].re);
+        QC s1 = qc(0, 0), s2 = qc(0, 0);
+        for (int l = 0; l < nma; l++) {
+            s1 = qadd(s1, qscale(qpowi(om[k], l), (Q)ma[l]));
+            s2 = qadd(s2, qscale(qpowi(qscale(om[k], -1), l), (Q)ma[l]));
+        }
+        var1 = qadd(var1, qdiv(qmul(s1, s2), den));
+    }
+    *out = (double)var1.re;
+    return 0;
+}
+

@@ -67,6 +67,8 @@ def lib():
         L.orc_truth_logdensity.restype = C.c_int
         L.orc_truth_filter.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
         L.orc_truth_filter.restype = C.c_int
+        L.orc_truth_variance.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, _dp]
+        L.orc_truth_variance.restype = C.c_int
         L.orc_sampler_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp]
         L.orc_ram_step.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_long, C.c_long, _dp, _dp, C.c_double]
         L.orc_ram_step.restype = C.c_int
@@ -93,6 +95,18 @@ def truth_logdensity(t, y, yerr, theta, p, q):
     if rc != 0:
         raise ValueError("orc_truth_logdensity: rc=%d" % rc)
     return float(out[0]), float(out[1])
+
+
+def truth_variance(roots, ma):
+    """CARp::Variance(roots, ma, sigma = 1) (src/carpack.cpp:377-409) in quad precision, roots / ma taken as the doubles given:
+    the arbiter of the device's sigma_noise."""
+    roots = np.asarray(roots, dtype=complex).ravel()
+    ma = _a(np.asarray(ma, dtype=float).ravel())
+    re, im, out = _a(roots.real.copy()), _a(roots.imag.copy()), np.empty(1)
+    rc = lib().orc_truth_variance(roots.size, _p(re), _p(im), _p(ma), ma.size, _p(out))
+    if rc != 0:
+        raise ValueError("orc_truth_variance: rc=%d" % rc)
+    return float(out[0])
 
 
 def truth_filter(t, y, yerr, theta, p, q):

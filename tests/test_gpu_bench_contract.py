@@ -53,6 +53,14 @@ def test_single_gpu_line():
                     assert v is None or 0.0 <= v <= 1.0, (path + "/" + k, v)
                 fracs(v, path + "/" + k)
     fracs(j)
+    # the binding ceilings as scalars next to `frac` (None only when no counter record of this build is committed), and the
+    # 2^20-evaluation leg
+    for blk in (rf, j["throughput"], j["throughput_1m"], j["mcmc"]):
+        assert {"valu_issue_frac", "fp64_frac", "fp64_tflops"} <= set(blk)
+        for k in ("valu_issue_frac", "fp64_frac"):
+            assert blk[k] is None or 0.0 < blk[k] <= 1.0, (k, blk[k])
+    t1 = j["throughput_1m"]
+    assert t1["batch_per_gpu"] == 1 << 20 and t1["finite"] > 0.5 * (1 << 20) and t1["evals_per_s"] > j["throughput"]["evals_per_s"]
     assert j["build"]["build_id"] and j["rccl_first_contact"]["verdict"] == "one rank: no exchange"
     assert len(j["ranks"]) == 1 and j["ranks"][0]["device_ordinal"] == 0
     for blk in (rf["pmc_per_launch"], j["mcmc"]["pmc_per_iteration"], j["throughput"]["pmc_per_launch"]):
@@ -84,32 +92,42 @@ def test_two_ranks_sharing_the_gpu():
     assert ld["first_contact_check"]["equals_one_gpu_run"] is True, ld["first_contact_check"]
 
 
-def test_four_ranks_with_the_native_ladder_path():
+def _native_ladder_ranks(nranks):
     """The line the driver's N > 1 runs produce, with the ladder leg on the library's NATIVE path (carma_pt_iterate_sharded:
-    pack kernel -> send/recv -> swap kernel on the sampler's stream, boundary checksums) -- four processes, two temperatures
-    each.  One GPU here, so the ranks share it and the eight RCCL entry points are the shared-memory test double of
-    tests/shm_transport (CARMA_RCCL_LIB); everything above them is what runs on four GPUs."""
+    pack kernel -> send/recv -> swap kernel on the sampler's stream, boundary checksums) -- `nranks` processes, 8 / nranks
+    temperatures each.  One GPU here, so the ranks share it and the eight RCCL entry points are the shared-memory test double of
+    tests/shm_transport (CARMA_RCCL_LIB); everything above them is what runs on that many GPUs."""
     import subprocess as sp
     here = os.path.join(ROOT, "tests", "shm_transport")
     lib = os.path.join(here, "libshm_rccl.so")
     sp.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-o", lib, os.path.join(here, "shm_rccl.cpp"), "-lrt", "-lpthread"],
            check=True, stdout=sp.PIPE, stderr=sp.STDOUT, timeout=600)
     env = dict(os.environ, CARMA_BENCH_SHARE_GPU="1", CARMA_RCCL_LIB=lib)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "4", "--steps", "50", "--warmup", "5", "--mcmc-iters", "100", "--no-pipelined", "--no-throughput",
-                        "--ladder-iters", "6"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--gpus", str(nranks), "--steps", "50", "--warmup", "5", "--mcmc-iters", "100", "--no-pipelined", "--no-throughput",
+                        "--ladder-iters", "6"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
-    assert j["n_gpus"] == 4 and j["finite_in_last_batch"] == 1024
+    assert j["n_gpus"] == nranks and j["finite_in_last_batch"] == 1024
     ld = j["ladder_sharded"]
-    assert ld["rccl_ranks"] == 4 and ld["temperatures_per_rank"] == 2 and ld["transport"].startswith("rccl send/recv"), ld
+    assert ld["rccl_ranks"] == nranks and ld["temperatures_per_rank"] == 8 // nranks and ld["transport"].startswith("rccl send/recv"), ld
     fc = ld["first_contact_check"]
-    assert fc["equals_one_gpu_run"] is True and fc["boundary_checksums_agree"] == [1, 1, 1, 1], fc
+    assert fc["equals_one_gpu_run"] is True and fc["boundary_checksums_agree"] == [1] * nranks, fc
     rates = ld["boundary_swaps_by_rank"]
-    assert [r_["proposed"] for r_ in rates] == [128 * 16, 2 * 128 * 16, 2 * 128 * 16, 128 * 16]
+    assert [r_["proposed"] for r_ in rates] == [128 * 16] + [2 * 128 * 16] * (nranks - 2) + [128 * 16]
     assert all(r_["checksums_agree"] == 1 and 0.0 < r_["rate"] < 1.0 for r_ in rates)
     assert j.get("ladder_leg_hung") in (None, False)
+
+
+def test_four_ranks_with_the_native_ladder_path():
+    _native_ladder_ranks(4)
+
+
+def test_eight_ranks_one_temperature_each():
+    """BASELINE configs[3] at its real partition -- eight ranks, ONE temperature per rank (every chain of a block is a boundary
+    chain on both sides) -- so that the driver's first 8-GPU run exercises no rank count the code has never seen."""
+    _native_ladder_ranks(8)
 
 
 def test_ladder_leg_cannot_hold_the_line_back():

@@ -79,14 +79,14 @@ def _run(resident):
     return res
 
 
-def _unsharded():
+def _unsharded(tg=TG):
     """The same ladder on ONE context (the one-GPU sampler kernel with its own sweep): what every sharded run must equal."""
     import carma_pack_amd as cpa
     from carma_pack_amd import parallel as par
     t, y, e = _series()
     ctx = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std())
-    ctx.pt_create(TG, R, NITER, seed=SEED, temperatures=par.ladder_temperatures(TG))
-    ctx.pt_shard(TG, 0, 0)
+    ctx.pt_create(tg, R, NITER, seed=SEED, temperatures=par.ladder_temperatures(tg))
+    ctx.pt_shard(tg, 0, 0)
     ctx.pt_start(None)
     ctx.pt_iterate(NITER)
     th, lp = ctx.pt_get_chains()
@@ -319,7 +319,8 @@ def _shm_rank_worker(rank, blocks_by_rank, port, q, lib, nsample):
         import carma_pack_amd as cpa
         from carma_pack_amd import _lib, parallel as par
         t, y, e = _series()
-        temps = par.ladder_temperatures(TG)
+        tg = sum(sum(b) for b in blocks_by_rank)                     # (5 in most cases; 8 for one temperature per rank x 8)
+        temps = par.ladder_temperatures(tg)
         comm = _lib.Comm.from_torch(dist, device=0)
         assert (comm.rank, comm.size) == (rank, len(blocks_by_rank))
         slot0 = sum(sum(b) for b in blocks_by_rank[:rank])
@@ -327,7 +328,7 @@ def _shm_rank_worker(rank, blocks_by_rank, port, q, lib, nsample):
         for Tl in blocks_by_rank[rank]:
             c = cpa.Context(t, y, e, P, Q, max_stdev=10.0 * y.std())
             c.pt_create(Tl, R, NITER, seed=SEED, temperatures=temps[slot0:slot0 + Tl])
-            c.pt_shard(TG, slot0, 0)
+            c.pt_shard(tg, slot0, 0)
             c.pt_start(None)
             ctxs.append(c)
             slot0 += Tl
@@ -362,7 +363,7 @@ def _run_shm_ranks(blocks_by_rank, nsample=0):
     return res
 
 
-@pytest.mark.parametrize("blocks_by_rank", [[[3], [2]], [[2], [2], [1]], [[1, 1], [2, 1]], [[1], [1], [1], [1], [1]]])
+@pytest.mark.parametrize("blocks_by_rank", [[[3], [2]], [[2], [2], [1]], [[1, 1], [2, 1]], [[1], [1], [1], [1], [1]], [[1]] * 8])
 def test_native_sharded_path_with_more_than_one_rank(blocks_by_rank):
     """carma_pt_iterate_sharded / carma_pt_sample_sharded with nranks = 2, 3 and 5 PROCESSES (one or two blocks each):
     which rank talks to which, in what order, the boundary self-check between processes.  RCCL refuses two ranks on one
@@ -370,8 +371,8 @@ def test_native_sharded_path_with_more_than_one_rank(blocks_by_rank):
     (tests/shm_transport, CARMA_RCCL_LIB) -- everything above them is the production code: `Comm.from_torch` (the id
     travels through torch.distributed), `carma_comm_create` with nranks > 1, the pack / exchange / swap / sweep order.
     The chain states must be the unsharded ladder's, bit for bit, whatever the partition; the rank that owns the coldest
-    temperature saves the samples."""
-    uth, ulp, _ = _unsharded()
+    temperature saves the samples.  [[1]] * 8 is BASELINE configs[3]'s partition: eight ranks, one temperature each."""
+    uth, ulp, _ = _unsharded(sum(sum(b) for b in blocks_by_rank))
     res = _run_shm_ranks(blocks_by_rank)
     ths = [o[0] for _, out, _ in res for o in out]
     lps = [o[1] for _, out, _ in res for o in out]

@@ -58,9 +58,16 @@ def test_sigma_noise_against_reference_vectors_and_restatement(cpa, readme):
             got, want = _lib.sigma_noise_batch(roots, ma, var), orc.post.sigma_noise(roots, ma, var)
             fin = np.isfinite(want)
             assert np.array_equal(np.isfinite(got), fin), (p, q)
-            # the sum over the roots cancels when roots cluster: both sides carry cond x eps; well-conditioned ones agree to 1e-10
-            rel = np.abs(got[fin] - want[fin]) / np.abs(want[fin])
-            assert np.mean(rel < 1e-10) > 0.9 and rel.max() < 1e-4, (p, q, rel.max(), np.mean(rel < 1e-10))
+            # the sum over the roots cancels when roots cluster: both sides carry cond x eps.  Within 1e-10 of the restatement, or --
+            # arbitrated by the same sum in quad precision (oracle/carma_truth_q.c, orc_truth_variance) -- no further from the exact
+            # value than the restatement is; at most 10 % of the entries may need the arbiter
+            from helpers import assert_parity
+            idx = np.flatnonzero(fin)
+
+            def exact(k, roots=roots, ma=ma, var=var, idx=idx):
+                i = idx[k]
+                return float(np.sqrt(var[i] / orc.truth_variance(roots[i], ma[i][:roots.shape[1]])))
+            assert_parity(got[fin], want[fin], 1e-10, "sigma_noise (%d,%d)" % (p, q), arbiter=exact, arb_factor=1.25, max_arb_frac=0.10)
 
 
 def test_psd_band_matches_reference_output(cpa, readme, golden_dir):
