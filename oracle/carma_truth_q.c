@@ -213,10 +213,12 @@ int orc_truth_filter(int n, const double* t, const double* y, const double* yerr
 
 /* CARp::Variance(omega, ma, sigma = 1, lag 0) (src/carpack.cpp:377-409; CarmaSample._sigma_noise, carma_pack.py:513-546, forms the
  * same sum) in quad precision, from roots and MA coefficients GIVEN AS DOUBLES: the arbiter of carma_sigma_noise_batch.
- * nma coefficients (nma <= p).  Returns 0; *out = the variance for unit driving noise (sigma_noise = sqrt(var / *out)).          */
+ * nma coefficients (nma <= p).  Returns 0; out[0] = the variance for unit driving noise (sigma_noise = sqrt(var / out[0])).       */
 int orc_truth_variance(int p, const double* om_re, const double* om_im, const double* ma, int nma, double* out)
 {
+    /* out[0] = the variance; out[1] = sum over the roots of |term_k| (the summation's condition number is out[1] / |out[0]|) */
     if (p < 1 || p >= PMAXQ || nma < 1 || nma > p) return -1;
+    Q sabs = 0;
     QC om[PMAXQ];
     for (int k = 0; k < p; k++) om[k] = qc((Q)om_re[k], (Q)om_im[k]);
     QC var1 = qc(0, 0);
@@ -230,9 +232,12 @@ int orc_truth_variance(int p, const double* om_re, const double* om_im, const do
             s1 = qadd(s1, qscale(qpowi(om[k], l), (Q)ma[l]));
             s2 = qadd(s2, qscale(qpowi(qscale(om[k], -1), l), (Q)ma[l]));
         }
-        var1 = qadd(var1, qdiv(qmul(s1, s2), den));
+        const QC term = qdiv(qmul(s1, s2), den);
+        var1 = qadd(var1, term);
+        sabs += sqrtq(qabs2(term));
     }
-    *out = (double)var1.re;
+    out[0] = (double)var1.re;
+    out[1] = (double)sabs;
     return 0;
 }
 

@@ -97,16 +97,17 @@ def truth_logdensity(t, y, yerr, theta, p, q):
     return float(out[0]), float(out[1])
 
 
-def truth_variance(roots, ma):
+def truth_variance(roots, ma, with_cond=False):
     """CARp::Variance(roots, ma, sigma = 1) (src/carpack.cpp:377-409) in quad precision, roots / ma taken as the doubles given:
-    the arbiter of the device's sigma_noise."""
+    the arbiter of the device's sigma_noise.  with_cond: also the condition number of the sum over the roots
+    (sum |term_k| / |sum term_k|), which bounds what ANY double-precision evaluation of the formula can deliver."""
     roots = np.asarray(roots, dtype=complex).ravel()
     ma = _a(np.asarray(ma, dtype=float).ravel())
-    re, im, out = _a(roots.real.copy()), _a(roots.imag.copy()), np.empty(1)
+    re, im, out = _a(roots.real.copy()), _a(roots.imag.copy()), np.empty(2)
     rc = lib().orc_truth_variance(roots.size, _p(re), _p(im), _p(ma), ma.size, _p(out))
     if rc != 0:
         raise ValueError("orc_truth_variance: rc=%d" % rc)
-    return float(out[0])
+    return (float(out[0]), float(out[1] / abs(out[0]))) if with_cond else float(out[0])
 
 
 def truth_filter(t, y, yerr, theta, p, q):
