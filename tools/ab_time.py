@@ -23,6 +23,9 @@ for B in %r:
     res["B%%d_us" %% B] = best * 1e6
 ctx.pt_create(16, 64, adapt_iters=10 ** 9, seed=11); ctx.pt_start(None); ctx.pt_iterate(200)
 t0 = time.perf_counter(); ctx.pt_iterate(3000); res["mcmc_it_per_s"] = 3000 / (time.perf_counter() - t0)
+c2 = cpa.Context(t, y, e, 5, 3, max_stdev=10.0 * y.std())
+c2.pt_create(16, 192, adapt_iters=10 ** 9, seed=11); c2.pt_start(None); c2.pt_iterate(100)
+t0 = time.perf_counter(); c2.pt_iterate(1500); res["mcmc_16x192_it_per_s"] = 1500 / (time.perf_counter() - t0)
 res["kernel"] = ctx.kernel_name(1024)
 print(json.dumps(res))
 '''
