@@ -16,12 +16,15 @@
 // carma_pipe3l.h: 30 for the covariance alone); measured in isolation 145-153 cycles per datum at P = 5 against 198
 // (tools/ubench/gen_ub11.py, profiles/r05/ub11_window_v1.txt).
 //
-// Frame and re-base as in carma_pipe3l.h (dyadic time grid per evaluation, frame half a window ahead, coordinates
-// rescaled by exact powers of two), with one difference: a chunk ENDS in front of a re-base datum, so a re-base is always
-// the first thing of a chunk (S <- A S A^T, z~ <- A z~ on the virtual lanes, then the start above).  Every evaluation
-// has its own chunk schedule -- a row whose next datum is a re-base datum completes its chunk with NEUTRAL slots
-// (h~ = c~ = 0, variance 1, innovation 0: the state does not move, the sums get exactly 0) -- so an evaluation's result
-// does not depend on its neighbours in the workgroup; the workgroup runs until its slowest row is through.
+// Frame as in carma_pipe3l.h (window of 2^-ex per evaluation, frame half a window ahead, coordinates rescaled by exact
+// powers of two); the RE-BASE is always the first thing of a chunk (S <- A S A^T, z~ <- A z~ on the virtual lanes, then the
+// start above): a chunk opens with one when the last datum it could take would leave the window, and only data further
+// than a window from the chunk's first datum are cut off (pipew_produce).  Every evaluation has its own chunk schedule
+// -- a cut chunk is completed with NEUTRAL slots (h~ = c~ = 0, variance 1, innovation 0: the state does not move, the
+// sums get exactly 0) -- so an evaluation's result does not depend on its neighbours in the workgroup; the workgroup
+// runs until its slowest row is through.
+// STATUS: opt-in (CARMA_TUNE_WIN_ROWS).  Measured 29.7 us against the one-datum pipeline's 31.0 at 1024 evaluations and
+// slower beyond (profiles/r05/window_pipeline_v1.txt): not the default.
 //
 //   waves P0, P1 (producers)   per chunk and row: schedule, exp / sincos, entries {h~_r, c~_r}, {scale yerr^2, y - mu}
 //   wave A (recursion)         [re-base]; start of the chunk; ND pivots; log-likelihood terms of the chunk
@@ -106,7 +109,7 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     }
     // schedule state of this row (row-uniform)
     int j0 = 0;
-    double base = series[0].w, t_before = base;
+    double base = series[0].w;
     // The chunk schedule is data dependent (a chunk ends in front of a re-base datum), so the records of a chunk cannot be
     // requested by index a chunk ahead as in carma_pipe3l.h -- and a global load at the head of every chunk would put an L2
     // round trip on every chunk (measured: 45 us per launch instead of 22).  So each row keeps a WINDOW of 64 records in
@@ -158,20 +161,26 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
             rec.w = hi ? w1_ : w0;
         }
         const double tj = rec.w;
-        const double tprev = dpp_mov_old<0x111>(t_before, tj);                // row_shr:1, lane 0 <- the datum before the chunk
-        const bool fl = jl > 0 && jl < n && floor(tj * sc) != floor(tprev * sc);
-        const unsigned long long flb = __ballot(fl);
-        const unsigned rowbits = (unsigned)(flb >> (16 * q)) & 0xffffu;
-        const bool rot = rowbits & 1u;                                        // the chunk opens with a re-base datum
-        const unsigned cut = (rowbits >> 1) & ((1u << (ND - 1)) - 1u);        // a re-base datum further on ends the chunk
-        int len = cut ? __builtin_ctz(cut) + 1 : ND;
+        // RE-BASE RULE (round 5, second version): look a chunk ahead.  The frame of a window carries scale factors e^(+-LIM_RE / 2)
+        // as long as a datum is no further than W = 2^-ex from the window's base.  If the LAST datum this chunk could take is
+        // beyond W, the chunk OPENS with a re-base at its first datum (rotation over the time since the old base, any length:
+        // a decayed coordinate underflows to 0) -- and only data further than W from THAT are cut off (a gap inside the chunk).
+        // The first version ended a chunk in front of every cell boundary of a dyadic time grid, as the one-datum pipeline
+        // re-bases: a row with a short window then ran 36 chunks where its neighbours ran 25, and the launch waits for the
+        // slowest row (34.1 us per 1024 evaluations, profiles/r05/window_pipeline_v1.txt).
         const int left = n - j0;
-        len = len < left ? len : (left > 0 ? left : 0);
+        const int ncand = left < ND ? (left > 0 ? left : 0) : ND;
         const double t0 = __shfl(tj, rowb, 64);
+        const double t_lastc = __shfl(tj, rowb + (ncand > 0 ? ncand - 1 : 0), 64);
+        const double W = sc > 0.0 ? 1.0 / sc : 1.0 / 0.0;
+        const bool rot = ncand > 0 && (t_lastc - base) > W;
         const double base_old = base;
         base = rot ? t0 : base;
         // (the difference of two time stamps is exact unless the base is much the smaller of the two: carma_pipe3l.h)
         const double dta_l = tj - base;
+        const unsigned long long flb = __ballot(dta_l > W && l < ncand);
+        const unsigned cut = (unsigned)(flb >> (16 * q)) & 0xffffu;            // (bit 0 never: dta = 0 or <= W at slot 0)
+        const int len = cut ? __builtin_ctz(cut) : ncand;
         const bool row_done = j0 + len >= n;
         const bool last = __ballot(!row_done) == 0ull;
         if (pw == 0) {
@@ -216,7 +225,6 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
                 if (two) dst[4] = make_double2(e1, -es);
             }
         }
-        if (len > 0) t_before = __shfl(tj, rowb + len - 1, 64);
         j0 += len;
         if (j0 - jw >= 16) {                                  // (at most one shift per chunk: len < 16)
             rw0 = rw1;
@@ -258,6 +266,11 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
     const bool act = l < P;
     ring[Geo::CONST_OFF + lane] = make_double2(act ? rc.h_own : 0.0, act ? rc.c_own : 0.0);
     __syncthreads();                                          // the producers take the constants from here
+#if defined(CARMA_WIN_STAMPS)
+#define WIN_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+    unsigned long long rs_c0 = 0;
+    WIN_STAMP(rs_c0);
+#endif
     double kk[P], hh[P], kn[P], hn[P];
 #pragma unroll
     for (int r = 0; r < P; r++) kk[r] = hh[r] = 0.0;
@@ -325,8 +338,9 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
     load(0, en, hdr);
     start(0);
 #if defined(CARMA_WIN_STAMPS)
-    unsigned long long rs_bar = 0, rs_piv = 0, rs_fin = 0, rs_t0 = 0, rs_t1 = 0, rs_t2 = 0, rs_t3 = 0;
+    unsigned long long rs_bar = 0, rs_piv = 0, rs_fin = 0, rs_t0 = 0, rs_t1 = 0, rs_t2 = 0, rs_t3 = 0, rs_loop0 = 0;
     int rs_n = 0;
+    WIN_STAMP(rs_loop0);
 #endif
     for (int c = 0;; c++) {
         const bool last = (hdr & 256ull) != 0ull;
@@ -368,10 +382,15 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
 #endif
     }
 #if defined(CARMA_WIN_STAMPS)
-    if (blockIdx.x == 0 && lane == 0)
-        printf("window pipeline, recursion wave: %d chunks, per chunk %llu cycles at the barrier, %llu loads + pivots, %llu terms + start of the next\n",
-               rs_n, rs_bar / (unsigned long long)(rs_n ? rs_n : 1), rs_piv / (unsigned long long)(rs_n ? rs_n : 1),
-               rs_fin / (unsigned long long)(rs_n ? rs_n : 1));
+    {
+        unsigned long long rs_end;
+        WIN_STAMP(rs_end);
+        if ((blockIdx.x % 37) == 0 && lane == 0)
+            printf("window pipeline, block %d recursion wave: %d+1 chunks, per chunk %llu cycles at the barrier, %llu loads + pivots, %llu terms + start of the next; "
+                   "first pivot %llu cycles after the constants were published, loop %llu cycles\n", (int)blockIdx.x,
+                   rs_n, rs_bar / (unsigned long long)(rs_n ? rs_n : 1), rs_piv / (unsigned long long)(rs_n ? rs_n : 1),
+                   rs_fin / (unsigned long long)(rs_n ? rs_n : 1), rs_loop0 - rs_c0, rs_end - rs_loop0);
+    }
 #endif
     return Grp<16>::sum(acc.total());
 }

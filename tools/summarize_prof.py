@@ -11,7 +11,7 @@ import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r04")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r05")
 pt_iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 os.makedirs(dst, exist_ok=True)
 sys.path.insert(0, root)
@@ -55,7 +55,7 @@ def collect(kern, grid=None, per_iteration=0):
 
 
 for name, kern, grid, it in (("", "k_logdens_carma_p3l<5>", 65536, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),
-                             ("_tput", "k_logdens_carma_lane<5", None, 0)):
+                             ("_tput", "k_logdens_carma_lane<5", 65536, 0)):      # (the 65 536-evaluation launches, not the 2^20 ones of throughput_1m)
     r = collect(kern, grid, it)
     if r["_dispatch"] is None:
         print("no dispatches of", kern)
