@@ -570,15 +570,14 @@ static long p3l_max_rows()
 
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
 enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC, WIN };
-// Largest launch (in workgroups of four evaluations) that takes the windowed wave pipeline (carma_pipew.h).
-// CARMA_TUNE_WIN_ROWS overrides (0 disables it); read once.
+// Largest launch (in workgroups of four evaluations) that takes the windowed wave pipeline (carma_pipew.h): one workgroup per CU
+// (measured per order at 1024 evaluations, profiles/r05/window_pipeline_v1.txt: 1-10 % ahead of the one-datum pipeline; with two
+// or three workgroups per CU that one is ahead).  CARMA_TUNE_WIN_ROWS overrides (0: never) -- read at EVERY launch, so that one
+// test process can run both pipelines.
 static long win_max_rows()
 {
-    static const long tune = [] {
-        const char* e = getenv("CARMA_TUNE_WIN_ROWS");
-        return e ? atol(e) : -1L;
-    }();
-    return tune >= 0 ? tune : 0L;
+    const char* e = getenv("CARMA_TUNE_WIN_ROWS");
+    return e ? atol(e) : (long)device_cus();
 }
 // smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
 static long lane_min_evals(int p = 5)

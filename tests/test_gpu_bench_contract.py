@@ -43,7 +43,7 @@ def test_single_gpu_line():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 1024) < 1e-6 * 1024
     # the kernel label comes from the library's own launch table, the counters from a profile of that very kernel
-    assert rf["kernel"] == "k_logdens_carma_p3l<5>" and rf["binding_resource"] == "fp64_valu_issue"
+    assert rf["kernel"] == "k_logdens_carma_w<5>" and rf["binding_resource"] == "fp64_valu_issue"      # (round 5: the windowed pipeline)
     assert rf["traffic"] is None or (rf["traffic_source"] and rf["traffic"] < rf["algorithmic_bytes_per_launch"])
     # no fraction on the line may exceed 1, and counters are attached only when they were measured on the running build
     def fracs(o, path=""):

@@ -303,8 +303,15 @@ def test_launch_shapes_agree(cpa, p, q):
     fin = np.isfinite(want)
     for name in res:
         assert np.array_equal(np.isfinite(res[name]), fin)
-    for name in ("p3b", "p3c", "p3d", "p3e"):                       # one kernel, whatever the number of workgroups per CU
-        assert np.array_equal(res["p3"], res[name], equal_nan=True), name
+    # Round 5: up to one workgroup per CU the WINDOWED pipeline (carma_pipew.h), beyond it the one-datum pipeline (carma_pipe3l.h) --
+    # each the same bits whatever the launch size; CARMA_TUNE_WIN_ROWS=0 (the suite's cross-section on the one-datum pipeline)
+    # puts all five on the latter
+    win = os.environ.get("CARMA_TUNE_WIN_ROWS") != "0"
+    assert ctx.kernel_name(1000) == ("k_logdens_carma_w<%d>" if win else "k_logdens_carma_p3l<%d>") % p
+    assert ctx.kernel_name(1100) == "k_logdens_carma_p3l<%d>" % p
+    assert np.array_equal(res["p3"], res["p3b"], equal_nan=True)
+    for name in ("p3d", "p3e") + (() if win else ("p3",)):           # one kernel, whatever the number of workgroups per CU
+        assert np.array_equal(res["p3c"], res[name], equal_nan=True), name
     if "pc" in res:
         assert np.array_equal(res["pc"], res["pc2"], equal_nan=True)
     # the producer waves evaluate the very function the lane kernel evaluates in line: same bits
@@ -570,9 +577,11 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
         assert v == res["mixed"][key] or (np.isnan(v) and np.isnan(res["mixed"][key]))
 
 
+@pytest.mark.parametrize("pipeline", ["window", "one-datum"])
 @pytest.mark.parametrize("p,q", [(2, 0), (4, 1), (5, 3), (6, 0), (7, 2)])
-def test_wave_pipeline_real_pairs(cpa, p, q):
-    """The wave pipeline's producer lanes evaluate ONE exp/sincos per root pair; a quadratic factor with two real roots
+def test_wave_pipeline_real_pairs(cpa, monkeypatch, p, q, pipeline):
+    """(Both wave pipelines: the windowed one, which small launches take since round 5, and -- CARMA_TUNE_WIN_ROWS=0, read at
+    every launch -- the one-datum pipeline.)  The wave pipeline's producer lanes evaluate ONE exp/sincos per root pair; a quadratic factor with two real roots
     is the pair whose members do not share a modulus and gets a second exponential.  Real-pair thetas alone, next to
     complex-pair ones in the same workgroup (the re-base grid of a workgroup is the finest of its four evaluations),
     and alone in a launch: same value every time, parity with the oracle."""
@@ -586,8 +595,11 @@ def test_wave_pipeline_real_pairs(cpa, p, q):
         r2 = r1 * rng.uniform(3.0, 20.0, 32)
         real[:, 3 + 2 * f] = np.log(r1 * r2)
         real[:, 4 + 2 * f] = np.log(r1 + r2)
+    if pipeline == "one-datum" or os.environ.get("CARMA_TUNE_WIN_ROWS") == "0":
+        monkeypatch.setenv("CARMA_TUNE_WIN_ROWS", "0")
+        pipeline = "one-datum"
     ctx = cpa.Context(t, y, yerr, p, q)
-    assert ctx.kernel_name(64).startswith("k_logdens_carma_p3l")
+    assert ctx.kernel_name(64).startswith("k_logdens_carma_w" if pipeline == "window" else "k_logdens_carma_p3l")
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     mixed = np.concatenate([cplx, real])[rng.permutation(64)]
     got_r, got_m = ctx.logdensity(real, ignore_prior=True), ctx.logdensity(mixed, ignore_prior=True)
@@ -1044,6 +1056,21 @@ def test_batches_at_the_end_of_their_allocation():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_guard.py")], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("CARMA_TUNE_WIN_ROWS") == "0", reason="this IS that run")
+def test_parity_suite_on_the_one_datum_pipeline():
+    """Since round 5 launches of up to one workgroup per CU take the windowed pipeline (carma_pipew.h); the one-datum pipeline
+    (carma_pipe3l.h) keeps 1025 ... 3072 evaluations and the row sampler.  So that it stays covered at the SMALL sizes most parity
+    tests use, this file's tests run once more with CARMA_TUNE_WIN_ROWS=0, in a process of their own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CARMA_TUNE_WIN_ROWS="0", CARMA_ALLOWANCE_FILE="parity_allowances_one_datum.json")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "not cross_section and not end_of_their_allocation and not one_datum_pipeline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.skipif(os.environ.get("CARMA_DEBUG_GUARD") == "1", reason="this IS the guarded run")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses the rocprofv3 output of tools/profile_round.sh into the files committed under profiles/:
    kernel_stats_<tag>.csv       (the --stats kernel summary, verbatim)
-   pmc_<tag>.json               headline kernel k_logdens_carma_p3l<5>: per-LAUNCH mean/min/max of each counter
+   pmc_<tag>.json               headline kernel k_logdens_carma_w<5> (round 5; before: k_logdens_carma_p3l<5>): per-LAUNCH mean/min/max of each counter
    pmc_<tag>_ptrow.json         sampler kernel k_pt_row<5,...>: counters summed over its dispatches / iterations run
                                 (the bench's sampler leg under --mcmc-iters 200: 100 warm-up + 200 timed = 300) -> per ITERATION
    pmc_<tag>_tput.json          throughput kernel k_logdens_carma_lane<5> (one evaluation per lane): per launch of 65 536 evaluations
@@ -54,7 +54,7 @@ def collect(kern, grid=None, per_iteration=0):
     return res
 
 
-for name, kern, grid, it in (("", "k_logdens_carma_p3l<5>", 65536, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),
+for name, kern, grid, it in (("", "k_logdens_carma_w<5>", 65536, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),
                              ("_tput", "k_logdens_carma_lane<5", 65536, 0)):      # (the 65 536-evaluation launches, not the 2^20 ones of throughput_1m)
     r = collect(kern, grid, it)
     if r["_dispatch"] is None:
