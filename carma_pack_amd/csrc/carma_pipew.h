@@ -266,14 +266,11 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
     const bool act = l < P;
     ring[Geo::CONST_OFF + lane] = make_double2(act ? rc.h_own : 0.0, act ? rc.c_own : 0.0);
     __syncthreads();                                          // the producers take the constants from here
-#if defined(CARMA_WIN_STAMPS)
-#define WIN_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
-    unsigned long long rs_c0 = 0;
-    WIN_STAMP(rs_c0);
-#endif
-    double kk[P], hh[P], kn[P], hn[P];
+    // two register sets for (kk, hh): the start of chunk c + 1 reads the columns of S out of chunk c's set while it writes the
+    // other one, so the sets alternate and no copy is needed (the loop below is unrolled by two)
+    double ka[P], ha[P], kb[P], hb[P];
 #pragma unroll
-    for (int r = 0; r < P; r++) kk[r] = hh[r] = 0.0;
+    for (int r = 0; r < P; r++) ka[r] = ha[r] = kb[r] = hb[r] = 0.0;
     double mA = 1.0, mB = 1.0, nuA = 0.0, nuB = 0.0;
     LogLikAcc acc;
     acc.init();
@@ -285,8 +282,8 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
         for (int r = 0; r < ENT; r++) e[r] = ring[Geo::RING_OFF + (b * ENT + r) * 64 + lane];
         h = reinterpret_cast<const unsigned long long*>(ring + Geo::HDR_OFF)[b];
     };
-    // start of a chunk from the columns of S in the virtual lanes (all zero in front of the first chunk)
-    auto start = [&](int b) __attribute__((always_inline)) {
+    // start of a chunk (into kn, hn) from the columns of S in the virtual lanes of kold (all zero in front of the first chunk)
+    auto start = [&](int b, double(&kold)[P], double(&kn)[P], double(&hn)[P]) __attribute__((always_inline)) {
         double nuF = (ND & 1) ? nuB : nuA;                    // virtual lanes: what the last pivot wrote
         if (__builtin_expect((hdr & 0xfull) != 0ull, 0)) {
             // re-base: S <- A S A^T, z~ <- A z~ with the rotation accumulated over the closing window (kfilter.cpp:200-204
@@ -311,12 +308,12 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
             const int plane = paired ? lane - s + sp : lane;
             double tmp[P];
 #pragma unroll
-            for (int r = 0; r < P; r++) tmp[r] = cs_own * kk[r] - ss_own * __shfl(kk[r], plane, 64);      // S A^T
+            for (int r = 0; r < P; r++) tmp[r] = cs_own * kold[r] - ss_own * __shfl(kold[r], plane, 64);      // S A^T
             nuF = cs_own * nuF - ss_own * __shfl(nuF, plane, 64);
 #pragma unroll
             for (int r = 0; r < P; r++) {                     // A (S A^T)
                 const int rp = (r ^ 1) < P ? (r ^ 1) : r;     // (an odd order's last root is real: s_r = 0)
-                kk[r] = cr[r] * tmp[r] - ((r ^ 1) < P ? sr[r] : 0.0) * tmp[rp];
+                kold[r] = cr[r] * tmp[r] - ((r ^ 1) < P ? sr[r] : 0.0) * tmp[rp];
             }
         }
         double nun = en[P].y, mn = en[P].x;
@@ -325,41 +322,28 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
             hn[r] = en[r].x;
             kn[r] = en[r].y;
         }
-        WA::init(kn, nun, mn, kk, nuF, hn);
-#pragma unroll
-        for (int r = 0; r < P; r++) {
-            kk[r] = kn[r];
-            hh[r] = hn[r];
-        }
+        WA::init(kn, nun, mn, kold, nuF, hn);
         mA = mB = mn;
         nuA = nuB = nun;
     };
-    __syncthreads();                                          // barrier 0
-    load(0, en, hdr);
-    start(0);
-#if defined(CARMA_WIN_STAMPS)
-    unsigned long long rs_bar = 0, rs_piv = 0, rs_fin = 0, rs_t0 = 0, rs_t1 = 0, rs_t2 = 0, rs_t3 = 0, rs_loop0 = 0;
-    int rs_n = 0;
-    WIN_STAMP(rs_loop0);
-#endif
-    for (int c = 0;; c++) {
+    // one chunk: the pivots, the log-likelihood terms, the start of the next chunk.  Returns true behind the last chunk.
+    auto chunk = [&](double(&kk)[P], double(&hh)[P], double(&kn)[P], double(&hn)[P], int c) __attribute__((always_inline)) -> bool {
         const bool last = (hdr & 256ull) != 0ull;
-#if defined(CARMA_WIN_STAMPS)
-        WIN_STAMP(rs_t0);
-#endif
-        __syncthreads();                                      // barrier c + 1: chunk c + 1 is in the ring
-#if defined(CARMA_WIN_STAMPS)
-        WIN_STAMP(rs_t1);
-#endif
         double2 en2[ENT];
         unsigned long long hdr2 = 0;
-        if (!last) load((c + 1) % NB, en2, hdr2);
-        __builtin_amdgcn_sched_barrier(0);                    // requested HERE, a chunk ahead
-        WA::chunk(kk, hh, mA, mB, nuA, nuB);
-#if defined(CARMA_WIN_STAMPS)
+        // barrier c + 1 (chunk c + 1 is in the ring) and its loads: in FRONT of the pivots, so that the loads have a chunk to
+        // arrive -- except for chunk 0, whose pivots need not wait for the production of chunk 1
+        if (c > 0) {
+            __syncthreads();
+            if (!last) load((c + 1) % NB, en2, hdr2);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        WIN_STAMP(rs_t2);
-#endif
+        WA::chunk(kk, hh, mA, mB, nuA, nuB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 0) {
+            __syncthreads();
+            if (!last) load((c + 1) % NB, en2, hdr2);
+        }
         // log-likelihood terms of the chunk (carpack.hpp:167-171): a data lane's variance and innovation are in the register its
         // own pivot read
         {
@@ -367,31 +351,20 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
             acc.add_var(varF);
             acc.chi2 += innF * (recip(varF) * innF);
         }
-        if (last) break;
+        if (last) return true;
 #pragma unroll
         for (int r = 0; r < ENT; r++) en[r] = en2[r];
         hdr = hdr2;
-        start((c + 1) % NB);
-#if defined(CARMA_WIN_STAMPS)
-        __builtin_amdgcn_sched_barrier(0);
-        WIN_STAMP(rs_t3);
-        rs_bar += rs_t1 - rs_t0;
-        rs_piv += rs_t2 - rs_t1;
-        rs_fin += rs_t3 - rs_t2;
-        rs_n++;
-#endif
+        start((c + 1) % NB, kk, kn, hn);
+        return false;
+    };
+    __syncthreads();                                          // barrier 0
+    load(0, en, hdr);
+    start(0, ka, kb, hb);
+    for (int c = 0;; c += 2) {
+        if (chunk(kb, hb, ka, ha, c)) break;
+        if (chunk(ka, ha, kb, hb, c + 1)) break;
     }
-#if defined(CARMA_WIN_STAMPS)
-    {
-        unsigned long long rs_end;
-        WIN_STAMP(rs_end);
-        if ((blockIdx.x % 37) == 0 && lane == 0)
-            printf("window pipeline, block %d recursion wave: %d+1 chunks, per chunk %llu cycles at the barrier, %llu loads + pivots, %llu terms + start of the next; "
-                   "first pivot %llu cycles after the constants were published, loop %llu cycles\n", (int)blockIdx.x,
-                   rs_n, rs_bar / (unsigned long long)(rs_n ? rs_n : 1), rs_piv / (unsigned long long)(rs_n ? rs_n : 1),
-                   rs_fin / (unsigned long long)(rs_n ? rs_n : 1), rs_loop0 - rs_c0, rs_end - rs_loop0);
-    }
-#endif
     return Grp<16>::sum(acc.total());
 }
 
