@@ -283,46 +283,56 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
         h = reinterpret_cast<const unsigned long long*>(ring + Geo::HDR_OFF)[b];
     };
     // start of a chunk (into kn, hn) from the columns of S in the virtual lanes of kold (all zero in front of the first chunk)
-    auto start = [&](int b, double(&kold)[P], double(&kn)[P], double(&hn)[P]) __attribute__((always_inline)) {
-        double nuF = (ND & 1) ? nuB : nuA;                    // virtual lanes: what the last pivot wrote
+    auto start = [&](int b, const double(&kold)[P], double(&kn)[P], double(&hn)[P]) __attribute__((always_inline)) {
+        const double nuF = (ND & 1) ? nuB : nuA;              // virtual lanes: what the last pivot wrote
+        double nun = en[P].y, mn = en[P].x;
+        double cn[P];
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            hn[r] = en[r].x;
+            cn[r] = en[r].y;
+        }
         if (__builtin_expect((hdr & 0xfull) != 0ull, 0)) {
-            // re-base: S <- A S A^T, z~ <- A z~ with the rotation accumulated over the closing window (kfilter.cpp:200-204
-            // for the whole window); a row without a re-base of its own gets the identity
-            double cr[P], sr[P];
+            // RE-BASE: S <- A S A^T, z~ <- A z~ with the rotation A accumulated over the closing window (kfilter.cpp:200-204 for the
+            // whole window; a row without a re-base of its own gets the identity).  S is not rotated where it sits: the start of the
+            // chunk needs S_new h~ = A (S_old (A^T h~)) only, so every lane rotates ITS OWN h~ by A^T (in the lane: the two members
+            // of a pair are two registers), takes S_old (A^T h~) through the same broadcast-FMAs as ever, and rotates the result by A
+            // -- for a virtual lane (h~ = e_s) that IS column s of A S A^T, and its nu' = (A^T e_s) . nu_old = -(A z~)_s.  No
+            // cross-lane traffic beyond the broadcasts the start has anyway (the first version mixed the columns of S between the
+            // virtual lanes through ds_bpermute: 330-600 cycles at every third chunk start of a row with a short window).
+            double cr[P], sr[P], hx[P];
+            const bool mine = ((hdr >> q) & 1ull) != 0ull;
 #pragma unroll
             for (int r = 0; r < P; r++) {
                 const double2 v = ring[Geo::ROT_OFF + (b * P + r) * 4 + q];
                 cr[r] = v.x;
-                sr[r] = v.y;
+                sr[r] = (r ^ 1) < P ? v.y : 0.0;                  // (an odd order's last root is real)
             }
-            const int s = l - ND;
-            double cs_own = 1.0, ss_own = 0.0;
 #pragma unroll
             for (int r = 0; r < P; r++) {
-                cs_own = s == r ? cr[r] : cs_own;
-                ss_own = s == r ? sr[r] : ss_own;
+                const int rp = (r ^ 1) < P ? (r ^ 1) : r;
+                hx[r] = fma(cr[r], hn[r], sr[r] * hn[rp]);        // (A^T h~)_r = c_r h~_r + s_r h~_partner
+                // (a row without a re-base of its own has c = 1, s = 0: every operation below is then exact, and its
+                // accumulation starts from c~ as in the other branch -- the same bits whatever its neighbours do)
+                kn[r] = mine ? 0.0 : cn[r];
             }
-            const int sp = s ^ 1;
-            const bool paired = s >= 0 && sp < P;
-            if (!paired) ss_own = 0.0;
-            const int plane = paired ? lane - s + sp : lane;
-            double tmp[P];
+            WA::init(kn, nun, kold, nuF, hx);
+            double t[P];
 #pragma unroll
-            for (int r = 0; r < P; r++) tmp[r] = cs_own * kold[r] - ss_own * __shfl(kold[r], plane, 64);      // S A^T
-            nuF = cs_own * nuF - ss_own * __shfl(nuF, plane, 64);
+            for (int r = 0; r < P; r++) t[r] = kn[r];
 #pragma unroll
-            for (int r = 0; r < P; r++) {                     // A (S A^T)
-                const int rp = (r ^ 1) < P ? (r ^ 1) : r;     // (an odd order's last root is real: s_r = 0)
-                kold[r] = cr[r] * tmp[r] - ((r ^ 1) < P ? sr[r] : 0.0) * tmp[rp];
+            for (int r = 0; r < P; r++) {
+                const int rp = (r ^ 1) < P ? (r ^ 1) : r;
+                kn[r] = fma(cr[r], t[r], -(sr[r] * t[rp])) + (mine ? cn[r] : 0.0);   // (A .)_r = c_r x_r - s_r x_partner, + c~
             }
-        }
-        double nun = en[P].y, mn = en[P].x;
+        } else {
 #pragma unroll
-        for (int r = 0; r < P; r++) {
-            hn[r] = en[r].x;
-            kn[r] = en[r].y;
+            for (int r = 0; r < P; r++) kn[r] = cn[r];
+            WA::init(kn, nun, kold, nuF, hn);
         }
-        WA::init(kn, nun, mn, kold, nuF, hn);
+        // var' = scale yerr^2 + h~ . k~'  (h~ . c~ = s0; kfilter.cpp:209-210)
+#pragma unroll
+        for (int r = 0; r < P; r++) mn = fma(hn[r], kn[r], mn);
         mA = mB = mn;
         nuA = nuB = nun;
     };

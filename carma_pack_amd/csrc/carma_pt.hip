@@ -22,6 +22,7 @@
 #include "carma_pt_row.h"
 #include "carma_ring.h"
 #include "carma_pipe3l.h"
+#include "carma_pipew.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -270,7 +271,12 @@ __device__ __forceinline__ unsigned long long pt_tag(unsigned long long iter, un
 // MINW = workgroups of this kernel a CU is to hold (waves per SIMD): 2 -> up to 256 registers, nothing spilled; 3 -> 168
 // registers, where the cold code of the swap step and of the random-number tails spills a few values around itself (the
 // recursion loops do not).  The host takes MINW = 3 only for grids of more than two workgroups per CU.
-template <int P, int MINW>
+// WIN (round 5): the log-density through the WINDOWED wave pipeline (carma_pipew.h) instead of the one-datum pipeline -- the chain
+// wave runs the recursion of covariance AND mean and gets the log-likelihood itself, the mean wave hands prior bounds and log prior
+// over through LDS, is the third producer, and keeps the sweep.  Taken where the whole ladder's grid is at most one workgroup per
+// CU (launch_pt_row_p): 16 x 64 ladders 31.1 -> 32.9 * 10^3 it/s on one box (profiles/r05/window_pipeline_v1.txt); with more
+// workgroups per CU the one-datum pipeline is ahead, as for the log-density kernels.
+template <int P, int MINW, bool WIN = false>
 __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
                                                    const double* __restrict__ temps, double* __restrict__ theta,
                                                    double* __restrict__ logpost, double* __restrict__ chol,
@@ -285,7 +291,10 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     const int round = (blockIdx.x >= (unsigned)S.ncu) + (blockIdx.x >= 2u * (unsigned)S.ncu);
     const int wave = ((round == 0 ? 0xE4 : round == 1 ? (S.rot & 0xff) : (S.rot >> 8)) >> (2 * (tid >> 6))) & 3;
     const int d = L.d, T = L.T;
-    Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3l.h rings
+    Cx* ring = reinterpret_cast<Cx*>(smem4);               // carma_pipe3l.h rings (WIN: carma_pipew.h's, in the same space)
+    double2* ringw = reinterpret_cast<double2*>(smem4);
+    static_assert(PipeWGeom<P>::ENTRIES <= Pipe3LGeom<P>::ENTRIES, "the window pipeline's LDS fits the one-datum pipeline's");
+    if constexpr (WIN) math_tab_fill(reinterpret_cast<double*>(ringw + PipeWGeom<P>::TAB_OFF));     // visible behind the barrier below
     double* s_thn = reinterpret_cast<double*>(ring + Pipe3LGeom<P>::ENTRIES);  // [CPW][16] proposals
     double* s_ll = s_thn + CPW * PT_DMAX;                  // [CPW] log-density of the proposals (mean wave -> chain wave)
     double* s_ua = s_ll + CPW;                             // [CPW] acceptance uniforms of this iteration (producer wave 1)
@@ -347,7 +356,10 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
         for (int it = 0; it < L.niter; it++) {
             const uint64_t iter = L.iter0 + (uint64_t)it;
             __syncthreads();                               // proposals visible
-            pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [](int) {});
+            if constexpr (WIN)
+                pipew_produce<P>(g, wave - 2, thn_lds, series, L.n, ringw, [](int) {});
+            else
+                pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [](int) {});
             if (wave == 2) {
                 s_z[lane64] = rng_student_t8(key, iter + 1, (uint32_t)(j < d ? j : 0));
                 if (lane64 == 0) *s_step = ram_adapt_step(d, iter);
@@ -376,7 +388,11 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             {
                 Model<P> m;
                 model_from_theta<P, G, MODEL_FLAGS>(g, thn_lds, L.q, pr, 0, m);
-                // before the recursion: off the critical path
+                if constexpr (WIN) {
+                    const double lpri = log_prior(m.scale, pr.measerr_dof);
+                    if (j == 0) ringw[PipeWGeom<P>::OUT_OFF + row] = make_double2(lpri, m.valid ? 1.0 : 0.0);
+                    pipew_produce<P>(g, 2, thn_lds, series, L.n, ringw, [](int) {});
+                } else {
                 double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], m.scale, series[L.n - 1].y, m.mu);
                 asm volatile("" : "+v"(lpri));
                 bool sing;
@@ -384,6 +400,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 ll += lpri;
                 if (sing || !m.valid) ll = -1.0 / 0.0;
                 if (j == 0) s_ll[row] = ll;
+                }
             }
             __syncthreads();                               // log-densities visible to the chain wave
             __builtin_amdgcn_s_setprio(3);                 // the ladder waits for this sweep (back to 1 in pipe3l_mean)
@@ -494,7 +511,15 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             filter_reset<P, G>(g, m, fc);
             RowConsts<P> rc;
             row_consts<P>(g, m, fc, rc);
-            pipe3l_cov<P>(g, m, rc, series, L.n + npad, npad, ring);
+            if constexpr (WIN) {
+                double llw = pipew_recur<P>(g, rc, ringw);
+                const double2 o = ringw[PipeWGeom<P>::OUT_OFF + row];
+                llw += o.x;
+                if (m.sing || o.y == 0.0) llw = -1.0 / 0.0;
+                if (j == 0) s_ll[row] = llw;
+            } else {
+                pipe3l_cov<P>(g, m, rc, series, L.n + npad, npad, ring);
+            }
         }
         CARMA_STAMP(st2);
         __syncthreads();                                   // log-densities visible
@@ -575,8 +600,9 @@ static size_t pt_row_lds(int d, int T)
 }
 
 template <int P>
-static const void* pt_row_fn(int minw)
+static const void* pt_row_fn(int minw, bool win = false)
 {
+    if (win && minw < 3) return reinterpret_cast<const void*>(&k_pt_row<P, 2, true>);
     return minw >= 3 ? reinterpret_cast<const void*>(&k_pt_row<P, 3>) : reinterpret_cast<const void*>(&k_pt_row<P, 2>);
 }
 
@@ -626,7 +652,12 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     const size_t lds = pt_row_lds(L.d, L.T);
     const long grid = (long)L.R * S.wpl;
     const int minw = grid > 2L * S.ncu ? 3 : 2;             // the 168-register build only where three workgroups share a CU
-    const void* fn = pt_row_fn<P>(minw);
+    // the windowed pipeline where the WHOLE ladder's grid is at most one workgroup per CU (from T_global: a sharded ladder's blocks
+    // decide as the one-GPU run does, so both stay on one arithmetic); CARMA_TUNE_PT_ROW_WIN=0 / 1 overrides, read per launch
+    const long grid_global = (long)L.R * (((long)L.T_global + 3) / 4);
+    bool win = grid_global <= (long)S.ncu;
+    if (const char* ew = getenv("CARMA_TUNE_PT_ROW_WIN")) win = atoi(ew) != 0 && minw < 3;
+    const void* fn = pt_row_fn<P>(minw, win);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     PtLaunch La = L;

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_diag
 SRC=carma_pack_amd/csrc
-for f in carma_kernels carma_capi carma_pt carma_pt_host carma_shard carma_mle; do
+for f in carma_kernels carma_capi carma_pt carma_pt_host carma_shard carma_mle carma_post carma_pt_lane; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC ${DIAG_FLAGS:--DCARMA_STAMPS} -Iinclude -I$SRC -c $SRC/$f.hip -o build_diag/$f.o &
 done
 wait
