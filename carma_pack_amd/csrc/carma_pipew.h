@@ -23,8 +23,10 @@
 // -- a cut chunk is completed with NEUTRAL slots (h~ = c~ = 0, variance 1, innovation 0: the state does not move, the
 // sums get exactly 0) -- so an evaluation's result does not depend on its neighbours in the workgroup; the workgroup
 // runs until its slowest row is through.
-// STATUS: opt-in (CARMA_TUNE_WIN_ROWS).  Measured 29.7 us against the one-datum pipeline's 31.0 at 1024 evaluations and
-// slower beyond (profiles/r05/window_pipeline_v1.txt): not the default.
+// STATUS: the default for launches of up to one workgroup per CU (CARMA_TUNE_WIN_ROWS moves the boundary) and for the row
+// sampler where the whole ladder's grid is that small: 27.4 us against the one-datum pipeline's 29.5 per 1024 evaluations,
+// 32.6 against 31.1 * 10^3 sampler iterations/s at 16 x 64 (profiles/r05/window_pipeline_v1.txt); with more workgroups per
+// CU the one-datum pipeline is ahead and keeps those sizes.
 //
 //   waves P0, P1 (producers)   per chunk and row: schedule, exp / sincos, entries {h~_r, c~_r}, {scale yerr^2, y - mu}
 //   wave A (recursion)         [re-base]; start of the chunk; ND pivots; log-likelihood terms of the chunk
