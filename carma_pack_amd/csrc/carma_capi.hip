@@ -311,6 +311,14 @@ carma_ctx* carma_ctx_create(const double* time, const double* y, const double* y
         for (int k = 2; k < c->n; k++) rep += (s[4 * (size_t)k] == s[4 * (size_t)(k - 1)]);
         c->repeated_dt = c->n > 8 && 4 * rep >= c->n;
     }
+    if (p >= 2) {
+        // SERIES_WINDOW_OK (carma_types.h): spans of 16 - p consecutive data against the shortest window the prior admits
+        const int ND = 16 - p;
+        const double wmin = 0.5 * 600.0 / (6.283185307179586 * c->pr.max_freq);       // Pipe3LGeom::LIM_RE; the grid halves it at worst
+        long over = 0, tot = 0;
+        for (int k = 0; k + ND - 1 < c->n; k++, tot++) over += (c->t[k + ND - 1] - c->t[k]) > wmin;
+        c->window_ok = tot > 0 && 10 * over <= tot;
+    }
     hipError_t e = dev_malloc(&c->d_series, sizeof(double) * s.size());
     if (e == hipSuccess) e = hipMemcpy(c->d_series, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -386,7 +394,7 @@ int carma_logdensity_batch_dev(carma_ctx* h, const double* d_theta, int B, int i
         e = launch_logdens_car1(d_theta, B, reinterpret_cast<const double4*>(c->d_series), c->n, c->pr, d_out, st);
     else
         e = launch_logdens_carma(c->p, d_theta, B, c->d, c->q, reinterpret_cast<const double4*>(c->d_series), c->n, c->pr,
-                                 ignore_prior, d_out, st, c->repeated_dt);
+                                 ignore_prior, d_out, st, c->series_flags());
     if (e != hipSuccess) return hip_fail(e, "launch logdensity");
     return CARMA_OK;
 }
@@ -433,7 +441,7 @@ int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len)
 {
     if (!h || !buf || len < 1 || B < 1) return CARMA_EINVAL;
     const Ctx* c = reinterpret_cast<const Ctx*>(h);
-    return logdens_kernel_name(c->p, B, c->n, buf, len, c->repeated_dt) > 0 ? CARMA_OK : CARMA_EINVAL;
+    return logdens_kernel_name(c->p, B, c->n, buf, len, c->series_flags()) > 0 ? CARMA_OK : CARMA_EINVAL;
 }
 
 int carma_normalize_roots(int p, const double* omega_re_im, double* out)

@@ -63,6 +63,8 @@ struct Ctx {
     std::vector<double> t, y, yerr;   // after sort/dedup
     Prior pr{};
     bool repeated_dt = false;         // >= 25 % of the time steps equal their predecessor (regular cadence)
+    bool window_ok = false;           // the series suits the windowed wave pipeline (carma_capi.hip, carma_ctx_create)
+    int series_flags() const { return (repeated_dt ? SERIES_REPEATED_DT : 0) | (window_ok ? SERIES_WINDOW_OK : 0); }
     double* d_series = nullptr;       // records {dt, y, yerr^2, t}[n + 16 pads], then yerr^2[n + 16], y[n + 16] (carma_types.h)
     double* d_theta = nullptr;        // staging for the host-pointer entry points
     double* d_out = nullptr;

@@ -644,12 +644,12 @@ static long lpc_max_evals()
     return 64L * (nb < 3 ? nb : 3) * device_cus();
 }
 template <int P>
-static LdShape logdens_shape(long B, int n)
+static LdShape logdens_shape(long B, int n, int series_flags)
 {
     constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
-    if (rows <= win_max_rows() && n >= 8) return LdShape::WIN;
+    if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS"))) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
     if (B > lpc_min_evals<P>() && B <= lpc_max_evals<P>() && n >= 8) return LdShape::LPC;
     if (B >= lane_min_evals(P)) return LdShape::LANE;
@@ -663,8 +663,9 @@ static LdShape logdens_shape(long B, int n)
 
 template <int P>
 static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, const double4* series, int n,
-                                   const Prior& pr, int ignore_prior, double* out, hipStream_t st, bool repeated_dt)
+                                   const Prior& pr, int ignore_prior, double* out, hipStream_t st, int series_flags)
 {
+    const bool repeated_dt = (series_flags & SERIES_REPEATED_DT) != 0;
     constexpr int G = GroupOf<P>::value;
     constexpr int EPW = 64 / G;   // evaluations per wave
     const long waves = ((long)B + EPW - 1) / EPW;
@@ -678,7 +679,7 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
                            series, n, pr, ignore_prior, out);
         return hipGetLastError();
     };
-    switch (logdens_shape<P>(B, n)) {
+    switch (logdens_shape<P>(B, n, series_flags)) {
         case LdShape::P3L:
             // covariance wave + mean wave + two producer waves per four evaluations, co-rotating frame
             // (carma_pipe3l.h); 42 KiB of LDS: up to three workgroups per CU
@@ -734,11 +735,12 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
 }
 
 template <int P>
-static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
+static int logdens_name_p(long B, int n, char* buf, int len, int series_flags)
 {
+    const bool repeated_dt = (series_flags & SERIES_REPEATED_DT) != 0;
     const char* dtc = repeated_dt ? ",true" : "";
     constexpr int G = GroupOf<P>::value;
-    switch (logdens_shape<P>(B, n)) {
+    switch (logdens_shape<P>(B, n, series_flags)) {
         case LdShape::WIN: return snprintf(buf, len, "k_logdens_carma_w<%d>", P);
         case LdShape::P3L: return snprintf(buf, len, "k_logdens_carma_p3l<%d>", P);
         case LdShape::PC1: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,1>", P, G);
@@ -751,31 +753,31 @@ static int logdens_name_p(long B, int n, char* buf, int len, bool repeated_dt)
     return -1;
 }
 
-int logdens_kernel_name(int p, long B, int n, char* buf, int len, bool repeated_dt)
+int logdens_kernel_name(int p, long B, int n, char* buf, int len, int series_flags)
 {
     switch (p) {
         case 1: return snprintf(buf, len, "k_logdens_car1");     // (or its parallel-in-time form: launch_logdens_car1)
-        case 2: return logdens_name_p<2>(B, n, buf, len, repeated_dt);
-        case 3: return logdens_name_p<3>(B, n, buf, len, repeated_dt);
-        case 4: return logdens_name_p<4>(B, n, buf, len, repeated_dt);
-        case 5: return logdens_name_p<5>(B, n, buf, len, repeated_dt);
-        case 6: return logdens_name_p<6>(B, n, buf, len, repeated_dt);
-        case 7: return logdens_name_p<7>(B, n, buf, len, repeated_dt);
+        case 2: return logdens_name_p<2>(B, n, buf, len, series_flags);
+        case 3: return logdens_name_p<3>(B, n, buf, len, series_flags);
+        case 4: return logdens_name_p<4>(B, n, buf, len, series_flags);
+        case 5: return logdens_name_p<5>(B, n, buf, len, series_flags);
+        case 6: return logdens_name_p<6>(B, n, buf, len, series_flags);
+        case 7: return logdens_name_p<7>(B, n, buf, len, series_flags);
         default: return -1;
     }
 }
 
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,
-                                const Prior& pr, int ignore_prior, double* out, hipStream_t st, bool repeated_dt)
+                                const Prior& pr, int ignore_prior, double* out, hipStream_t st, int series_flags)
 {
     (void)hipGetLastError();   // HIP's last-error is sticky: drop anything left by earlier calls
     switch (p) {
-        case 2: return launch_logdens_p<2>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
-        case 3: return launch_logdens_p<3>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
-        case 4: return launch_logdens_p<4>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
-        case 5: return launch_logdens_p<5>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
-        case 6: return launch_logdens_p<6>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
-        case 7: return launch_logdens_p<7>(theta, B, d, q, series, n, pr, ignore_prior, out, st, repeated_dt);
+        case 2: return launch_logdens_p<2>(theta, B, d, q, series, n, pr, ignore_prior, out, st, series_flags);
+        case 3: return launch_logdens_p<3>(theta, B, d, q, series, n, pr, ignore_prior, out, st, series_flags);
+        case 4: return launch_logdens_p<4>(theta, B, d, q, series, n, pr, ignore_prior, out, st, series_flags);
+        case 5: return launch_logdens_p<5>(theta, B, d, q, series, n, pr, ignore_prior, out, st, series_flags);
+        case 6: return launch_logdens_p<6>(theta, B, d, q, series, n, pr, ignore_prior, out, st, series_flags);
+        case 7: return launch_logdens_p<7>(theta, B, d, q, series, n, pr, ignore_prior, out, st, series_flags);
         default: return hipErrorInvalidValue;
     }
 }

@@ -12,10 +12,10 @@ int device_cus();
 // repeated_dt: a good part of the series' time steps equal their predecessor (regular cadence): the throughput kernels
 // then run the variant that re-uses the transition factors of such steps (carma_core.h, RhoInline DTC)
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,
-                                const Prior& pr, int ignore_prior, double* out, hipStream_t st, bool repeated_dt = false);
+                                const Prior& pr, int ignore_prior, double* out, hipStream_t st, int series_flags = 0);
 // name of the kernel launch_logdens_* picks for B evaluations of a series of n points (as rocprofv3 prints it, up to
 // the namespace and the argument list)
-int logdens_kernel_name(int p, long B, int n, char* buf, int len, bool repeated_dt = false);
+int logdens_kernel_name(int p, long B, int n, char* buf, int len, int series_flags = 0);
 hipError_t launch_logdens_car1(const double* theta, int B, const double4* series, int n, const Prior& pr, double* out,
                                hipStream_t st);
 hipError_t launch_kfilter_carma(int p, const double* om_re_im, const double* ma, double sigsqr, const double4* series,
@@ -58,6 +58,6 @@ hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const dou
 size_t pt_lane_scratch_doubles(int d, long nchain);
 hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const double4* series, const Prior& pr,
                           const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
-                          unsigned* nswap, double* samples, double* sample_lp, bool repeated_dt, hipStream_t st);
+                          unsigned* nswap, double* samples, double* sample_lp, int series_flags, hipStream_t st);
 
 }  // namespace carma

@@ -167,7 +167,7 @@ static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save
     const PtLaunch L = pt_launch_args(c, ch, do_exchange, thin, save_offset ? *save_offset : 0);
     hipError_t e;
     if (s->use_row) {
-        PtRowSync S{s->d_stage, s->d_abort, ++s->epoch, s->wpl, device_cus(), 1, 0};
+        PtRowSync S{s->d_stage, s->d_abort, ++s->epoch, s->wpl, device_cus(), 1, c->window_ok ? 1 : 0, 0};
         e = launch_pt_row(c->p, L, S, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
                           s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
         if (e == hipErrorCooperativeLaunchTooLarge) {      // the grid is not co-resident on this device: ladder kernel
@@ -177,7 +177,7 @@ static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save
     }
     if (!s->use_row && s->use_lane) {
         e = launch_pt_lane(c->p, L, s->d_lane_scratch, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta,
-                           s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->repeated_dt, st);
+                           s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->series_flags(), st);
     } else if (!s->use_row) {
         e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
                       s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);

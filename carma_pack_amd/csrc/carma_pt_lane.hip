@@ -341,7 +341,7 @@ static hipError_t ram_launch_d(int d, F&& f)
 // either end.  The iterations, the save slots and the Philox keys are those of launch_pt for the same PtLaunch.
 hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const double4* series, const Prior& pr,
                           const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
-                          unsigned* nswap, double* samples, double* sample_lp, bool repeated_dt, hipStream_t st)
+                          unsigned* nswap, double* samples, double* sample_lp, int series_flags, hipStream_t st)
 {
     (void)hipGetLastError();
     if (p < 1 || L.T < 1 || L.T > 64 || L.d < 4 || L.d > RAM_DMAX || (p == 1) != (L.d == 4)) return hipErrorInvalidValue;
@@ -369,7 +369,7 @@ hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const doubl
             });
         if (e == hipSuccess)
             e = p == 1 ? launch_logdens_car1(S.thn, (int)nc, series, L.n, pr, S.ll, st)
-                       : launch_logdens_carma(p, S.thn, (int)nc, L.d, L.q, series, L.n, pr, 0, S.ll, st, repeated_dt);
+                       : launch_logdens_carma(p, S.thn, (int)nc, L.d, L.q, series, L.n, pr, 0, S.ll, st, series_flags);
         if (e == hipSuccess) {
             const bool next = fused && it + 1 < L.niter;
             e = ram_launch_d(L.d, [&](auto dc) {

@@ -30,6 +30,15 @@ inline
     return r >= 11 ? 16 - r : 0;
 }
 
+// What the launchers know about the series of a context (carma_ctx_create), as bits:
+//   SERIES_REPEATED_DT  >= 25 % of the time steps equal their predecessor (the regular-cadence variants of the throughput kernels)
+//   SERIES_WINDOW_OK    the windowed wave pipeline (carma_pipew.h) suits it: a chunk of 16 - p consecutive data is, for 90 % of the
+//                       chunks, no longer than the SHORTEST window the prior admits (half of LIM_RE / (2 pi max_freq)).  Otherwise the
+//                       rows with short windows cut their chunks and re-base at every chunk start, and a launch -- or a ladder's
+//                       rendezvous -- waits for them: BASELINE configs[3]'s series (min dt 0.1, median 1.1) ran 464 instead of 780
+//                       sampler iterations/s on that pipeline.
+constexpr int SERIES_REPEATED_DT = 1, SERIES_WINDOW_OK = 2;
+
 // Arguments of one launch of the persistent PT kernel.
 struct PtLaunch {
     int d, q, n;                 // parameter dimension, MA order, series length
@@ -56,6 +65,7 @@ struct PtRowSync {
     int wpl;                 // workgroups per ladder = ceil(T / 4)
     int ncu;                 // compute units of the device: workgroups i, i + ncu, i + 2 ncu share a CU
     int xcd_map;             // > 1: a ladder's workgroups sit xcd_map blocks apart (same XCD), see k_pt_row
+    int window_ok;           // the context's series suits the windowed pipeline (SERIES_WINDOW_OK)
     int rot;                 // which wave plays which part in the second (bits 0-7) and third (bits 8-15) workgroup of a CU:
                              // 2 bits per wave, set by the launcher (the placement differs between launch kinds)
 };
