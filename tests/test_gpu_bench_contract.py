@@ -59,6 +59,8 @@ def test_single_gpu_line():
         assert {"valu_issue_frac", "fp64_frac", "fp64_tflops"} <= set(blk)
         for k in ("valu_issue_frac", "fp64_frac"):
             assert blk[k] is None or 0.0 < blk[k] <= 1.0, (k, blk[k])
+    st = j["steady_state"]
+    assert st["launches"] == 1000 and 0.8 * j["value"] < st["evals_per_s"] < 1.3 * j["value"]
     t1 = j["throughput_1m"]
     assert t1["batch_per_gpu"] == 1 << 20 and t1["finite"] > 0.5 * (1 << 20) and t1["evals_per_s"] > j["throughput"]["evals_per_s"]
     assert j["build"]["build_id"] and j["rccl_first_contact"]["verdict"] == "one rank: no exchange"
