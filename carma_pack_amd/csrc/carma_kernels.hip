@@ -26,7 +26,6 @@
 #include "carma_pipe3l.h"
 #include "carma_pipew.h"
 #include "carma_lane.h"
-#include "carma_lane_frame.h"
 #include "carma_launch.h"
 
 namespace carma {
@@ -250,42 +249,6 @@ __global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restr
         return;
     }
     const double ll = logdensity_lane_ring<P, NP, REPDT>(theta + e * d, q, series, n, pr, ignore_prior, ring);
-    if (live) out[e] = ll;
-}
-
-// The producer-wave kernel in a CO-ROTATING FRAME (round 5, carma_lane_frame.h): no rotation of the matrix, the consumer's step
-// is ~80 arithmetic instructions instead of ~146, the producers' datum ~215 instead of ~150 -- so the split needs more
-// producers: NP = 6 (seven waves; while a CU holds one workgroup, i.e. up to 64 x #CUs evaluations) or NP = 3 (four waves, two
-// workgroups per CU: the registers allow eight waves per CU).  For series without repeated time steps (a regular cadence keeps
-// the kernel above, which re-uses a repeated step's factors).  The same frame with everything in line (lane_filter_frame) is
-// no faster than the rotating lane kernel -- what the recursion saves, the two vectors per datum cost (measured: 257 against
-// 221 us at 65 536 evaluations) -- and is not a kernel: the test harness compiles it for the host.
-template <int P, int NP>
-__global__ __launch_bounds__(64 * (1 + NP)) __attribute__((amdgpu_waves_per_eu(P <= 6 ? 2 : 1))) void k_logdens_carma_lpcf(
-    const double* __restrict__ theta, int B, int d, int q, const double4* __restrict__ series, int n, Prior pr, int ignore_prior,
-    double* __restrict__ out, int ncu, int rot)
-{
-    constexpr int CH = LaneFrameCH<P, NP>::value;
-    extern __shared__ double lpc_ring[];
-    const int lane = threadIdx.x & 63;
-    int part = (int)(threadIdx.x >> 6);                       // 0: the consumer
-    if (NP == 3) {
-        // (two workgroups per CU: which wave plays which part rotates with the round of workgroups, k_logdens_carma_lpc)
-        const int round = (int)(blockIdx.x / (unsigned)ncu);
-        part = (part + ((rot >> (4 * (round & 3))) & 3)) & 3;
-    }
-    long e = (long)blockIdx.x * 64 + lane;
-    const bool live = e < B;
-    if (!live) e = B - 1;
-    __shared__ double s_tab[MATH_TAB_N];
-    math_tab_fill(s_tab);
-    __syncthreads();
-    if (part >= 1) {
-        lane_frame_produce<P, NP, CH>(part - 1, theta + e * d, q, pr, ignore_prior, lpc_ring, series, n, s_tab);
-        return;
-    }
-    __builtin_amdgcn_s_setprio(3);                            // ahead of the producer that shares its SIMD
-    const double ll = logdensity_lane_frame_ring<P, NP, CH>(theta + e * d, q, series, n, pr, ignore_prior, lpc_ring);
     if (live) out[e] = ll;
 }
 
@@ -680,14 +643,6 @@ static long lpc_max_evals()
     }
     return 64L * (nb < 3 ? nb : 3) * device_cus();
 }
-// The producer-wave kernel runs in the co-rotating frame (carma_lane_frame.h) unless the series has repeated time steps;
-// CARMA_TUNE_LANE_FRAME=0 keeps the rotating kernel (read at EVERY launch: the parity tests run both in one process).
-static bool lane_frame_on(int series_flags)
-{
-    if (series_flags & SERIES_REPEATED_DT) return false;
-    const char* e = getenv("CARMA_TUNE_LANE_FRAME");
-    return e ? atoi(e) != 0 : true;
-}
 template <int P>
 static LdShape logdens_shape(long B, int n, int series_flags)
 {
@@ -759,23 +714,9 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
         case LdShape::LPC: {
             using Geo = LaneRingGeom<P, 3>;
             static_assert(Geo::BYTES <= 64 * 1024, "within the LDS a launch may ask for without raising the kernel's limit");
-            using GeoF3 = LaneFrameRingGeom<P, 3, LaneFrameCH<P, 3>::value>;
-            using GeoF6 = LaneFrameRingGeom<P, 6, LaneFrameCH<P, 6>::value>;
-            static_assert(GeoF3::BYTES <= 64 * 1024, "within the LDS a launch may ask for without raising the kernel's limit");
             if (repeated_dt)
                 hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3, true>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta,
                                    B, d, q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
-            else if (lane_frame_on(series_flags) && B <= 64L * device_cus()) {
-                if (GeoF6::BYTES > 64 * 1024) {               // (p = 6, 7: 72 / 84 KiB, one workgroup per CU)
-                    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_lpcf<P, 6>),
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GeoF6::BYTES);
-                    if (ea != hipSuccess) return ea;
-                }
-                hipLaunchKernelGGL((k_logdens_carma_lpcf<P, 6>), dim3((unsigned)(((long)B + 63) / 64)), dim3(448), GeoF6::BYTES, st, theta, B,
-                                   d, q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
-            } else if (lane_frame_on(series_flags))
-                hipLaunchKernelGGL((k_logdens_carma_lpcf<P, 3>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), GeoF3::BYTES, st, theta, B,
-                                   d, q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
             else
                 hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta, B, d,
                                    q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
@@ -807,9 +748,7 @@ static int logdens_name_p(long B, int n, char* buf, int len, int series_flags)
         case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1%s>", P, G, dtc);
         case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4%s>", P, G, dtc);
         case LdShape::LANE: return snprintf(buf, len, "k_logdens_carma_lane<%d%s>", P, dtc);
-        case LdShape::LPC:
-            if (lane_frame_on(series_flags)) return snprintf(buf, len, "k_logdens_carma_lpcf<%d,%d>", P, B <= 64L * device_cus() ? 6 : 3);
-            return snprintf(buf, len, "k_logdens_carma_lpc<%d,3%s>", P, dtc);
+        case LdShape::LPC: return snprintf(buf, len, "k_logdens_carma_lpc<%d,3%s>", P, dtc);
     }
     return -1;
 }

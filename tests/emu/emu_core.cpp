@@ -6,7 +6,6 @@
 #include "grp_emu.h"
 #include "../../carma_pack_amd/csrc/carma_core.h"
 #include "../../carma_pack_amd/csrc/carma_lane.h"
-#include "../../carma_pack_amd/csrc/carma_lane_frame.h"
 
 using namespace carma;
 
@@ -75,28 +74,6 @@ extern "C" int emu_logdensity_carma_lane(int p, int q, const double* theta, int 
             case 5: out[b] = logdensity_lane<5>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
             case 6: out[b] = logdensity_lane<6>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
             case 7: out[b] = logdensity_lane<7>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
-            default: return -1;
-        }
-    }
-    return 0;
-}
-
-// the same in the co-rotating frame (carma_lane_frame.h)
-extern "C" int emu_logdensity_carma_lane_frame(int p, int q, const double* theta, int B, const double* series, int n, const double* prior,
-                                               int ignore_prior, double* out)
-{
-    Prior pr{prior[0], prior[1], prior[2], prior[3]};
-    const double4* s4 = reinterpret_cast<const double4*>(series);
-    const int d = 3 + p + q;
-    for (int b = 0; b < B; b++) {
-        const double* th = theta + (size_t)b * d;
-        switch (p) {
-            case 2: out[b] = logdensity_lane_frame<2>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
-            case 3: out[b] = logdensity_lane_frame<3>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
-            case 4: out[b] = logdensity_lane_frame<4>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
-            case 5: out[b] = logdensity_lane_frame<5>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
-            case 6: out[b] = logdensity_lane_frame<6>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
-            case 7: out[b] = logdensity_lane_frame<7>(th, q, s4, n, pr, ignore_prior, h_math_tab); break;
             default: return -1;
         }
     }

@@ -48,15 +48,13 @@ def logdensity_carma(t, y, yerr, p, q, thetas, prior, ignore_prior=False):
     return out
 
 
-def logdensity_carma_lane(t, y, yerr, p, q, thetas, prior, ignore_prior=False, frame=False):
-    """Same evaluation through the one-evaluation-per-lane code of the throughput regime (carma_lane.h; frame: its co-rotating
-    form, carma_lane_frame.h)."""
+def logdensity_carma_lane(t, y, yerr, p, q, thetas, prior, ignore_prior=False):
+    """Same evaluation through the one-evaluation-per-lane code of the throughput regime (carma_lane.h)."""
     s = pack_series(t, y, yerr)
     th = np.ascontiguousarray(thetas, dtype=float).reshape(-1, 3 + p + q)
     pr = np.array(list(prior) + [50.0])
     out = np.empty(th.shape[0])
-    fn = lib().emu_logdensity_carma_lane_frame if frame else lib().emu_logdensity_carma_lane
-    rc = fn(p, q, _p(th), th.shape[0], _p(s), t.size, _p(pr), int(ignore_prior), _p(out))
+    rc = lib().emu_logdensity_carma_lane(p, q, _p(th), th.shape[0], _p(s), t.size, _p(pr), int(ignore_prior), _p(out))
     assert rc == 0
     return out
 

@@ -132,9 +132,8 @@ def test_emu_predict_orders(p, q):
     np.testing.assert_allclose(a[1], b[1], rtol=1e-8)
 
 
-@pytest.mark.parametrize("frame", [False, True], ids=["rotating", "frame"])
 @pytest.mark.parametrize("p,q", [(2, 0), (2, 1), (3, 2), (4, 1), (4, 3), (5, 3), (6, 2), (6, 5), (7, 3), (7, 6)])
-def test_lane_code_matches_oracle(p, q, frame, golden_dir):
+def test_lane_code_matches_oracle(p, q, golden_dir):
     """carma_lane.h -- one evaluation per lane, the throughput regime's kernel body (plain scalar code, so the host runs
     the very functions the GPU compiles) -- against the oracle on prior-like and golden parameter vectors, with the bounds
     on and off, real root pairs included, and against the lane-group loop it must agree with to rounding."""
@@ -154,7 +153,7 @@ def test_lane_code_matches_oracle(p, q, frame, golden_dir):
     m = orc.OracleModel(t, y, yerr, p, q)
     pr = (m.max_stdev, m.max_freq, m.min_freq)
     for ign in (False, True):
-        got = emu.logdensity_carma_lane(t, y, yerr, p, q, th, pr, ignore_prior=ign, frame=frame)
+        got = emu.logdensity_carma_lane(t, y, yerr, p, q, th, pr, ignore_prior=ign)
         want = m.logdensity_batch(th, ignore_prior=ign)
         assert_parity(got, want, 1e-10, "lane p=%d q=%d" % (p, q), arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0],
                       max_arb_frac=0.1)
@@ -165,48 +164,6 @@ def test_lane_code_matches_oracle(p, q, frame, golden_dir):
         # each closer to the exact value than the oracle -- the arbiter above has seen them)
         rel = np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])
         assert np.all(rel <= 1e-6) and np.sum(rel > 1e-9) <= 2, rel
-
-
-def _frame_rebases(t, roots):
-    """carma_lane_frame.h's re-base rule restated: data further than W = 2^-ex from the lane's base."""
-    wl = max(np.max(np.abs(roots.real)) / 600.0, np.max(np.abs(roots.imag)) / 65536.0)
-    W = 1.0 / 2.0 ** np.frexp(wl)[1]
-    base, k = t[0], 0
-    for tj in t[1:]:
-        if tj - base > W:
-            base, k = tj, k + 1
-    return k
-
-
-@pytest.mark.parametrize("p,q", [(2, 1), (5, 3), (6, 5), (7, 6)])
-def test_lane_frame_rebases(p, q):
-    """The co-rotating lane code on series that force re-bases (long, with gaps of every size), prior-like vectors whose fastest
-    root leaves its window tens of times, real root pairs included: against the oracle, arbitrated in quad precision."""
-    from helpers import loglik_truth
-    rng = np.random.default_rng(100 * p + q)
-    dt = rng.uniform(0.5, 2.0, 599)
-    dt[rng.integers(0, 599, 12)] *= 10.0 ** rng.uniform(1, 4, 12)          # gaps from 10 to 10^4 steps
-    t = np.concatenate([[3.0], 3.0 + np.cumsum(dt)])
-    y = 5.0 + np.sin(t / 11.0) + 0.5 * rng.standard_normal(t.size)
-    yerr = rng.uniform(0.2, 0.6, t.size)
-    th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(16)])
-    th[-1, 3:5] = [np.log(0.02), np.log(0.5)]                               # a quadratic factor with two real roots
-    for i in range(8):                                                      # a fast first pair: window of a few tens of data
-        re_, im_ = -2 * np.pi * rng.uniform(0.2, 0.8), 2 * np.pi * rng.uniform(0.05, 0.4)
-        th[i, 3:5] = [np.log(re_ * re_ + im_ * im_), np.log(-2.0 * re_)]
-    m = orc.OracleModel(t, y, yerr, p, q)
-    pr = (m.max_stdev, m.max_freq, m.min_freq)
-    nreb = np.array([_frame_rebases(t, orc.ar_roots(v, p)) for v in th])
-    assert np.sum(nreb >= 8) >= 8, nreb                                     # the test does what its name says
-    got = emu.logdensity_carma_lane(t, y, yerr, p, q, th, pr, ignore_prior=True, frame=True)
-    want = m.logdensity_batch(th, ignore_prior=True)
-    assert_parity(got, want, 1e-10, "lane frame, re-bases p=%d q=%d" % (p, q),
-                  arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.15)
-    rot = emu.logdensity_carma_lane(t, y, yerr, p, q, th, pr, ignore_prior=True)
-    fin = np.isfinite(rot)
-    assert np.array_equal(np.isfinite(got), fin)
-    rel = np.abs(got[fin] - rot[fin]) / np.abs(rot[fin])
-    assert np.all(rel <= 1e-6) and np.sum(rel > 1e-9) <= 2, rel
 
 
 def test_lane_code_regular_cadence():
