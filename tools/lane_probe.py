@@ -13,7 +13,8 @@ if os.environ.get('LANE_PROBE_REGULAR'):      # constant cadence: the transition
     t = np.floor(t[0]) + 2.0 * np.arange(len(t))      # (exact differences: every step repeats)
 P, Q = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5, 3)
 ctx = cpa.Context(t, y, yerr, P, Q, max_stdev=10*np.sqrt(np.mean(y*y)-np.mean(y)**2))
-base = theta_batch(np.random.default_rng(2), 4096, P, Q, t, y, theta_center=g['theta'][0] if (P, Q) == (5, 3) else None)
+base = theta_batch(np.random.default_rng(2), 4096, P, Q, t, y, theta_center=g['theta'][0] if (P, Q) == (5, 3) else None,
+                   frac_post=float(os.environ.get('LANE_PROBE_POST', '0.5')))      # 1.0: posterior-like vectors only
 import oracle as orc
 m = orc.OracleModel(t, y, yerr, P, Q, max_stdev=ctx.prior()[0])
 want = m.logdensity_batch(base[:512], nthreads=8)
