@@ -137,8 +137,10 @@ def main():
             ctx.logdensity_dev(pool[i % NPOOL].data_ptr(), B, outs[i & 1].data_ptr(), ignore_prior=False, stream=s2[i & 1].cuda_stream)
         torch.cuda.synchronize()
         barrier()
+        # (a secondary leg with its own launch count: 20 launches would not amortise the closing synchronisation of two streams)
+        PSTEPS = max(args.steps, 200)
         tp0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(PSTEPS):
             ctx.logdensity_dev(pool[i % NPOOL].data_ptr(), B, outs[i & 1].data_ptr(), ignore_prior=False, stream=s2[i & 1].cuda_stream)
         torch.cuda.synchronize()
         barrier()
@@ -148,8 +150,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tp = float(tt.item())
         pipelined = {"metric": "Kalman log-lik evals/sec, the same %d-evaluation batches, two in flight (two streams)" % B,
-                     "evals_per_s": world * B * args.steps / tp, "ms_per_step": 1e3 * tp / args.steps, "streams": 2,
-                     "steps": args.steps}
+                     "evals_per_s": world * B * PSTEPS / tp, "ms_per_step": 1e3 * tp / PSTEPS, "streams": 2,
+                     "steps": PSTEPS}
 
     # ---- throughput regime: the same kernel family with the chip full (B = 65536 per launch) ----------------
     tput = None
@@ -157,7 +159,9 @@ def main():
         BT = 65536
         big = torch.from_numpy(np.tile(pool_h[0], (BT // B + 1, 1))[:BT].copy()).to(dev)
         outb = torch.empty(BT, dtype=torch.float64, device=dev)
-        for _ in range(3):
+        # (40 untimed launches, 9 ms: with every SIMD full of FP64 work the clocks settle over milliseconds -- behind a 20-step
+        # run the first launches of this leg took 240 us where they take 216 behind a 200-step run, profiles/r05/bench_*_v4.json)
+        for _ in range(40):
             ctx.logdensity_dev(big.data_ptr(), BT, outb.data_ptr(), ignore_prior=False, stream=sh)
         torch.cuda.synchronize()
         barrier()

@@ -1,8 +1,8 @@
-"""The windowed wave pipeline (carma_pipew.h, k_logdens_carma_w<P>; opt-in through CARMA_TUNE_WIN_ROWS -- round 5's blocked form
-of kfilter.cpp:189-215, measured and NOT made the default: profiles/r05/window_pipeline_v1.txt) against the oracle, so that the
-path stays correct while it waits for a cheaper producer: every order, posterior-like and prior-like parameters (re-base data
-open chunks, rows of a workgroup end at different chunk counts), a series long enough for hundreds of chunks, the prior's -inf
-pattern.  The tuning variable is read once per process, hence the child process."""
+"""The windowed wave pipeline (carma_pipew.h, k_logdens_carma_w<P>: round 5's blocked form of kfilter.cpp:189-215, the default up to
+one workgroup per CU for series whose sampling suits it) FORCED on every launch size through CARMA_TUNE_WIN_ROWS, against the oracle:
+every order, posterior-like and prior-like parameters (re-base data open chunks, rows of a workgroup end at different chunk
+counts), a series long enough for hundreds of chunks, the prior's -inf pattern, and a series on which the dispatch itself would
+NOT take it (SERIES_WINDOW_OK, carma_types.h).  The tuning variable is part of the child's environment."""
 import json
 import os
 import subprocess
@@ -69,3 +69,31 @@ def test_window_pipeline_long_series():
     got = _window(t, y, e, 5, 2, ms, th, True)
     assert_parity(got, m.logdensity_batch(th, ignore_prior=True), 1e-10, "window pipeline, n = 3000",
                   arbiter=lambda k: loglik_truth(t, y, e, th[k], 5, 2)[0], arb_factor=1.25, max_arb_frac=0.06)
+
+
+def test_series_window_criterion():
+    """SERIES_WINDOW_OK (set at context creation: 90 % of the spans of 16 - p consecutive data within half a re-base window of the
+    prior's fastest root).  The README series has it: window pipeline up to one workgroup per CU.  BASELINE configs[3]'s series
+    (time steps 0.1 + |Cauchy|, max_freq = 10) does not: the one-datum pipeline at every size -- and the window pipeline, forced,
+    is still right on it (most of its chunks are cut short there: slow, not wrong)."""
+    import carma_pack_amd as cpa
+    from carma_pack_amd.synth import config4_series
+    from helpers import assert_parity, loglik_truth, prior_like_theta
+    if os.environ.get("CARMA_TUNE_WIN_ROWS") is not None:
+        pytest.skip("the dispatch under test is overridden by CARMA_TUNE_WIN_ROWS")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "carma53_readme.npz"))
+    ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3)
+    assert ctx.kernel_name(1024) == "k_logdens_carma_w<5>" and ctx.kernel_name(1025) == "k_logdens_carma_p3l<5>"
+    t, y, e, _ = config4_series(1500, seed=4)
+    ms = 10.0 * y.std()
+    c4 = cpa.Context(t, y, e, 7, 6, max_stdev=ms)
+    assert c4.kernel_name(64) == "k_logdens_carma_p3l<7>" and c4.kernel_name(1024) == "k_logdens_carma_p3l<7>"
+    rng = np.random.default_rng(77)
+    th = np.array([prior_like_theta(rng, 7, 6, t, y) for _ in range(40)])
+    m = orc.OracleModel(t, y, e, 7, 6, max_stdev=ms)
+    want = m.logdensity_batch(th, ignore_prior=True)
+    arb = lambda k: loglik_truth(t, y, e, th[k], 7, 6)[0]   # noqa: E731
+    assert_parity(c4.logdensity(th, ignore_prior=True), want, 1e-10, "configs[3]-like series, dispatch", arbiter=arb, arb_factor=1.25,
+                  max_arb_frac=0.1)
+    assert_parity(_window(t, y, e, 7, 6, ms, th, True), want, 1e-10, "configs[3]-like series, window pipeline forced", arbiter=arb,
+                  arb_factor=1.25, max_arb_frac=0.1)
