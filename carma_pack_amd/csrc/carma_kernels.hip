@@ -226,7 +226,9 @@ __global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restr
 // Which wave plays which part rotates with the round of workgroups (blockIdx against the CU count): the waves of the
 // workgroups that share a CU land on its SIMDs in a fixed pattern (tools/ubench/wave_placement.hip), and two consumers
 // on one SIMD would wait for each other.
-template <int P, int NP, bool REPDT = false>
+// UNROLLED: the consumer takes a ring buffer of six steps as one basic block (carma_lane.h, LaneFactorsRing) -- launches of up to
+// one workgroup per CU.
+template <int P, int NP, bool REPDT = false, bool UNROLLED = false>
 __global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restrict__ theta, int B, int d, int q,
                                                            const double4* __restrict__ series, int n, Prior pr,
                                                            int ignore_prior, double* __restrict__ out, int ncu, int rot)
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_logdens_carma_lpc(const double* __restr
         lane_produce<P, NP, REPDT>((part - Geo::NC) % NP, theta + e * d, ring, series, n, s_tab);
         return;
     }
-    const double ll = logdensity_lane_ring<P, NP, REPDT>(theta + e * d, q, series, n, pr, ignore_prior, ring);
+    const double ll = logdensity_lane_ring<P, NP, REPDT, UNROLLED>(theta + e * d, q, series, n, pr, ignore_prior, ring);
     if (live) out[e] = ll;
 }
 
@@ -617,7 +619,11 @@ static long lpc_min_evals()
     //   p = 2, 3   from 12 x #CUs evaluations (3073):  50 / 62 us flat up to 16 384 against 62-68 / 67-89 (pair kernel, lane groups)
     //   p = 4      from 32 x #CUs (8193):              88 us against 90-93
     //   p >= 5     from 32 x #CUs (8193), as in round 3: below, the lane-group kernel's 104-112 us are ahead of 107-160
+    // Round 5, the consumer takes a ring buffer as one basic block (LaneFactorsRing, UNROLLED: 110 -> 92 us at p = 5):
+    //   p = 5      from 16 x #CUs (4097): 89-90 us flat against 99-103 for the lane groups (8192: 8.0 -> 9.1e7 evals/s)
+    //   p = 4, 6, 7  as before (72 against 71-73; 118 against 104-106; 142 against 109-113: profiles/r05/lpc_min_probe_v1.txt)
     if (P <= 3) return 12L * device_cus();
+    if (P == 5) return 16L * device_cus();
     return 32L * device_cus();
 }
 template <int P>
@@ -717,6 +723,9 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             if (repeated_dt)
                 hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3, true>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta,
                                    B, d, q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
+            else if ((long)B <= 64L * device_cus())
+                hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3, false, true>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES,
+                                   st, theta, B, d, q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
             else
                 hipLaunchKernelGGL((k_logdens_carma_lpc<P, 3>), dim3((unsigned)(((long)B + 63) / 64)), dim3(256), Geo::BYTES, st, theta, B, d,
                                    q, series, n, pr, ignore_prior, out, device_cus(), lpc_rot());
@@ -748,6 +757,7 @@ static int logdens_name_p(long B, int n, char* buf, int len, int series_flags)
         case LdShape::PLAIN1: return snprintf(buf, len, "k_logdens_carma<%d,%d,1%s>", P, G, dtc);
         case LdShape::PLAIN4: return snprintf(buf, len, "k_logdens_carma<%d,%d,4%s>", P, G, dtc);
         case LdShape::LANE: return snprintf(buf, len, "k_logdens_carma_lane<%d%s>", P, dtc);
+        // (up to one workgroup per CU its UNROLLED instantiation, <P,3,false,true>: the same kernel, the same bits)
         case LdShape::LPC: return snprintf(buf, len, "k_logdens_carma_lpc<%d,3%s>", P, dtc);
     }
     return -1;

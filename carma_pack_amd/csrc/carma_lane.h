@@ -183,6 +183,7 @@ CARMA_DEV void lane_factors(const double (&wre)[P], const double (&wim)[P], cons
 // Where lane_filter takes a NEW time step's factors from.  LaneFactorsInline: the lane computes them itself.
 template <int P>
 struct LaneFactorsInline {
+    static constexpr int UNROLL = 1;
     const LaneModel<P>& m;
     bool anyreal;
     const double* tab;
@@ -219,10 +220,32 @@ struct LaneRingGeom {
     static constexpr size_t DOUBLES = (size_t)2 * CH * NV * 64;                    // per consumer
     static constexpr size_t BYTES = NC * DOUBLES * sizeof(double);                 // p = 5: 56 KiB (NP = 1), 42 KiB (NP = 3)
 };
-template <int P, int NP>
+template <int P, int NP, bool UNROLLED = false>
 struct LaneFactorsRing {
     using Geo = LaneRingGeom<P, NP>;
+    // UNROLLED (round 5): lane_filter takes a whole buffer of CH steps as ONE basic block (series without repeated time steps) --
+    // the barrier in front, the slots at compile-time offsets, the reads of the later steps' factors move up across the earlier
+    // steps: 110 -> 95 us at p = 5 while a CU holds one workgroup (profiles/r05/ab_lpc_unroll_v1.txt; p = 3: 64 -> 55, p = 7:
+    // 165 -> 147); with two workgroups per CU the step-by-step loop is 1-4 % ahead and stays.  Same bits.
+    static constexpr int UNROLL = UNROLLED ? Geo::CH : 1;
     const double* ring;                                       // [2][CH][NV][64], + lane
+    CARMA_DEV const double* chunk(int c) const
+    {
+        __syncthreads();                                      // barrier c: chunk c is in the ring
+        return ring + (size_t)((c & 1) * Geo::CH) * Geo::NV * 64;
+    }
+    CARMA_DEV static void get_at(const double* cb, int s, double (&cr)[P], double (&sr)[P])
+    {
+        const double* b = cb + (size_t)s * Geo::NV * 64;
+#pragma unroll
+        for (int r = 0; r < P; r++) cr[r] = b[r * 64];
+#pragma unroll
+        for (int i = 0; i < P / 2; i++) {
+            const double sv = b[(P + i) * 64];
+            sr[2 * i] = sv;
+            sr[2 * i + 1] = -sv;
+        }
+    }
     CARMA_DEV void step(int kk) const
     {
         if ((kk - 1) % Geo::CH == 0) __syncthreads();          // barrier c: chunk c is in the ring
@@ -263,6 +286,12 @@ __device__ __forceinline__ void lane_produce(int k, const double* theta, double*
     anyreal = __builtin_amdgcn_ballot_w64(anyreal) != 0;
     const int nc = (n - 1 + Geo::CH - 1) / Geo::CH;
     for (int c = 0; c < nc; c++) {
+#if defined(CARMA_AB_NOPROD)                                  // timing-only A/B build: the consumer alone
+        if (c >= 2) {
+            __syncthreads();
+            continue;
+        }
+#endif
 #pragma unroll 1
         for (int s = k; s < Geo::CH; s += NP) {
             const int kk = 1 + c * Geo::CH + s;
@@ -317,7 +346,90 @@ CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ 
     acc.init();
     double4 rprev = series[0];
     double dt_prev = -1.0;                                   // (a time step is never negative)
-    for (int kk = 1; kk < n; kk++) {
+    int kk0 = 1;
+    if constexpr (Src::UNROLL > 1 && !REPDT && !WRITE_MV) {
+        // Whole ring buffers, U steps as one basic block.  (The statements of the loop below, once more: routing BOTH loops through
+        // one body cost the in-line kernel 5 % at 65 536 evaluations -- profiles/r05/ab_lpc_unroll_v2.txt -- so that loop stays as it is.)
+        constexpr int U = Src::UNROLL;
+        for (; kk0 + U <= n; kk0 += U) {                      // (kk0 - 1 is a multiple of U)
+            const double* cb = src.chunk((kk0 - 1) / U);
+#pragma unroll
+            for (int us = 0; us < U; us++) {
+                const int kk = kk0 + us;
+                const double4 rec = series[kk];
+                Src::get_at(cb, us, cr, sr);
+            // --- var_{kk-1} = s0 + h D h^T + e, mean_{kk-1} = h.z   (kfilter.cpp:180-184, 207-213)
+            double pv = 0.0, pm = 0.0;
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                pv = fma(m.h[r], w[r], pv);
+                pm = fma(m.h[r], z[r], pm);
+            }
+            const double var = m.s0 + pv + rprev.z * m.scale;
+            const double innov = (rprev.y - m.mu) - pm;
+            if constexpr (WRITE_MV) {
+                mv[(long)(kk - 1) * mv_stride] = pm + m.mu;
+                mv[(long)(n + kk - 1) * mv_stride] = var;
+            }
+            acc.add_var(var);
+            const double s = recip(var);
+            const double si = s * innov;
+            acc.chi2 += innov * si;
+            // --- state (kfilter.cpp:191-194, 200-201)
+            double zu[P];
+#pragma unroll
+            for (int r = 0; r < P; r++) zu[r] = fma(k[r], si, z[r]);
+#pragma unroll
+            for (int r = 0; r < P; r++) z[r] = (r < PE) ? cr[r] * zu[r] - sr[r] * zu[r ^ 1] : cr[r] * zu[r];
+            // --- covariance (kfilter.cpp:197, 204): d = D - k k^T / var (upper triangle), mm = d Phi^T, D = Phi mm
+            double d[NT];
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const double t = k[i] * s;
+#pragma unroll
+                for (int j = i; j < P; j++) d[tri<P>(i, j)] = fma(-t, k[j], D[tri<P>(i, j)]);
+            }
+            // mm_ij for j >= i, and below the diagonal the one entry a pair's even row needs from its partner: (i + 1, i)
+            double mm[P][P];
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+#pragma unroll
+                for (int j = 0; j < P; j++) {
+                    const bool need = (j >= i) || (j == i - 1 && (i & 1) && i < PE);
+                    if (need) {
+                        if (j < PE)
+                            mm[i][j] = d[tri<P>(i, j)] * cr[j] - d[tri<P>(i, j ^ 1)] * sr[j];
+                        else
+                            mm[i][j] = d[tri<P>(i, j)] * cr[j];
+                    } else {
+                        mm[i][j] = 0.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+#pragma unroll
+                for (int j = i; j < P; j++) {
+                    if (i < PE)
+                        D[tri<P>(i, j)] = cr[i] * mm[i][j] - sr[i] * mm[i ^ 1][j];
+                    else
+                        D[tri<P>(i, j)] = cr[i] * mm[i][j];
+                }
+            }
+            // --- w = D h, gain of the next step k = w + c   (kfilter.cpp:191 of the next Update)
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < P; j++) a = fma(D[tri<P>(i, j)], m.h[j], a);
+                w[i] = a;
+                k[i] = a + m.c[i];
+            }
+                rprev = rec;
+            }
+        }
+    }
+    for (int kk = kk0; kk < n; kk++) {
         const double4 rec = series[kk];
         // --- transition factors of this step; a repeated time step (wave-uniform: the series is shared) re-uses them
         src.step(kk);
@@ -509,14 +621,14 @@ CARMA_DEV double logdensity_lane(const double* theta, int q, const double4* __re
 
 #if defined(__HIPCC__)
 // the same with the factors from the producer wave's ring (consumer side of k_logdens_carma_lpc)
-template <int P, int NP, bool REPDT = true>
+template <int P, int NP, bool REPDT = true, bool UNROLLED = false>
 __device__ __forceinline__ double logdensity_lane_ring(const double* theta, int q, const double4* __restrict__ series, int n,
                                                        const Prior& pr, int ignore_prior, const double* ring /* + lane */)
 {
     LaneModel<P> m;
     lane_model_from_theta<P>(theta, q, pr, ignore_prior, m);
-    const LaneFactorsRing<P, NP> src{ring};
-    double ll = lane_filter<P, LaneFactorsRing<P, NP>, false, REPDT>(m, series, n, src);
+    const LaneFactorsRing<P, NP, UNROLLED && !REPDT> src{ring};
+    double ll = lane_filter<P, LaneFactorsRing<P, NP, UNROLLED && !REPDT>, false, REPDT>(m, series, n, src);
     ll += log_prior(m.scale, pr.measerr_dof);
     if (m.sing || !m.valid) ll = -1.0 / 0.0;
     return ll;

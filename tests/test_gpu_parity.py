@@ -527,7 +527,7 @@ def test_corotating_frame_windows_and_rebases(cpa, p, q):
         assert np.array_equal(ctx.logdensity(th[i:i + 1], ignore_prior=True), got[i:i + 1], equal_nan=True)
 
 
-@pytest.mark.parametrize("p,q", [(4, 1), (5, 3), (7, 2)])
+@pytest.mark.parametrize("p,q", [(4, 1), (5, 3), (6, 3), (7, 2)])
 def test_pair_shared_factors_and_real_pairs(cpa, p, q):
     """Throughput-regime kernels share the exp/sincos of a root pair between its two lanes (RhoPair) unless a group
     of the wave holds a quadratic factor with two REAL roots.  Batches of complex-pair thetas, of real-pair thetas and
@@ -550,7 +550,8 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
     B = 8000                                                    # lane-group throughput kernel (p <= 4: its consumer / producer pair form --
                                                                 # from 8193 / 3073 evaluations those orders are on producer waves since round 4)
     BL, BP = 60000, (20000 if p <= 4 else 12000)                # one evaluation per lane: in line / with producer waves
-    assert ctx.kernel_name(B).startswith("k_logdens_carma<" if p >= 5 else "k_logdens_carma_pc<")
+    # (p = 5: 4 097 ... 8 192 evaluations are on producer waves since round 5; its lane-group kernel: test_lane_group_kernels_of_the_low_orders)
+    assert ctx.kernel_name(B).startswith("k_logdens_carma<" if p >= 6 else ("k_logdens_carma_lpc<" if p == 5 else "k_logdens_carma_pc<"))
     assert ctx.kernel_name(BL).startswith("k_logdens_carma_lane<")
     assert ctx.kernel_name(BP).startswith("k_logdens_carma_lpc<")
     res = {}
@@ -981,7 +982,7 @@ def test_filter_of_many_models_in_one_launch(cpa, p):
 
 
 def test_lane_group_kernels_of_the_low_orders():
-    """k_logdens_carma<P,G,W> for p <= 4 (and the pair form k_logdens_carma_pc up to 512 waves): since round 4 the default
+    """k_logdens_carma<P,G,W> for p <= 5 (and the pair form k_logdens_carma_pc up to 512 waves): since round 4 (p = 5: round 5) the default
     dispatch hands those orders to the producer-wave kernel right above the wave pipeline's range, so these kernels are
     reached through CARMA_TUNE_LPC_MIN / CARMA_TUNE_LANE_MIN only (read once per process: a process of its own).  Same bar
     as everywhere: the oracle to 1e-10 or no further from the quad-precision value, copies of a vector give the same bits."""
@@ -994,7 +995,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import carma_pack_amd as cpa
 import oracle as orc
 from helpers import assert_parity, irregular_series, prior_like_theta, loglik_truth
-for p, q in ((2, 1), (3, 1), (4, 2)):
+for p, q in ((2, 1), (3, 1), (4, 2), (5, 2)):                 # (p = 5: 4 097 ... 8 192 evaluations went to the producer waves in round 5)
     t, y, yerr = irregular_series(130, seed=40 + p)
     rng = np.random.default_rng(77 + p)
     th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(40)])
