@@ -353,7 +353,7 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
     //   * p <= 4, whose batched launch is the producer-wave kernel right above the wave pipeline's range (carma_kernels.hip,
     //     lpc_min_evals): from 16 x #CUs chains (p = 3: 78 us flat up to 16 384 chains against 103-105, p = 4: 88-107 against
     //     116; at 3200 ... 4096 chains the ladder kernel's 74 / 79 us are still ahead of 78 / 83), p = 2 from 12 x #CUs (64 us
-    //     flat against 73-96).
+    //     flat against 73-96); p = 5 from 16 x #CUs as well since round 5 (below).
     // CARMA_PT_KERNEL=lane forces it (T <= 64), CARMA_TUNE_PT_LANE_MIN = N replaces the table by "from N chains".
     const char* force = getenv("CARMA_PT_KERNEL");
     if (e == hipSuccess && ntemps <= 64) {
@@ -370,8 +370,14 @@ int carma_pt_create(carma_ctx* h, int ntemps, int nreplicas, const double* tempe
         // evaluation per lane, launch_logdens_car1 -- and a small ladder such as run_mcmc_car1's default ~10 chains would pay 2-3
         // launches per iteration with nothing parallel to hide them: those keep the persistent k_pt.)
         if (c->p == 1) pays = c->n >= 64 && (long)nchain >= 64 && !((long)nchain > 48 * cus && (long)nchain <= 64 * cus);
-        if (c->p == 2) pays = pays || (long)nchain > 12 * cus;
-        if (c->p == 3 || c->p == 4) pays = pays || (long)nchain > 16 * cus;
+        // (p = 3 from 12 x #CUs as well since round 5: 70 us against the ladder kernel's 72.6 at 3200 / 4096 chains; p = 4: 83 against 75,
+        // p = 6, 7 at 4608 ... 8192 chains: 150 / 172 against 130 / 138 -- mcmc_lane_threshold_v3.txt)
+        if (c->p == 2 || c->p == 3) pays = pays || (long)nchain > 12 * cus;
+        if (c->p == 4) pays = pays || (long)nchain > 16 * cus;
+        // p = 5 (round 5): its batched launch is the producer-wave kernel from 4 097 evaluations since the consumer takes a ring buffer
+        // at a time (89 us) -- 111-112 us per iteration flat for 4 352 ... 8 192 chains against the ladder kernel's 122-125 (which does
+        // 80 us up to 4 096 chains, against 91: profiles/r05/mcmc_lane_threshold_v1.txt, _v2.txt)
+        if (c->p == 5) pays = pays || (long)nchain > 16 * cus;
         if (tv) pays = (long)nchain >= atol(tv);
         const bool forced = force && std::strcmp(force, "lane") == 0;
         if (forced || (!force && pays)) {

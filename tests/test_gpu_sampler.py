@@ -221,19 +221,24 @@ def test_lane_kernel_is_the_choice_for_large_ensembles(cpa, monkeypatch):
     ctx = cpa.Context(t, y, yerr, 3, 1, max_stdev=ms)
     ctx.pt_create(8, 16, adapt_iters=50, seed=3)
     assert ctx.pt_kernel() in ("row", "ladder")
-    # p = 3: one chain per lane from 16 x #CUs chains (its batched launch is the producer-wave kernel from 3073 evaluations)
+    # p = 3: one chain per lane from 12 x #CUs chains (its batched launch is the producer-wave kernel from 3073 evaluations)
     ncu = 256                                                # (MI355X)
-    ctx.pt_create(8, 2 * ncu, adapt_iters=50, seed=3)        # 4096 chains
+    ctx.pt_create(8, 3 * ncu // 2, adapt_iters=50, seed=3)   # 3072 chains
     assert ctx.pt_kernel() in ("row", "ladder")
-    ctx.pt_create(8, 3 * ncu, adapt_iters=50, seed=3)        # 6144 chains
+    ctx.pt_create(8, 3 * ncu // 2 + 8, adapt_iters=50, seed=3)   # 3136 chains
     assert ctx.pt_kernel() == "lane"
     ctx.pt_create(16, 3 * ncu, adapt_iters=50, seed=3)       # 12 288 chains
     assert ctx.pt_kernel() == "lane"
-    c5 = cpa.Context(t, y, yerr, 5, 2, max_stdev=ms)         # p = 5: 16 temperatures x 8 lanes = two waves per ladder
-    c5.pt_create(16, 2 * ncu, adapt_iters=50, seed=3)        # 1024 waves: the ladder kernel's one round
+    c5 = cpa.Context(t, y, yerr, 5, 2, max_stdev=ms)         # p = 5: from 16 x #CUs chains too since round 5 (producer-wave kernel from 4 097)
+    c5.pt_create(16, ncu, adapt_iters=50, seed=3)            # 4096 chains
     assert c5.pt_kernel() in ("row", "ladder")
-    c5.pt_create(16, 2 * ncu + 8, adapt_iters=50, seed=3)
+    c5.pt_create(16, ncu + 8, adapt_iters=50, seed=3)
     assert c5.pt_kernel() == "lane"
+    c7 = cpa.Context(t, y, yerr, 7, 2, max_stdev=ms)         # p = 6, 7: 16 temperatures x 8 lanes = two waves per ladder, one round of
+    c7.pt_create(16, 2 * ncu, adapt_iters=50, seed=3)        # the ladder kernel = 1024 waves
+    assert c7.pt_kernel() in ("row", "ladder")
+    c7.pt_create(16, 2 * ncu + 8, adapt_iters=50, seed=3)
+    assert c7.pt_kernel() == "lane"
     ctx.pt_create(8, 4096 + 3, adapt_iters=50, seed=3)       # 32 792 chains: one chain per lane, a ragged last wave
     assert ctx.pt_kernel() == "lane"
     ctx.pt_start(None)
