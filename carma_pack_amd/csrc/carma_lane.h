@@ -227,12 +227,15 @@ struct LaneFactorsRing {
     // the barrier in front, the slots at compile-time offsets, the reads of the later steps' factors move up across the earlier
     // steps: 110 -> 95 us at p = 5 while a CU holds one workgroup (profiles/r05/ab_lpc_unroll_v1.txt; p = 3: 64 -> 55, p = 7:
     // 165 -> 147); with two workgroups per CU the step-by-step loop is 1-4 % ahead and stays.  Same bits.
+    // (half a buffer at a time -- three steps, or two -- is slower at p = 6, 7, where the whole buffer spills into AGPRs:
+    // 131 / 155 us against 124 / 150, profiles/r05/ab_lpc_unroll_hi_v1.txt)
     static constexpr int UNROLL = UNROLLED ? Geo::CH : 1;
     const double* ring;                                       // [2][CH][NV][64], + lane
-    CARMA_DEV const double* chunk(int c) const
+    // first step kk of a buffer (kk - 1 a multiple of CH)
+    CARMA_DEV const double* chunk(int kk) const
     {
         __syncthreads();                                      // barrier c: chunk c is in the ring
-        return ring + (size_t)((c & 1) * Geo::CH) * Geo::NV * 64;
+        return ring + (size_t)((((kk - 1) / Geo::CH) & 1) * Geo::CH) * Geo::NV * 64;
     }
     CARMA_DEV static void get_at(const double* cb, int s, double (&cr)[P], double (&sr)[P])
     {
@@ -352,7 +355,7 @@ CARMA_DEV double lane_filter(const LaneModel<P>& m, const double4* __restrict__ 
         // one body cost the in-line kernel 5 % at 65 536 evaluations -- profiles/r05/ab_lpc_unroll_v2.txt -- so that loop stays as it is.)
         constexpr int U = Src::UNROLL;
         for (; kk0 + U <= n; kk0 += U) {                      // (kk0 - 1 is a multiple of U)
-            const double* cb = src.chunk((kk0 - 1) / U);
+            const double* cb = src.chunk(kk0);
 #pragma unroll
             for (int us = 0; us < U; us++) {
                 const int kk = kk0 + us;
