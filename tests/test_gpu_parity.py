@@ -318,6 +318,34 @@ def test_launch_shapes_agree(cpa, p, q):
     assert np.array_equal(res["lpc"], res["plain"], equal_nan=True)
 
 
+@pytest.mark.parametrize("p,q", [(3, 1), (5, 2), (7, 3)])
+def test_producer_wave_ring_buffers_and_series_length(cpa, p, q):
+    """Round 5: up to one workgroup per CU the producer-wave kernel's consumer takes a ring buffer of six steps as one basic block and
+    the remaining n - 1 mod 6 steps one by one.  Every residue (and the shortest series the kernel takes): the same bits as the in-line
+    lane kernel, whose loop has no buffers, and parity with the oracle."""
+    from helpers import loglik_truth
+    B1, B2, BL = 12000, 20000, 70000                            # one / two workgroups per CU (rolled loop) / in line
+    for n in (8, 9, 12, 13, 14, 18, 19, 20, 37):
+        t, y, yerr = irregular_series(n, seed=300 + n)
+        rng = np.random.default_rng(3000 + 10 * n + p)
+        th = np.array([prior_like_theta(rng, p, q, t, y) for _ in range(25)])
+        ctx = cpa.Context(t, y, yerr, p, q)
+        assert ctx.kernel_name(B1).startswith("k_logdens_carma_lpc<") and ctx.kernel_name(BL).startswith("k_logdens_carma_lane<")
+        m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
+        want = m.logdensity_batch(th, ignore_prior=True)
+        res = {}
+        for B in (B1, B2, BL):
+            if not ctx.kernel_name(B).startswith("k_logdens_carma_l"):      # (p = 7: 20 000 evaluations are the lane groups')
+                continue
+            got = ctx.logdensity(np.tile(th, (B // 25 + 1, 1))[:B], ignore_prior=True)
+            assert np.array_equal(got, np.tile(got[:25], B // 25 + 1)[:B], equal_nan=True), (n, B)
+            res[B] = got[:25]
+        assert_parity(res[B1], want, RTOL, "producer waves, n=%d p=%d" % (n, p),
+                      arbiter=lambda i: loglik_truth(t, y, yerr, th[i], p, q)[0], max_arb_frac=0.2)
+        for B in res:
+            assert np.array_equal(res[B], res[BL], equal_nan=True), (n, B)
+
+
 @pytest.mark.parametrize("p,q", [(2, 0), (5, 3), (7, 4)])
 def test_series_lengths_around_chunk_boundaries(cpa, p, q):
     """The ring kernels work in 16-step chunks (one barrier each, buffers rotating; six steps in the lane kernel with
