@@ -143,8 +143,8 @@ def main():
         for i in range(PSTEPS):
             ctx.logdensity_dev(pool[i % NPOOL].data_ptr(), B, outs[i & 1].data_ptr(), ignore_prior=False, stream=s2[i & 1].cuda_stream)
         torch.cuda.synchronize()
-        barrier()
         tp = time.perf_counter() - tp0
+        barrier()
         if dist is not None:
             tt = torch.tensor([tp], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -173,8 +173,8 @@ def main():
             ctx.logdensity_dev(big.data_ptr(), BT, outb.data_ptr(), ignore_prior=False, stream=sh)
         e1.record(stream)
         torch.cuda.synchronize()
-        barrier()
         tq = time.perf_counter() - tq0
+        barrier()
         if dist is not None:
             tt = torch.tensor([tq], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,8 +203,8 @@ def main():
             ctx.logdensity_dev(bigm.data_ptr(), BM, outm.data_ptr(), ignore_prior=False, stream=sh)
         e1.record(stream)
         torch.cuda.synchronize()
-        barrier()
         tq = time.perf_counter() - tq0
+        barrier()
         if dist is not None:
             tt = torch.tensor([tq], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -229,8 +229,8 @@ def main():
         barrier()
         tm0 = time.perf_counter()
         big_ctx.pt_iterate(IT_)
-        barrier()
         tm = time.perf_counter() - tm0
+        barrier()
         if dist is not None:
             tt = torch.tensor([tm], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -258,8 +258,8 @@ def main():
         barrier()
         tm0 = time.perf_counter()
         ctx.pt_iterate(args.mcmc_iters)
-        barrier()
         tm = time.perf_counter() - tm0
+        barrier()
         if dist is not None:
             tt = torch.tensor([tm], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -289,8 +289,8 @@ def main():
         for i in range(NS):
             step(i)
         torch.cuda.synchronize()
-        barrier()
         ts = time.perf_counter() - ts0
+        barrier()
         if dist is not None:
             tt = torch.tensor([ts], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -318,6 +318,10 @@ def main():
         torch.cuda.synchronize()
 
     # ---- timed region: EXACTLY K steps --------------------------------------------------------
+    # (N > 1: every rank reads its clock when ITS K steps are through -- between the closing synchronize and the closing barrier -- and the
+    # MAX over ranks is the job's time: all ranks left the opening barrier together, so that is when the last one finished.  The closing
+    # barrier itself -- an RCCL all-reduce and its host wake-up, ~0.1 ms -- is not a step of the path: inside a 20-step region of 0.55 ms it
+    # would read as a fifth of the time.  The legs above are timed the same way.  N = 1: the barrier is a no-op.)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
@@ -330,8 +334,8 @@ def main():
         step(i)
     ev1.record(stream)
     torch.cuda.synchronize()
-    barrier()
     elapsed = time.perf_counter() - t0
+    barrier()
     dev_ms = ev0.elapsed_time(ev1)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -656,8 +660,8 @@ def ladder_sharded_leg(cpa, dist, world, share, dev, dev_index, barrier, iters):
     barrier()
     tl0 = time.perf_counter()
     run(iters)
-    barrier()
     tl = time.perf_counter() - tl0
+    barrier()
     rates = None
     if dist is not None:
         tt = torch.tensor([tl], dtype=torch.float64, device=dev)
