@@ -33,6 +33,9 @@ struct PtState {
     unsigned long long iter = 0;
     std::vector<double> temps;
     double *d_temps = nullptr, *d_theta = nullptr, *d_lp = nullptr, *d_chol = nullptr;
+    // lane sampler (use_lane): the factors live in the chain-minor scratch between calls
+    bool lane_factor_loaded = false;   // the scratch holds the current factors (else: take them from d_chol at the next launch)
+    bool chol_stale = false;           // d_chol is behind the scratch (pt_sync_factor brings it up to date)
     bool ext_state = false;
     unsigned *d_nacc = nullptr, *d_nswap = nullptr;
     double *d_samples = nullptr, *d_slp = nullptr;
@@ -84,5 +87,10 @@ void pt_state_free(Ctx* c);
 int pt_enqueue(Ctx* c, long niter, int do_exchange, int thin, long* save_offset, hipStream_t st);
 // after the stream has been synchronised: did a cross-workgroup rendezvous of the row kernel time out?
 int pt_check_abort(Ctx* c, bool* aborted);
+// The lane sampler keeps the proposal factors in its chain-minor working state between calls.  pt_sync_factor: bring the chain-major
+// array d_chol up to date before it is read (enqueued on st; no-op for the other kernels); pt_factor_written: d_chol was written, the
+// next launch reloads.
+hipError_t pt_sync_factor(Ctx* c, hipStream_t st);
+void pt_factor_written(Ctx* c);
 
 }  // namespace carma

@@ -58,6 +58,9 @@ hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const dou
 size_t pt_lane_scratch_doubles(int d, long nchain);
 hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const double4* series, const Prior& pr,
                           const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
-                          unsigned* nswap, double* samples, double* sample_lp, int series_flags, hipStream_t st);
+                          unsigned* nswap, double* samples, double* sample_lp, int series_flags, bool load_factor, hipStream_t st);
+// the lane sampler keeps the proposal factors in its chain-minor working state between calls; this writes them to the chain-major
+// array the other entry points read (carma_pt_get_factor, the shard packers): enqueued on st
+hipError_t pt_lane_store_factor(int d, int T, int R, double* scratch, double* chol, hipStream_t st);
 
 }  // namespace carma

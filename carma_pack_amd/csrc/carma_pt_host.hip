@@ -177,7 +177,12 @@ static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save
     }
     if (!s->use_row && s->use_lane) {
         e = launch_pt_lane(c->p, L, s->d_lane_scratch, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta,
-                           s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->series_flags(), st);
+                           s->d_lp, s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, c->series_flags(), !s->lane_factor_loaded,
+                           st);
+        if (e == hipSuccess) {
+            s->lane_factor_loaded = true;                   // ... and stays in the scratch: the chain-major copy is behind until
+            s->chol_stale = true;                           // somebody asks for it (pt_sync_factor)
+        }
     } else if (!s->use_row) {
         e = launch_pt(c->p, L, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
                       s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
@@ -218,6 +223,25 @@ int pt_check_abort(Ctx* c, bool* aborted)
     return CARMA_OK;
 }
 
+// The chain-major factors d_chol brought up to date with the lane sampler's working state (no-op for the other kernels): before
+// anything reads d_chol.  Enqueued on st.
+hipError_t pt_sync_factor(Ctx* c, hipStream_t st)
+{
+    PtState* s = c->pt;
+    if (!s || !s->use_lane || !s->chol_stale) return hipSuccess;
+    const hipError_t e = pt_lane_store_factor(c->d, s->T, s->R, s->d_lane_scratch, s->d_chol, st);
+    if (e == hipSuccess) s->chol_stale = false;
+    return e;
+}
+// ... and the other way round: d_chol was written (carma_pt_set_factor, a restored backup): the next launch reloads the factors
+void pt_factor_written(Ctx* c)
+{
+    if (c->pt) {
+        c->pt->lane_factor_loaded = false;
+        c->pt->chol_stale = false;
+    }
+}
+
 // chain state <-> backup (theta, logpost, chol), asynchronous on st
 static hipError_t pt_backup(Ctx* c, bool restore, hipStream_t st)
 {
@@ -225,6 +249,12 @@ static hipError_t pt_backup(Ctx* c, bool restore, hipStream_t st)
     const size_t nchain = (size_t)s->T * s->R, d = c->d;
     double* b = s->d_backup;
     struct Part { double* p; size_t n; } parts[3] = {{s->d_theta, nchain * d}, {s->d_lp, nchain}, {s->d_chol, nchain * d * d}};
+    if (!restore) {
+        const hipError_t es = pt_sync_factor(c, st);
+        if (es != hipSuccess) return es;
+    } else {
+        pt_factor_written(c);
+    }
     for (auto& pt : parts) {
         hipError_t e = restore ? hipMemcpyAsync(pt.p, b, sizeof(double) * pt.n, hipMemcpyDeviceToDevice, st)
                                : hipMemcpyAsync(b, pt.p, sizeof(double) * pt.n, hipMemcpyDeviceToDevice, st);

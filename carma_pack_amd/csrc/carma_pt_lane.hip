@@ -90,23 +90,32 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// chain-major state arrays -> chain-minor working state (load != 0) or back
+// chain-major state arrays -> chain-minor working state (load != 0) or back.  what: 1 = values and log-posteriors, 2 = the factors
+// (d (d + 1) / 2 of the d (d + 3) / 2 + 1 numbers of a chain, strided by d^2 on the chain-major side: they stay resident in the
+// chain-minor state between calls and are converted only when somebody reads or writes the chain-major copy -- round 5)
+constexpr int RAM_CONV_STATE = 1, RAM_CONV_FACTOR = 2;
 __global__ __launch_bounds__(256) void k_ram_convert(PtLaunch L, RamState S, double* __restrict__ theta,
-                                                     double* __restrict__ logpost, double* __restrict__ chol, int load)
+                                                     double* __restrict__ logpost, double* __restrict__ chol, int load, int what)
 {
     const long gi = (long)blockIdx.x * 256 + threadIdx.x;
     if (gi >= S.nc) return;
     const int d = L.d;
     if (load) {
-        for (int j = 0; j < d; j++) S.th[(long)j * S.nc + gi] = theta[gi * d + j];
-        for (int k = 0; k < d; k++)
-            for (int j = k; j < d; j++) S.R[(tri_row(d, k) + (j - k)) * S.nc + gi] = chol[(gi * d + k) * d + j];
-        S.lp[gi] = logpost[gi];
+        if (what & RAM_CONV_STATE) {
+            for (int j = 0; j < d; j++) S.th[(long)j * S.nc + gi] = theta[gi * d + j];
+            S.lp[gi] = logpost[gi];
+        }
+        if (what & RAM_CONV_FACTOR)
+            for (int k = 0; k < d; k++)
+                for (int j = k; j < d; j++) S.R[(tri_row(d, k) + (j - k)) * S.nc + gi] = chol[(gi * d + k) * d + j];
     } else {
-        for (int j = 0; j < d; j++) theta[gi * d + j] = S.th[(long)j * S.nc + gi];
-        for (int k = 0; k < d; k++)
-            for (int j = k; j < d; j++) chol[(gi * d + k) * d + j] = S.R[(tri_row(d, k) + (j - k)) * S.nc + gi];
-        logpost[gi] = S.lp[gi];
+        if (what & RAM_CONV_STATE) {
+            for (int j = 0; j < d; j++) theta[gi * d + j] = S.th[(long)j * S.nc + gi];
+            logpost[gi] = S.lp[gi];
+        }
+        if (what & RAM_CONV_FACTOR)
+            for (int k = 0; k < d; k++)
+                for (int j = k; j < d; j++) chol[(gi * d + k) * d + j] = S.R[(tri_row(d, k) + (j - k)) * S.nc + gi];
     }
 }
 
@@ -339,9 +348,11 @@ static hipError_t ram_launch_d(int d, F&& f)
 
 // niter iterations of the sampler for large ensembles, enqueued on st: 2 launches per iteration (+ the first proposal) + one conversion at
 // either end.  The iterations, the save slots and the Philox keys are those of launch_pt for the same PtLaunch.
+// load_factor: the chain-minor factors are not current (first call, or the chain-major copy was written): take them from chol.  The
+// chain-major copy is NOT written back here -- pt_lane_store_factor does that for whoever wants to read it.
 hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const double4* series, const Prior& pr,
                           const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
-                          unsigned* nswap, double* samples, double* sample_lp, int series_flags, hipStream_t st)
+                          unsigned* nswap, double* samples, double* sample_lp, int series_flags, bool load_factor, hipStream_t st)
 {
     (void)hipGetLastError();
     if (p < 1 || L.T < 1 || L.T > 64 || L.d < 4 || L.d > RAM_DMAX || (p == 1) != (L.d == 4)) return hipErrorInvalidValue;
@@ -350,7 +361,8 @@ hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const doubl
     const int LPW = 64 / L.T;
     const long waves = ((long)L.R + LPW - 1) / LPW;
     const unsigned grid = (unsigned)((waves + 3) / 4), gridc = (unsigned)((nc + 255) / 256);
-    hipLaunchKernelGGL(k_ram_convert, dim3(gridc), dim3(256), 0, st, L, S, theta, logpost, chol, 1);
+    hipLaunchKernelGGL(k_ram_convert, dim3(gridc), dim3(256), 0, st, L, S, theta, logpost, chol, 1,
+                       RAM_CONV_STATE | (load_factor ? RAM_CONV_FACTOR : 0));
     hipError_t e = hipGetLastError();
     for (int it = 0; it < L.niter && e == hipSuccess; it++) {
         PtLaunch Li = L;
@@ -383,10 +395,24 @@ hipError_t launch_pt_lane(int p, const PtLaunch& L, double* scratch, const doubl
         }
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_ram_convert, dim3(gridc), dim3(256), 0, st, L, S, theta, logpost, chol, 0);
+        hipLaunchKernelGGL(k_ram_convert, dim3(gridc), dim3(256), 0, st, L, S, theta, logpost, chol, 0, RAM_CONV_STATE);
         e = hipGetLastError();
     }
     return e;
+}
+
+// the chain-minor factors -> the chain-major array chol [R][T][d][d] (enqueued on st)
+hipError_t pt_lane_store_factor(int d, int T, int R, double* scratch, double* chol, hipStream_t st)
+{
+    (void)hipGetLastError();
+    PtLaunch L{};
+    L.d = d;
+    L.T = T;
+    L.R = R;
+    const long nc = (long)R * T;
+    const RamState S = ram_state(scratch, d, nc);
+    hipLaunchKernelGGL(k_ram_convert, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, L, S, nullptr, nullptr, chol, 0, RAM_CONV_FACTOR);
+    return hipGetLastError();
 }
 
 }  // namespace carma

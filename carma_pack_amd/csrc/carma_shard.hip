@@ -654,7 +654,8 @@ int carma_pt_get_factor(carma_ctx* h, double* chol)
     if (!h || !reinterpret_cast<Ctx*>(h)->pt || !chol) return CARMA_EINVAL;
     Ctx* c = reinterpret_cast<Ctx*>(h);
     PtState* s = c->pt;
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = pt_sync_factor(c, c->stream);            // (lane sampler: the factors live in its working state between calls)
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(chol, s->d_chol, sizeof(double) * (size_t)s->T * s->R * c->d * c->d, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hip_fail(e, "carma_pt_get_factor");
     return CARMA_OK;
@@ -668,6 +669,7 @@ int carma_pt_set_factor(carma_ctx* h, const double* chol)
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(s->d_chol, chol, sizeof(double) * (size_t)s->T * s->R * c->d * c->d, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hip_fail(e, "carma_pt_set_factor");
+    pt_factor_written(c);
     return CARMA_OK;
 }
 

@@ -211,6 +211,45 @@ def test_lane_kernel_walks_the_ladder_kernels_trajectory(cpa, p, q, T, R, kern, 
     assert_same_evaluation(a[3], b[3], a[2], p, "saved samples, lane vs ladder kernel", thetas_b=b[2])
 
 
+def test_lane_sampler_keeps_its_factors_between_calls(cpa, monkeypatch):
+    """Round 5: the lane sampler's proposal factors stay in its chain-minor working state between calls; the chain-major
+    array is written when somebody reads it (carma_pt_get_factor) and re-read after somebody wrote it (carma_pt_set_factor).  Twelve
+    calls of one iteration (what a sharded ladder does) = one call of twelve, bit for bit, factors included; a factor set half way is
+    the factor the next proposal uses."""
+    from helpers import irregular_series
+    monkeypatch.setenv("CARMA_PT_KERNEL", "lane")
+    t, y, yerr = irregular_series(60, seed=9)
+    ms = _pop_stdev(y)
+
+    def run(plan):
+        ctx = cpa.Context(t, y, yerr, 3, 1, max_stdev=ms)
+        ctx.pt_create(6, 21, adapt_iters=10 ** 6, seed=5)
+        ctx.pt_start(None)
+        assert ctx.pt_kernel() == "lane"
+        for step in plan:
+            if step == "get":
+                ctx.pt_get_factor()
+            elif step == "same":
+                ctx.pt_set_factor(ctx.pt_get_factor())
+            elif step == "double":
+                ctx.pt_set_factor(2.0 * ctx.pt_get_factor())
+            else:
+                ctx.pt_iterate(step)
+        th, lp = ctx.pt_get_chains()
+        return np.array(th), np.array(lp), np.array(ctx.pt_get_factor())
+
+    one = run([12])
+    for plan in ([1] * 12, [5, "get", 7], [5, "same", 3, "get", 1, 3], [2, 2, 2, "get", "get", 6]):
+        got = run(plan)
+        for a, b in zip(one, got):
+            np.testing.assert_array_equal(a, b, err_msg=str(plan))
+    dbl = run([5, "double", 7])
+    assert not np.array_equal(dbl[0], one[0])                 # the doubled proposal scale was used
+    # ... and its own single-iteration replay agrees with it
+    for a, b in zip(dbl, run([5, "double"] + [1] * 7)):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_lane_kernel_is_the_choice_for_large_ensembles(cpa, monkeypatch):
     """Dispatch by chain count (carma_pt_create): small ensembles keep the row / ladder kernels, tens of thousands of
     chains take one chain per lane; the stored log-posterior of every chain equals the oracle's LogDensity of its state."""
