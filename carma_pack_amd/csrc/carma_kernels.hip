@@ -202,6 +202,50 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w(const double* __restric
     if (live && g.lane() == 0) out[e] = ll;
 }
 
+// The TWO-SIDED window pipeline (round 6): an evaluation takes TWO DPP rows -- the even row filters the first half of the series
+// forward, the odd row the second half backward (carma_pipew.h, TS), and the two states are merged at the meeting time -- so the
+// serial chain of kfilter.cpp:189-215 is half as long.  Two evaluations per workgroup.
+template <int P>
+__global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restrict__ theta, int B, int d, int q,
+                                                          const double4* __restrict__ series, int n, Prior pr,
+                                                          int ignore_prior, double* __restrict__ out, int ncu)
+{
+    extern __shared__ double4 smem4[];
+    const int tid = threadIdx.x, lane64 = tid & 63;
+    const int round = (blockIdx.x >= (unsigned)ncu) + (blockIdx.x >= 2u * (unsigned)ncu);
+    const int wave = ((round == 0 ? 0xE4 : round == 1 ? 0xD2 : 0x36) >> (2 * (tid >> 6))) & 3;
+    Grp<16> g{nullptr, lane64, nullptr};
+    double2* ring = reinterpret_cast<double2*>(smem4);
+    long e = ((long)blockIdx.x * 64 + lane64) / 32;
+    const bool live = e < B;
+    if (!live) e = B - 1;
+    using Geo = PipeWGeom<P>;
+    math_tab_fill(reinterpret_cast<double*>(ring + Geo::TAB_OFF));
+    if (wave >= 2) {
+        pipew_produce<P, true>(g, wave - 2, theta + e * d, series, n, ring, [](int) {});
+        return;
+    }
+    Model<P> m;
+    if (wave == 1) {
+        model_from_theta<P, 16, MODEL_FLAGS>(g, theta + e * d, q, pr, ignore_prior, m);
+        const double lpri = log_prior(m.scale, pr.measerr_dof);
+        if ((lane64 & 15) == 0) ring[Geo::OUT_OFF + (lane64 >> 4)] = make_double2(lpri, m.valid ? 1.0 : 0.0);
+        pipew_produce<P, true>(g, 2, theta + e * d, series, n, ring, [](int) {});
+        return;
+    }
+    model_from_theta<P, 16, MODEL_CONSTS>(g, theta + e * d, q, pr, ignore_prior, m);
+    FilterConsts<P> fc;
+    filter_reset<P, 16>(g, m, fc);
+    RowConsts<P> rc;
+    row_consts<P>(g, m, fc, rc);
+    double ll = pipew_recur<P, true>(g, rc, ring);
+    const double2 o = ring[Geo::OUT_OFF + (lane64 >> 4)];
+    ll += o.x;
+    const double ninf = -1.0 / 0.0;
+    if (m.sing || o.y == 0.0) ll = ninf;
+    if (live && (lane64 & 31) == 0) out[e] = ll;
+}
+
 // Throughput regime proper (tens of thousands of evaluations): ONE EVALUATION PER LANE (carma_lane.h) -- nothing crosses
 // lanes, all 64 lanes work; a wave per 64 evaluations.
 // REPDT (here and below): the variant for series with repeated time steps (carma_lane.h, lane_filter)
@@ -571,7 +615,7 @@ static long p3l_max_rows()
 }
 
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
-enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC, WIN };
+enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC, WIN, WIN2 };
 // Largest launch (in workgroups of four evaluations) that takes the windowed wave pipeline (carma_pipew.h): one workgroup per CU
 // (measured per order at 1024 evaluations, profiles/r05/window_pipeline_v1.txt: 1-10 % ahead of the one-datum pipeline; with two
 // or three workgroups per CU that one is ahead).  CARMA_TUNE_WIN_ROWS overrides (0: never) -- read at EVERY launch, so that one
@@ -580,6 +624,13 @@ static long win_max_rows()
 {
     const char* e = getenv("CARMA_TUNE_WIN_ROWS");
     return e ? atol(e) : (long)device_cus();
+}
+// Largest launch (in EVALUATIONS) that takes the two-sided window pipeline: two workgroups of two evaluations per CU.
+// CARMA_TUNE_WIN2_EVALS overrides (0: never) -- read at every launch, as above.
+static long win2_max_evals()
+{
+    const char* e = getenv("CARMA_TUNE_WIN2_EVALS");
+    return e ? atol(e) : 4L * device_cus();
 }
 // smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
 static long lane_min_evals(int p = 5)
@@ -655,6 +706,7 @@ static LdShape logdens_shape(long B, int n, int series_flags)
     constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
+    if (B <= win2_max_evals() && n >= 16 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS"))) return LdShape::WIN2;
     if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS"))) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
     if (B > lpc_min_evals<P>() && B <= lpc_max_evals<P>() && n >= 8) return LdShape::LPC;
@@ -694,6 +746,10 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             return hipGetLastError();
         case LdShape::WIN:
             hipLaunchKernelGGL((k_logdens_carma_w<P>), dim3((unsigned)rows), dim3(256), PipeWGeom<P>::BYTES, st, theta, B, d, q,
+                               series, n, pr, ignore_prior, out, device_cus());
+            return hipGetLastError();
+        case LdShape::WIN2:
+            hipLaunchKernelGGL((k_logdens_carma_w2<P>), dim3((unsigned)(((long)B + 1) / 2)), dim3(256), PipeWGeom<P>::BYTES, st, theta, B, d, q,
                                series, n, pr, ignore_prior, out, device_cus());
             return hipGetLastError();
         case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);
@@ -751,6 +807,7 @@ static int logdens_name_p(long B, int n, char* buf, int len, int series_flags)
     constexpr int G = GroupOf<P>::value;
     switch (logdens_shape<P>(B, n, series_flags)) {
         case LdShape::WIN: return snprintf(buf, len, "k_logdens_carma_w<%d>", P);
+        case LdShape::WIN2: return snprintf(buf, len, "k_logdens_carma_w2<%d>", P);
         case LdShape::P3L: return snprintf(buf, len, "k_logdens_carma_p3l<%d>", P);
         case LdShape::PC1: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,1>", P, G);
         case LdShape::PC2: return snprintf(buf, len, "k_logdens_carma_pc<%d,%d,2>", P, G);

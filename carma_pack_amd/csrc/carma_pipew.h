@@ -54,16 +54,24 @@ struct PipeWGeom {
     static constexpr int CONST_OFF = HDR_OFF + NB;            // double2 {h_r, c_r}[64]
     static constexpr int OUT_OFF = CONST_OFF + 64;            // double2 {log prior, valid}[4] from the set-up wave
     static constexpr int TAB_OFF = OUT_OFF + 4;               // double[MATH_TAB_N]: tables of the short exp / sincos (carma_math.h)
-    static constexpr int ENTRIES = TAB_OFF + MATH_TAB_N / 2;
+    static constexpr int MRG_OFF = TAB_OFF + MATH_TAB_N / 2;  // two-sided kernels: double[2][P][P + 1], the forward rows' (D, -a) for the merge
+    static constexpr int MRG_STRIDE = P + 1 + ((P + 1) & 1);  // (doubles per column: an even count, so that columns are double2 aligned)
+    static constexpr int ENTRIES = MRG_OFF + (2 * P * MRG_STRIDE + 1) / 2;
     static constexpr int NPROD = 3;                           // producer waves: P0, P1 and the set-up wave once it is through
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(double2);
     static constexpr double LIM_RE = Pipe3LGeom<P>::LIM_RE, LIM_IM = Pipe3LGeom<P>::LIM_IM;
 };
 
 // producer waves (pw = 0 .. NPROD - 1).  `tail(pw)` runs once all chunks are produced (the sampler kernel draws there).
-template <int P, class Tail>
+// TS (two-sided, round 6): rows 0 / 2 of the workgroup run the recursion FORWARD over the first (n + 1) / 2 data, rows 1 / 3 run it
+// BACKWARD over the rest -- the same recursion on the reversed series with h and c exchanged and the rotation sense reversed (the
+// state is a stationary Gauss-Markov process: reversed in time it is Markov with transition V F^T V^-1, diagonal again in the dual
+// coordinates u = V^-1 z, where the observation vector is c = V h and "V h" is h; tests/tools/proto/two_sided.py) -- and one more
+// chunk after the data, the FINAL chunk, carries nothing but the rotation of both states to the meeting time in true
+// coordinates (frame factor g included), where pipew_recur merges them.
+template <int P, bool TS = false, class Tail>
 __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
-                                              const double4* __restrict__ series, int n, double2* __restrict__ ring, Tail&& tail)
+                                              const double4* __restrict__ series, int n_all, double2* __restrict__ ring, Tail&& tail)
 {
     using Geo = PipeWGeom<P>;
     constexpr int ND = Geo::ND, NB = Geo::NB, ENT = Geo::ENT;
@@ -76,8 +84,16 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     const int lane = g.lane64, l = lane & 15, rowb = lane & ~15, q = lane >> 4;
     const int sub = l / NPAIR, jr = 2 * (l - sub * NPAIR);
     const bool worker = sub < PPL, two = jr + 1 < P;
-    const Cx w = own_ar_root<P>(theta, jr);
-    const Cx w1 = two ? own_ar_root<P>(theta, jr + 1) : w;
+    // the part of the series this row works on
+    const bool bwd = TS && (q & 1);
+    const int nfwd = (n_all + 1) / 2;
+    const int n = TS ? (bwd ? n_all - nfwd : nfwd) : n_all;
+    Cx w = own_ar_root<P>(theta, jr);
+    Cx w1 = two ? own_ar_root<P>(theta, jr + 1) : w;
+    if (bwd) {                                                // F^T instead of F: the conjugate roots
+        w.im = -w.im;
+        w1.im = -w1.im;
+    }
     int esig = 0;                                             // binary exponent of sigma_y (rescaling, carma_pipe3l.h)
     {
         const double sg = fabs(theta[0]);
@@ -111,7 +127,15 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     }
     // schedule state of this row (row-uniform)
     int j0 = 0;
-    double base = series[0].w;
+    // (a backward row walks the series from its end, in the negated time)
+    auto recat = [=](int j) {
+        const int jj = j < n ? j : n - 1;
+        double4 r = series[bwd ? n_all - 1 - jj : jj];
+        if (bwd) r.w = -r.w;
+        return r;
+    };
+    double base = recat(0).w;
+    const double t_meet = TS ? (bwd ? -series[nfwd - 1].w : series[nfwd - 1].w) : 0.0;    // the last forward datum's time
     // The chunk schedule is data dependent (a chunk ends in front of a re-base datum), so the records of a chunk cannot be
     // requested by index a chunk ahead as in carma_pipe3l.h -- and a global load at the head of every chunk would put an L2
     // round trip on every chunk (measured: 45 us per launch instead of 22).  So each row keeps a WINDOW of 64 records in
@@ -119,7 +143,6 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     // first two and are fetched from their lanes (ds_bpermute); when the row has moved past the first sixteen the window
     // shifts and the next sixteen are requested, two shifts before they are needed.
     int jw = 0;
-    auto recat = [series, n](int j) { return series[j < n ? j : n - 1]; };
     double4 rw0 = recat(l), rw1 = recat(16 + l), rw2 = recat(32 + l), rw3 = recat(48 + l);
     __syncthreads();                                          // the recursion wave has published (h_r, c_r)
     double2 hc_own, hc_par;
@@ -136,12 +159,17 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         if (!(m1 > 0.0 && m1 < 1.0 / 0.0)) e1x = 0;
         hc_own = make_double2(ldexp(hc_own.x, esig - e0), ldexp(hc_own.y, e0 - esig));
         hc_par = make_double2(ldexp(hc_par.x, esig - e1x), ldexp(hc_par.y, e1x - esig));
+        if (bwd) {                                            // dual coordinates: h' = c, c' = V^-1 c = h (the same powers of two)
+            hc_own = make_double2(hc_own.y, hc_own.x);
+            hc_par = make_double2(hc_par.y, hc_par.x);
+        }
     }
 #if defined(CARMA_WIN_STAMPS)
     unsigned long long ps_work = 0, ps_wait = 0, ps_t0 = 0, ps_t1 = 0;
     int ps_n = 0;
 #define WIN_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #endif
+    bool fin = false;                                         // TS: the final chunk (no data, the rotation to the meeting time)
     for (int c = 0;; c++) {
         const int b = c % NB;
 #if defined(CARMA_WIN_STAMPS)
@@ -172,10 +200,10 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         // slowest row (34.1 us per 1024 evaluations, profiles/r05/window_pipeline_v1.txt).
         const int left = n - j0;
         const int ncand = left < ND ? (left > 0 ? left : 0) : ND;
-        const double t0 = __shfl(tj, rowb, 64);
+        const double t0 = fin ? t_meet : __shfl(tj, rowb, 64);
         const double t_lastc = __shfl(tj, rowb + (ncand > 0 ? ncand - 1 : 0), 64);
         const double W = sc > 0.0 ? 1.0 / sc : 1.0 / 0.0;
-        const bool rot = ncand > 0 && (t_lastc - base) > W;
+        const bool rot = fin || (ncand > 0 && (t_lastc - base) > W);
         const double base_old = base;
         base = rot ? t0 : base;
         // (the difference of two time stamps is exact unless the base is much the smaller of the two: carma_pipe3l.h)
@@ -189,7 +217,7 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
             const unsigned long long rb = __ballot(rot);
             if (lane == 0)
                 reinterpret_cast<unsigned long long*>(ring + Geo::HDR_OFF)[b] =
-                    ((rb & 1ull) | ((rb >> 15) & 2ull) | ((rb >> 30) & 4ull) | ((rb >> 45) & 8ull)) | (last ? 256ull : 0ull);
+                    ((rb & 1ull) | ((rb >> 15) & 2ull) | ((rb >> 30) & 4ull) | ((rb >> 45) & 8ull)) | ((TS ? fin : last) ? 256ull : 0ull);
             if (l < ND)
                 ring[Geo::RING_OFF + (b * ENT + P) * 64 + lane] = l < len ? make_double2(rec.z * scale, rec.y - mu) : make_double2(1.0, 0.0);
         }
@@ -223,8 +251,10 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
             }
             if (worker && is_rot) {                           // rotation over the closing window (identity when there is none)
                 double2* dst = ring + Geo::ROT_OFF + (b * P + jr) * 4 + q;
-                dst[0] = make_double2(ec, es);
-                if (two) dst[4] = make_double2(e1, -es);
+                // (the final chunk leaves the frame: its rotation carries the frame factor, S -> the true D = (G A) S (G A)^T)
+                const double f0 = fin ? g0 : 1.0, f1 = fin ? g1 : 1.0;
+                dst[0] = make_double2(ec * f0, es * f0);
+                if (two) dst[4] = make_double2(e1 * f1, -es * f1);
             }
         }
         j0 += len;
@@ -245,7 +275,8 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         ps_wait += ps_t0 - ps_t1;
         ps_n++;
 #endif
-        if (last) break;
+        if (TS ? fin : last) break;
+        fin = last;
     }
 #if defined(CARMA_WIN_STAMPS)
     if (blockIdx.x == 0 && lane == 0)
@@ -253,11 +284,111 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
                ps_work / (unsigned long long)ps_n, ps_wait / (unsigned long long)ps_n);
 #endif
     tail(pw);
-    __syncthreads();                                          // the recursion wave's barrier in front of its last chunk
+    // the recursion wave's barrier in front of its last chunk (TS: that barrier was the final chunk's)
+    if (!TS) __syncthreads();
 }
 
-// wave A.  Returns the log-likelihood of the row's evaluation (row-uniform).
+// The merge of a two-sided evaluation (rows 2k: forward over the first half, 2k + 1: backward over the second half of the series).
+// After the final chunk's start the virtual lanes of the forward row hold the columns of Da and -a  (z_m | first half ~ N(a, V + Da)),
+// those of the backward row the columns of Db and -beta  (u_m = V^-1 z_m | second half ~ N(beta, V^-1 + Db)), and
+//     log p(y) = l_a + l_b - 1/2 log det N + w.N^-1 a + (beta / 2).N^-1 (Da beta) ,   N = I - Da Db ,  w = beta + Db a / 2
+// (tests/tools/proto/two_sided.py; V does not appear, and the diagonal rescaling of the coordinates by powers of two -- forward
+// z / 2^e, backward u 2^e -- is a similarity of N).  The lanes of the BACKWARD row hold the COLUMNS of the bordered matrix
+//     [ N  a  Da beta ]      lanes ND .. 15: columns of N;  lane ND - 1: a;  lane ND - 2: Da beta
+//     [ w    0    0   ]      (rows P and P + 1 are never pivot rows)
+//     [ beta/2  0  0  ]
+// and eliminate its first P columns with row pivoting -- the pivot search is a compare chain inside lane ND + k, the row exchange
+// a select in every lane, the multipliers come by DPP broadcast --, after which the border holds -w.N^-1 a and -(beta/2).N^-1 Da beta
+// and the pivots the determinant.  Both go into the row's accumulators: |pivot| as a "variance", -2 x the quadratic terms as chi^2.
 template <int P>
+__device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], double nu, double2* __restrict__ ring, LogLikAcc& acc)
+{
+    using Geo = PipeWGeom<P>;
+    constexpr int ND = Geo::ND, ST = Geo::MRG_STRIDE;
+    const int l = lane & 15, q = lane >> 4;
+    const bool bwd = (q & 1) != 0, virt = l >= ND;
+    double* mrg = reinterpret_cast<double*>(ring + Geo::MRG_OFF) + (q >> 1) * (P * ST);
+    // forward row: column s of Da and -a_s to LDS (the wave's own LDS operations execute in order: no barrier)
+    if (!bwd && virt) {
+        double* dst = mrg + (l - ND) * ST;
+#pragma unroll
+        for (int r = 0; r < P; r++) dst[r] = kf[r];
+        dst[P] = nu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double av[P];                                             // a
+#pragma unroll
+    for (int k = 0; k < P; k++) av[k] = mrg[k * ST + P];
+    // x: what this lane's column is the product of Da with;  col_i = base_i - sum_k Da_ik x_k
+    //   lane ND + j:  x = Db[:, j] (own registers), base = e_j      -> column j of N = I - Da Db
+    //   lane ND - 2:  x = -beta, base = 0                           -> Da beta
+    //   lane ND - 1:  x = 0,     base = a                           -> a
+    // (nu holds the NEGATED means on both sides; the quadratic terms are bilinear in (a, beta) jointly, so the two signs cancel and
+    // "a", "beta" below are simply the registers' values)
+    double x[P], col[P + 2];
+    double betak[P];
+    static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        betak[k] = Grp<16>::template bcast_c<ND + k>(nu);     // beta_k (backward rows)
+    });
+#pragma unroll
+    for (int k = 0; k < P; k++) x[k] = virt ? kf[k] : (l == ND - 2 ? -betak[k] : 0.0);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        double c0 = virt ? (l - ND == i ? 1.0 : 0.0) : (l == ND - 1 ? av[i] : 0.0);
+#pragma unroll
+        for (int k = 0; k < P; k++) c0 = fma(-mrg[k * ST + i], x[k], c0);      // Da_ik = Da_ki: column k, row i
+        col[i] = c0;
+    }
+    // border rows (columns of N only): w_j = beta_j + 1/2 sum_k Db_kj a_k,  beta_j / 2
+    {
+        double wj = nu;
+#pragma unroll
+        for (int k = 0; k < P; k++) wj = fma(0.5 * kf[k], av[k], wj);
+        col[P] = virt ? wj : 0.0;
+        col[P + 1] = virt ? 0.5 * nu : 0.0;
+    }
+    double piv = 1.0;
+    static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        // pivot row: the largest |col_i|, i >= k, of column k (lane ND + k decides)
+        int idx = k;
+        double best = fabs(col[k]);
+#pragma unroll
+        for (int i = k + 1; i < P; i++) {
+            const double v = fabs(col[i]);
+            const bool gt = v > best;
+            best = gt ? v : best;
+            idx = gt ? i : idx;
+        }
+        idx = Grp<16>::template bcast_c<ND + k>(idx);
+        double ck = col[k];
+#pragma unroll
+        for (int i = k + 1; i < P; i++) {
+            const bool sel = idx == i;
+            const double ci = col[i];
+            col[i] = sel ? col[k] : ci;
+            ck = sel ? ci : ck;
+        }
+        col[k] = ck;
+        if (l == ND + k) piv = ck;
+        const double r = -recip(ck);
+#pragma unroll
+        for (int i = k + 1; i < P + 2; i++) {
+            const double li = Grp<16>::template bcast_c<ND + k>(col[i] * r);    // -(multiplier of row i), from the pivot column's lane
+            col[i] = fma(li, ck, col[i]);
+        }
+    });
+    if (bwd) {
+        if (virt) acc.add_var(fabs(piv));
+        // border: col[P] in lane ND - 1 = -(w.N^-1 a), col[P + 1] in lane ND - 2 = -(beta/2).N^-1 (Da beta);  l += Q  <=>  chi2 -= 2 Q
+        acc.chi2 += l == ND - 1 ? 2.0 * col[P] : (l == ND - 2 ? 2.0 * col[P + 1] : 0.0);
+    }
+}
+
+// wave A.  Returns the log-likelihood of the row's evaluation (row-uniform; TS: of the two rows of an evaluation together).
+template <int P, bool TS = false>
 __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<P>& rc, double2* __restrict__ ring)
 {
     using Geo = PipeWGeom<P>;
@@ -338,9 +469,10 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
         mA = mB = mn;
         nuA = nuB = nun;
     };
-    // one chunk: the pivots, the log-likelihood terms, the start of the next chunk.  Returns true behind the last chunk.
+    // one chunk: the pivots, the log-likelihood terms, the start of the next chunk.  Returns true behind the last chunk (TS: when
+    // the chunk it has just started is the final one, whose start is all there is to it).
     auto chunk = [&](double(&kk)[P], double(&hh)[P], double(&kn)[P], double(&hn)[P], int c) __attribute__((always_inline)) -> bool {
-        const bool last = (hdr & 256ull) != 0ull;
+        const bool last = !TS && (hdr & 256ull) != 0ull;
         double2 en2[ENT];
         unsigned long long hdr2 = 0;
         // barrier c + 1 (chunk c + 1 is in the ring) and its loads: in FRONT of the pivots, so that the loads have a chunk to
@@ -368,16 +500,24 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
         for (int r = 0; r < ENT; r++) en[r] = en2[r];
         hdr = hdr2;
         start((c + 1) % NB, kk, kn, hn);
-        return false;
+        return TS && (hdr & 256ull) != 0ull;
     };
     __syncthreads();                                          // barrier 0
     load(0, en, hdr);
     start(0, ka, kb, hb);
     for (int c = 0;; c += 2) {
-        if (chunk(kb, hb, ka, ha, c)) break;
-        if (chunk(ka, ha, kb, hb, c + 1)) break;
+        if (chunk(kb, hb, ka, ha, c)) {
+            if constexpr (TS) pipew_merge<P>(lane, ka, nuA, ring, acc);
+            break;
+        }
+        if (chunk(ka, ha, kb, hb, c + 1)) {
+            if constexpr (TS) pipew_merge<P>(lane, kb, nuA, ring, acc);
+            break;
+        }
     }
-    return Grp<16>::sum(acc.total());
+    double ll = Grp<16>::sum(acc.total());
+    if constexpr (TS) ll += __shfl_xor(ll, 16, 64);           // forward + backward row (+ the merge, in the backward row's sums)
+    return ll;
 }
 
 }  // namespace carma
