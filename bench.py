@@ -51,6 +51,9 @@ def main():
                     help="N > 1: seconds after which the run ends without the ladder-sharded leg (it is the only leg with an "
                          "exchange between the ranks)")
     ap.add_argument("--ladder-iters", type=int, default=150)
+    ap.add_argument("--no-api", action="store_true", help="skip the legs through the drop-in Python API (the reference's own workloads: "
+                    "the notebook's run_mcmc(20000) on OGLE, the README's run_mcmc(50000), choose_order(pmax=7))")
+    ap.add_argument("--api-scale", type=float, default=1.0, help="fraction of the API legs' iteration counts (tests use 0.02)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -514,9 +517,94 @@ def main():
             }
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(t, y, yerr, p, q, max_stdev, pool_h[0], args.cpu_seconds)
+        if world == 1 and not args.no_api:
+            try:
+                res.update(api_legs(args.api_scale, None if args.no_cpu else res.get("cpu_baseline")))
+            except Exception as ex:                                   # noqa: BLE001 (the headline line does not depend on these legs)
+                res["api_legs_error"] = repr(ex)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def api_legs(scale, cpu):
+    """The reference's OWN workloads through the drop-in Python API (carmcmc.CarmaModel, not the C ABI):
+      quickstart_ogle   CarmaModel(t, y, yerr, p=6, q=0).run_mcmc(20000) on OGLE-LMC-LPV-00007 -- the notebook's "about 10-15 minutes"
+                        (examples/carma_pack_guide.ipynb:302-327): 30 000 iterations of ONE ladder of 10 temperatures
+      readme_run        CarmaModel(p=5, q=3).run_mcmc(50000) on the README series (README.md:65-71): 75 000 iterations x 10 temperatures
+      choose_order      choose_order(pmax=7, ntrials=100) on OGLE (28 orders, carma_pack.py:131-192)
+    each with the wall time split into: the sampler call (run_mcmc_carma: start values, chains on the device, samples to the host),
+    the post-hoc log-likelihood batch (carma_pack.py:305-315), the sigma_noise batch, and the rest of CarmaSample's construction;
+    beside it the cpu_baseline port's single-thread estimate for the same number of Kalman evaluations."""
+    import carmcmc as cm
+    from carma_pack_amd import _carmcmc as lib
+    from carma_pack_amd import carma_pack as cp
+    og = np.loadtxt(os.path.join(ROOT, "tests", "golden", "ogle_lmc_lpv_00007.dat"))
+    to, yo, eo = og[:, 0] - og[:, 0].min(), og[:, 1], og[:, 2]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "carma53_readme.npz"))
+    cpu1 = (cpu or {}).get("single_thread_value")
+
+    def timed_run(t, y, e, p, q, nsamples):
+        acc = {"sampler": 0.0, "loglik_batch": 0.0, "sigma_noise": 0.0}
+        orig_run, orig_sig = lib.run_mcmc_carma, lib.sigma_noise_batch
+
+        def run(*a, **k):
+            t0 = time.perf_counter()
+            obj = orig_run(*a, **k)
+            acc["sampler"] += time.perf_counter() - t0
+            ob = obj.getLogDensityBatch
+
+            def batch(*aa, **kk):
+                t1 = time.perf_counter()
+                r = ob(*aa, **kk)
+                acc["loglik_batch"] += time.perf_counter() - t1
+                return r
+            obj.getLogDensityBatch = batch
+            return obj
+
+        def sig(*a, **k):
+            t0 = time.perf_counter()
+            r = orig_sig(*a, **k)
+            acc["sigma_noise"] += time.perf_counter() - t0
+            return r
+        lib.run_mcmc_carma, lib.sigma_noise_batch = run, sig
+        try:
+            t0 = time.perf_counter()
+            model = cm.CarmaModel(t, y, e, p=p, q=q)
+            sample = model.run_mcmc(nsamples, seed=20260101)
+            wall = time.perf_counter() - t0
+        finally:
+            lib.run_mcmc_carma, lib.sigma_noise_batch = orig_run, orig_sig
+        ntemp = max(10, p + q)
+        iters = nsamples + nsamples // 2
+        evals = iters * ntemp + nsamples
+        lp = sample.get_samples("logpost")
+        out = {"call": "CarmaModel(t, y, yerr, p=%d, q=%d).run_mcmc(%d)" % (p, q, nsamples), "n": int(len(t)), "wall_s": wall,
+               "iterations": iters, "temperatures": ntemp, "iterations_per_s": iters / acc["sampler"], "kalman_evals": evals,
+               "split_s": {"sampler_call": acc["sampler"], "post_hoc_loglik_batch": acc["loglik_batch"], "sigma_noise_batch": acc["sigma_noise"],
+                           "carma_sample_rest": wall - sum(acc.values())},
+               "samples": int(lp.size), "logpost_finite": bool(np.all(np.isfinite(lp)))}
+        if cpu1:
+            # the CPU port's single-thread rate is for CARMA(5,3), n = 270: scaled by the step count n p^2 of this call
+            rate = cpu1 * (270.0 * 25.0) / (len(t) * float(p * p))
+            out["cpu_port_single_thread_estimate_s"] = evals / rate
+        return out
+
+    res = {}
+    ns1, ns2 = max(200, int(20000 * scale)), max(200, int(50000 * scale))
+    res["quickstart_ogle"] = timed_run(to, yo, eo, 6, 0, ns1)
+    res["quickstart_ogle"]["reference_statement"] = "about 10-15 minutes (examples/carma_pack_guide.ipynb:302-327; hardware not stated)"
+    res["readme_run"] = timed_run(g["t"], g["y"], g["yerr"], 5, 3, ns2)
+    t0 = time.perf_counter()
+    model = cm.CarmaModel(to, yo, eo)
+    ntr = max(4, int(100 * min(1.0, scale * 5)))
+    best, pqlist, aicc = model.choose_order(7, ntrials=ntr, seed=5)
+    res["choose_order"] = {"call": "CarmaModel(t, y, yerr).choose_order(7, ntrials=%d) on OGLE-LMC-LPV-00007" % ntr, "wall_s": time.perf_counter() - t0,
+                           "orders": len(pqlist), "chosen": [int(model.p), int(model.q)], "aicc_min": float(np.min(aicc))}
+    if scale != 1.0:
+        for k in res:
+            res[k]["scale"] = scale
+    return res
 
 
 def _pci_bus_id(dev_index):

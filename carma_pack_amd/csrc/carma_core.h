@@ -473,8 +473,9 @@ struct RhoPair {
 #define CARMA_MARK_DUMP(who, k)                                                                                   \
     do {                                                                                                            \
         if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                                             \
-            printf("%s %d: start %lld | +%lld +%lld +%lld +%lld cycles\n", who, k, mark_[0], mark_[1] ? mark_[1] - mark_[0] : 0, \
-                   mark_[2] ? mark_[2] - mark_[0] : 0, mark_[3] ? mark_[3] - mark_[0] : 0, mark_[4] ? mark_[4] - mark_[0] : 0);   \
+            printf("%s %d: start %lld | +%lld +%lld +%lld +%lld +%lld +%lld +%lld cycles\n", who, k, mark_[0], mark_[1] ? mark_[1] - mark_[0] : 0, \
+                   mark_[2] ? mark_[2] - mark_[0] : 0, mark_[3] ? mark_[3] - mark_[0] : 0, mark_[4] ? mark_[4] - mark_[0] : 0,   \
+                   mark_[5] ? mark_[5] - mark_[0] : 0, mark_[6] ? mark_[6] - mark_[0] : 0, mark_[7] ? mark_[7] - mark_[0] : 0);   \
     } while (0)
 #else
 #define CARMA_STAMP(var) do { } while (0)

@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w(const double* __restric
 // The TWO-SIDED window pipeline (round 6): an evaluation takes TWO DPP rows -- the even row filters the first half of the series
 // forward, the odd row the second half backward (carma_pipew.h, TS), and the two states are merged at the meeting time -- so the
 // serial chain of kfilter.cpp:189-215 is half as long.  Two evaluations per workgroup.
+// Which wave plays which part: as k_logdens_carma_w.  (Measured and dropped, profiles/r06/w2_check_v2.txt: with two workgroups per
+// CU, two producer waves per workgroup on the SIMDs without a recursion wave and the set-up wave idle -- one producer then makes two
+// passes per chunk, and the recursion wave waits for it: 28.0 against 25.1 us per 1024 evaluations.)
 template <int P>
 __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restrict__ theta, int B, int d, int q,
                                                           const double4* __restrict__ series, int n, Prior pr,
@@ -220,30 +223,88 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
     const bool live = e < B;
     if (!live) e = B - 1;
     using Geo = PipeWGeom<P>;
-    math_tab_fill(reinterpret_cast<double*>(ring + Geo::TAB_OFF));
+    CARMA_MARK_DECL;
+    CARMA_MARK(0);
+    // The parameters through LDS: each lane requests ONE element of its row's vector -- together with the element of the math tables it
+    // copies -- and everything behind reads theta from the wave's own LDS copy.  (Read where they are used, the parameters were three
+    // or four dependent L2 round trips in every wave's prologue, and the tables' copy one more in front of them: a second pass over
+    // the same set-up code took 2.3 k cycles where the first took 5.6 k, profiles/r06/w2_stamps_v4.txt.)
+    const double* th;
+    {
+        double* s_th = reinterpret_cast<double*>(ring + Geo::TH_OFF) + (tid >> 6) * 64 + (lane64 & ~15);
+        const int l16 = lane64 & 15;
+        const double thv = l16 < d ? theta[e * d + l16] : 0.0;
+        double* tab = reinterpret_cast<double*>(ring + Geo::TAB_OFF);
+        const double tv = tid < MATH_TAB_N ? c_math_tab[tid] : 0.0;
+        s_th[l16] = thv;
+        if (tid < MATH_TAB_N) tab[tid] = tv;
+        static_assert(MATH_TAB_N <= 256, "one table element per thread");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        th = s_th;
+    }
     if (wave >= 2) {
-        pipew_produce<P, true>(g, wave - 2, theta + e * d, series, n, ring, [](int) {});
+#if defined(CARMA_STAMPS)
+        pipew_produce<P, true>(g, wave - 2, th, series, n, ring, [](int) {}, mark_);
+        CARMA_MARK_DUMP("two-sided producer: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", wave - 2);
+#else
+        pipew_produce<P, true>(g, wave - 2, th, series, n, ring, [](int) {});
+#endif
+        __syncthreads();                                      // (the set-up wave's hand-over, below)
         return;
     }
     Model<P> m;
     if (wave == 1) {
-        model_from_theta<P, 16, MODEL_FLAGS>(g, theta + e * d, q, pr, ignore_prior, m);
+        // the third producer FIRST -- prior bounds and log prior (carpack.hpp:118-126, 178-191; carpack.cpp:314-374) are wanted at the
+        // very end only, and in front of the pipeline they kept the first chunk waiting (the other waves were at the first barrier
+        // 3.5 k cycles before this one: profiles/r06/w2_stamps_v3.txt); now they run while the recursion wave merges
+#if defined(CARMA_STAMPS)
+        pipew_produce<P, true>(g, 2, th, series, n, ring, [](int) {}, mark_);
+        CARMA_MARK_DUMP("two-sided set-up wave: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", 2);
+#else
+        pipew_produce<P, true>(g, 2, th, series, n, ring, [](int) {});
+#endif
+        model_from_theta<P, 16, MODEL_FLAGS>(g, th, q, pr, ignore_prior, m);
         const double lpri = log_prior(m.scale, pr.measerr_dof);
         if ((lane64 & 15) == 0) ring[Geo::OUT_OFF + (lane64 >> 4)] = make_double2(lpri, m.valid ? 1.0 : 0.0);
-        pipew_produce<P, true>(g, 2, theta + e * d, series, n, ring, [](int) {});
+        __syncthreads();
         return;
     }
-    model_from_theta<P, 16, MODEL_CONSTS>(g, theta + e * d, q, pr, ignore_prior, m);
+    model_from_theta<P, 16, MODEL_CONSTS>(g, th, q, pr, ignore_prior, m);
+    CARMA_MARK(1);
+#if defined(CARMA_STAMPS) && defined(CARMA_STAMP_TWICE)
+    {
+        // the same set-up once more (instructions now cached, theta in the L1): what a warm pass costs
+        const double* th2 = th;
+        asm volatile("" : "+v"(th2));
+        long long w0 = clock64();
+        Model<P> m2;
+        model_from_theta<P, 16, MODEL_CONSTS>(g, th2, q, pr, ignore_prior, m2);
+        double sink = m2.sigsqr + m2.kap.re + m2.b.re;
+        asm volatile("" : "+v"(sink));
+        long long w1 = clock64();
+        if (blockIdx.x == 0 && lane64 == 0) printf("set-up a second time: %lld cycles (first: %lld)\n", w1 - w0, mark_[1] - mark_[0]);
+    }
+#endif
     FilterConsts<P> fc;
     filter_reset<P, 16>(g, m, fc);
     RowConsts<P> rc;
     row_consts<P>(g, m, fc, rc);
+    CARMA_MARK(2);
+#if defined(CARMA_STAMPS)
+    double ll = pipew_recur<P, true>(g, rc, ring, mark_);
+#else
     double ll = pipew_recur<P, true>(g, rc, ring);
+#endif
+    __syncthreads();                                          // the set-up wave's {log prior, valid}
     const double2 o = ring[Geo::OUT_OFF + (lane64 >> 4)];
     ll += o.x;
     const double ninf = -1.0 / 0.0;
     if (m.sing || o.y == 0.0) ll = ninf;
     if (live && (lane64 & 31) == 0) out[e] = ll;
+    CARMA_MARK(7);
+    CARMA_MARK_DUMP("two-sided recursion: model, reset, barrier 0, first start, last start, merge, end", 0);
 }
 
 // Throughput regime proper (tens of thousands of evaluations): ONE EVALUATION PER LANE (carma_lane.h) -- nothing crosses
@@ -706,7 +767,8 @@ static LdShape logdens_shape(long B, int n, int series_flags)
     constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
-    if (B <= win2_max_evals() && n >= 16 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS"))) return LdShape::WIN2;
+    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS")))
+        return LdShape::WIN2;                         // (CARMA_TUNE_WIN_ROWS = 0: no window pipeline of either kind)
     if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS"))) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
     if (B > lpc_min_evals<P>() && B <= lpc_max_evals<P>() && n >= 8) return LdShape::LPC;

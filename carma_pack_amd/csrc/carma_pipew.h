@@ -43,6 +43,12 @@
 
 namespace carma {
 
+#if defined(CARMA_STAMPS)
+#define PIPEW_MARK(i) do { if (mk) { __builtin_amdgcn_sched_barrier(0); mk[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define PIPEW_MARK(i) do { } while (0)
+#endif
+
 template <int P>
 struct PipeWGeom {
     static constexpr int ND = 16 - P;                         // data lanes of a row
@@ -54,9 +60,15 @@ struct PipeWGeom {
     static constexpr int CONST_OFF = HDR_OFF + NB;            // double2 {h_r, c_r}[64]
     static constexpr int OUT_OFF = CONST_OFF + 64;            // double2 {log prior, valid}[4] from the set-up wave
     static constexpr int TAB_OFF = OUT_OFF + 4;               // double[MATH_TAB_N]: tables of the short exp / sincos (carma_math.h)
-    static constexpr int MRG_OFF = TAB_OFF + MATH_TAB_N / 2;  // two-sided kernels: double[2][P][P + 1], the forward rows' (D, -a) for the merge
+    static constexpr int MRG_OFF = TAB_OFF + MATH_TAB_N / 2;  // two-sided kernels, per evaluation (2): the merge's exchange area (pipew_merge)
     static constexpr int MRG_STRIDE = P + 1 + ((P + 1) & 1);  // (doubles per column: an even count, so that columns are double2 aligned)
-    static constexpr int ENTRIES = MRG_OFF + (2 * P * MRG_STRIDE + 1) / 2;
+    static constexpr int MRG_X = 0;                           //   double[P][ST]  the forward row's columns of Da and -a
+    static constexpr int MRG_COL = MRG_X + P * MRG_STRIDE;    //   double[ST]     the pivot column of a step
+    static constexpr int MRG_L = MRG_COL + MRG_STRIDE;        //   double[P][ST]  L, row i = lane ND + i's
+    static constexpr int MRG_T = MRG_L + P * MRG_STRIDE;      //   double[P][ST]  T = Db L, row i = lane ND + i's; [i][P] = u_i
+    static constexpr int MRG_DOUBLES = MRG_T + P * MRG_STRIDE;
+    static constexpr int TH_OFF = MRG_OFF + (2 * MRG_DOUBLES + 1) / 2;   // two-sided log-density kernel: double[4 waves][4 rows][16], theta per row
+    static constexpr int ENTRIES = TH_OFF + 128;
     static constexpr int NPROD = 3;                           // producer waves: P0, P1 and the set-up wave once it is through
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(double2);
     static constexpr double LIM_RE = Pipe3LGeom<P>::LIM_RE, LIM_IM = Pipe3LGeom<P>::LIM_IM;
@@ -71,7 +83,8 @@ struct PipeWGeom {
 // coordinates (frame factor g included), where pipew_recur merges them.
 template <int P, bool TS = false, class Tail>
 __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
-                                              const double4* __restrict__ series, int n_all, double2* __restrict__ ring, Tail&& tail)
+                                              const double4* __restrict__ series, int n_all, double2* __restrict__ ring, Tail&& tail,
+                                              long long* mk = nullptr)
 {
     using Geo = PipeWGeom<P>;
     constexpr int ND = Geo::ND, NB = Geo::NB, ENT = Geo::ENT;
@@ -88,6 +101,25 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     const bool bwd = TS && (q & 1);
     const int nfwd = (n_all + 1) / 2;
     const int n = TS ? (bwd ? n_all - nfwd : nfwd) : n_all;
+    // (a backward row walks the series from its end, in the negated time)
+    auto recat = [=](int j) {
+        const int jj = j < n ? j : n - 1;
+        double4 r = series[bwd ? n_all - 1 - jj : jj];
+        if (bwd) r.w = -r.w;
+        return r;
+    };
+    // The chunk schedule is data dependent (a chunk ends in front of a re-base datum), so the records of a chunk cannot be
+    // requested by index a chunk ahead as in carma_pipe3l.h -- and a global load at the head of every chunk would put an L2
+    // round trip on every chunk (measured: 45 us per launch instead of 22).  So each row keeps a WINDOW of 64 records in
+    // registers, lane l holding records jw + l, jw + 16 + l, jw + 32 + l, jw + 48 + l; a chunk's sixteen records lie in the
+    // first two and are fetched from their lanes (ds_bpermute); when the row has moved past the first sixteen the window
+    // shifts and the next sixteen are requested, two shifts before they are needed.
+    // (Requested FIRST: nothing in front of the first barrier depends on them, and behind the roots' exponentials their L2 round
+    // trip was one more serial latency of the prologue.)
+    int jw = 0;
+    double4 rw0 = recat(l), rw1 = recat(16 + l), rw2 = recat(32 + l), rw3 = recat(48 + l);
+    const double t_first = recat(0).w;
+    const double t_meet = TS ? (bwd ? -series[nfwd - 1].w : series[nfwd - 1].w) : 0.0;    // the last forward datum's time
     Cx w = own_ar_root<P>(theta, jr);
     Cx w1 = two ? own_ar_root<P>(theta, jr + 1) : w;
     if (bwd) {                                                // F^T instead of F: the conjugate roots
@@ -127,24 +159,10 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     }
     // schedule state of this row (row-uniform)
     int j0 = 0;
-    // (a backward row walks the series from its end, in the negated time)
-    auto recat = [=](int j) {
-        const int jj = j < n ? j : n - 1;
-        double4 r = series[bwd ? n_all - 1 - jj : jj];
-        if (bwd) r.w = -r.w;
-        return r;
-    };
-    double base = recat(0).w;
-    const double t_meet = TS ? (bwd ? -series[nfwd - 1].w : series[nfwd - 1].w) : 0.0;    // the last forward datum's time
-    // The chunk schedule is data dependent (a chunk ends in front of a re-base datum), so the records of a chunk cannot be
-    // requested by index a chunk ahead as in carma_pipe3l.h -- and a global load at the head of every chunk would put an L2
-    // round trip on every chunk (measured: 45 us per launch instead of 22).  So each row keeps a WINDOW of 64 records in
-    // registers, lane l holding records jw + l, jw + 16 + l, jw + 32 + l, jw + 48 + l; a chunk's sixteen records lie in the
-    // first two and are fetched from their lanes (ds_bpermute); when the row has moved past the first sixteen the window
-    // shifts and the next sixteen are requested, two shifts before they are needed.
-    int jw = 0;
-    double4 rw0 = recat(l), rw1 = recat(16 + l), rw2 = recat(32 + l), rw3 = recat(48 + l);
+    double base = t_first;
+    PIPEW_MARK(1);
     __syncthreads();                                          // the recursion wave has published (h_r, c_r)
+    PIPEW_MARK(2);
     double2 hc_own, hc_par;
     {
         const double2* cst = ring + Geo::CONST_OFF + rowb;
@@ -269,7 +287,9 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         WIN_STAMP(ps_t1);
         ps_work += ps_t1 - ps_t0;
 #endif
+        if (c < 3) PIPEW_MARK(3 + 2 * c - (c == 2));           // chunk 0, 1: arrival at the barrier (marks 3, 5); chunk 2: mark 6
         __syncthreads();                                      // barrier c: chunk c is in the ring
+        if (c == 0) PIPEW_MARK(4);
 #if defined(CARMA_WIN_STAMPS)
         WIN_STAMP(ps_t0);
         ps_wait += ps_t0 - ps_t1;
@@ -290,16 +310,45 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
 
 // The merge of a two-sided evaluation (rows 2k: forward over the first half, 2k + 1: backward over the second half of the series).
 // After the final chunk's start the virtual lanes of the forward row hold the columns of Da and -a  (z_m | first half ~ N(a, V + Da)),
-// those of the backward row the columns of Db and -beta  (u_m = V^-1 z_m | second half ~ N(beta, V^-1 + Db)), and
-//     log p(y) = l_a + l_b - 1/2 log det N + w.N^-1 a + (beta / 2).N^-1 (Da beta) ,   N = I - Da Db ,  w = beta + Db a / 2
-// (tests/tools/proto/two_sided.py; V does not appear, and the diagonal rescaling of the coordinates by powers of two -- forward
-// z / 2^e, backward u 2^e -- is a similarity of N).  The lanes of the BACKWARD row hold the COLUMNS of the bordered matrix
-//     [ N  a  Da beta ]      lanes ND .. 15: columns of N;  lane ND - 1: a;  lane ND - 2: Da beta
-//     [ w    0    0   ]      (rows P and P + 1 are never pivot rows)
-//     [ beta/2  0  0  ]
-// and eliminate its first P columns with row pivoting -- the pivot search is a compare chain inside lane ND + k, the row exchange
-// a select in every lane, the multipliers come by DPP broadcast --, after which the border holds -w.N^-1 a and -(beta/2).N^-1 Da beta
-// and the pivots the determinant.  Both go into the row's accumulators: |pivot| as a "variance", -2 x the quadratic terms as chi^2.
+// those of the backward row the columns of Db and -beta  (u_m = V^-1 z_m | second half ~ N(beta, V^-1 + Db)).  With X = -Da, Y = -Db
+// (both positive semidefinite; alpha ~ N(0, X), beta ~ N(0, Y), E[alpha beta^T] = Da Db, sufficient statistics of the two halves)
+//     log p(y) = l_a + l_b - 1/2 log det W + beta.a - 1/2 a.Y a - 1/2 |C^-1 L^T (Y a - beta)|^2 ,   X = L L^T,  W = I - L^T Y L = C C^T
+// (tests/tools/proto/two_sided.py: merge_chol / lane_merge_chol; V does not appear, and the diagonal rescaling of the coordinates by
+// powers of two -- forward z / 2^e, backward u 2^e -- cancels in every term).  Why not simply N = I - Da Db and an LU (the first
+// version): in modal coordinates of nearly coincident roots X has entries ~ 1 / separation^2 that cancel in the product, and N loses
+// what the recursions kept (roots 1e-6 apart: 1.5e-3 against the one-pass filter's 3e-6, this form 6e-9; two real roots 6e-4 apart,
+// inside the prior's bounds: 3e-5 against 6e-8).  Why X = L L^T with DIAGONAL PIVOTING: X is numerically rank deficient as a rule -- a
+// half of the series says nothing about the modes that have decayed by the meeting time, and the two coordinates of a pair can carry
+// one direction only -- and in any fixed order a pivot at rounding level met before an informative one grows into it (pivots
+// 1, 0.93, 1e-13, 1e-2, 1e-2 in root order against 1, 0.93, 0.1, 1e-2, 1e-14 pivoted: errors up to 7e-4 on the parity sweeps'
+// prior-like entries, profiles/r06/merge_pivots_v1.txt); with the largest remaining diagonal as the pivot whatever is left when
+// the pivots reach rounding level is at that level too, and is dropped.
+// Lanes ND + j of the BACKWARD row hold column j throughout.  The pivot of a step is found by a 4-step DPP maximum over a 32-bit
+// key (upper half of the diagonal, lane number in the low bits), its column goes through LDS -- the one place where a register
+// index would be a run-time value --, the update X_ij -= l_i l_j takes both factors from that column, so that the Schur complement
+// stays symmetric bit for bit.  T = Db L by broadcasts, W and the border v = L^T (Y a - beta) through LDS again (lane m takes
+// column m: pivot order, not coordinate order), W = C C^T without pivoting (positive definite).  The pivots of W go into the row's
+// accumulators as "variances", the quadratic terms as chi^2.
+CARMA_DEV double rsqrt_pos(double d)
+{
+#ifdef __HIPCC__
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y0, y0, 1.0);                   // 1 - d y0^2
+    return fma(y0, fma(0.375 * e, e, 0.5 * e), y0);           // one cubic step: e^3 ~ 1e-22
+#else
+    return 1.0 / sqrt(d);
+#endif
+}
+// (release by the writing lanes, acquire by the reading ones: the LDS operations of ONE wave execute in order, but without the pair
+// the compiler moves the other rows' loads above the stores -- they are different threads to it)
+CARMA_DEV void merge_lds_sync()
+{
+#ifdef __HIPCC__
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 template <int P>
 __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], double nu, double2* __restrict__ ring, LogLikAcc& acc)
 {
@@ -307,89 +356,156 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     constexpr int ND = Geo::ND, ST = Geo::MRG_STRIDE;
     const int l = lane & 15, q = lane >> 4;
     const bool bwd = (q & 1) != 0, virt = l >= ND;
-    double* mrg = reinterpret_cast<double*>(ring + Geo::MRG_OFF) + (q >> 1) * (P * ST);
-    // forward row: column s of Da and -a_s to LDS (the wave's own LDS operations execute in order: no barrier)
+    const int j = virt ? l - ND : 0;                          // this lane's column (the other lanes' results are not used)
+    double* mrg = reinterpret_cast<double*>(ring + Geo::MRG_OFF) + (q >> 1) * Geo::MRG_DOUBLES;
+    double* colb = mrg + Geo::MRG_COL;
+    // forward row: column s of Da and -a_s to LDS
     if (!bwd && virt) {
-        double* dst = mrg + (l - ND) * ST;
+        double* dst = mrg + Geo::MRG_X + j * ST;
 #pragma unroll
         for (int r = 0; r < P; r++) dst[r] = kf[r];
         dst[P] = nu;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    double av[P];                                             // a
-#pragma unroll
-    for (int k = 0; k < P; k++) av[k] = mrg[k * ST + P];
-    // x: what this lane's column is the product of Da with;  col_i = base_i - sum_k Da_ik x_k
-    //   lane ND + j:  x = Db[:, j] (own registers), base = e_j      -> column j of N = I - Da Db
-    //   lane ND - 2:  x = -beta, base = 0                           -> Da beta
-    //   lane ND - 1:  x = 0,     base = a                           -> a
-    // (nu holds the NEGATED means on both sides; the quadratic terms are bilinear in (a, beta) jointly, so the two signs cancel and
-    // "a", "beta" below are simply the registers' values)
-    double x[P], col[P + 2];
-    double betak[P];
-    static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        betak[k] = Grp<16>::template bcast_c<ND + k>(nu);     // beta_k (backward rows)
-    });
-#pragma unroll
-    for (int k = 0; k < P; k++) x[k] = virt ? kf[k] : (l == ND - 2 ? -betak[k] : 0.0);
+    merge_lds_sync();
+    // (nu holds the NEGATED means on both sides: every term below is bilinear in (a, beta) jointly, so "a" and "beta" are simply
+    // the registers' values)
+    double S[P], av[P];
 #pragma unroll
     for (int i = 0; i < P; i++) {
-        double c0 = virt ? (l - ND == i ? 1.0 : 0.0) : (l == ND - 1 ? av[i] : 0.0);
-#pragma unroll
-        for (int k = 0; k < P; k++) c0 = fma(-mrg[k * ST + i], x[k], c0);      // Da_ik = Da_ki: column k, row i
-        col[i] = c0;
+        // X_ij from ONE of the two stored elements (i, j), (j, i): the recursion's S is symmetric up to rounding only, and the
+        // elimination below must see a matrix that is symmetric bit for bit
+        S[i] = -mrg[Geo::MRG_X + (i >= j ? j * ST + i : i * ST + j)];
+        av[i] = mrg[Geo::MRG_X + i * ST + P];                 // a_i
     }
-    // border rows (columns of N only): w_j = beta_j + 1/2 sum_k Db_kj a_k,  beta_j / 2
+    double aj = mrg[Geo::MRG_X + j * ST + P];
+    // Equilibration by exact powers of two, X <- D X D, Y <- D^-1 Y D^-1, a <- D a, beta <- D^-1 beta with D_kk ~ 1 / sqrt(X_kk): every
+    // term below is invariant, and "a pivot at rounding level" gets a meaning (the diagonal of X is in [1, 4) wherever it is positive).
+    // The recursions' coordinates are scaled for THEIR sums (carma_pipe3l.h): a coordinate can sit at 1e-300 in X and 1e+300 in Y.
+    int sj = 0;
+    double dg = -mrg[Geo::MRG_X + j * ST + j];                // own diagonal, kept beside S[] (where its index is the lane's number)
     {
-        double wj = nu;
-#pragma unroll
-        for (int k = 0; k < P; k++) wj = fma(0.5 * kf[k], av[k], wj);
-        col[P] = virt ? wj : 0.0;
-        col[P + 1] = virt ? 0.5 * nu : 0.0;
+        int ex;
+        (void)frexp(dg, &ex);
+        if (dg > 0.0 && dg < 1.0 / 0.0) sj = -(ex >> 1);
     }
-    double piv = 1.0;
+    dg = ldexp(dg, 2 * sj);
+    double kfs[P];
+    static_for<0, P>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const int si = Grp<16>::template bcast_c<ND + i>(sj);
+        S[i] = ldexp(S[i], si + sj);
+        kfs[i] = ldexp(kf[i], -si - sj);
+        av[i] = ldexp(av[i], si);
+    });
+    aj = ldexp(aj, sj);
+    nu = ldexp(nu, -sj);
+    // ---- X = L L^T with diagonal pivoting.  Lane j keeps ROW j of L: Lr[m] = L_jm, m the step.
+    double Lr[P];
+    bool done = !virt;
+    static_for<0, P>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        // the largest remaining diagonal (a key of its upper 28 bits and the lane: the lowest lane wins a tie); nothing above
+        // rounding level left: no pivot, a zero column
+        unsigned key = (!done && dg > 4e-15) ? (((unsigned)__double2hiint(dg) & ~0xFu) | (unsigned)(15 - l)) : 0u;
+#ifdef __HIPCC__
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_QUAD_XOR1, 0xf, 0xf, true));
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_QUAD_XOR2, 0xf, 0xf, true));
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true));
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_ROW_MIRROR, 0xf, 0xf, true));
+#endif
+        const bool any = key != 0u;
+        const int pl = 15 - (int)(key & 15u);                 // the pivot's lane in the row (row-uniform)
+        const bool isp = any && l == pl;
+        if (isp && bwd) {
+#pragma unroll
+            for (int i = 0; i < P; i++) colb[i] = S[i];
+        }
+        merge_lds_sync();
+        const int pc = any ? pl - ND : 0;
+        const double dpiv = colb[pc];
+        const double r1 = any ? rsqrt_pos(dpiv) : 0.0;
+        // X_ij -= l_i l_j, l = (pivot column) / sqrt(pivot): the same two factors for both members of a symmetric pair
+        const double lj = done ? 0.0 : colb[j] * r1;          // (the pivot's own: sqrt(pivot))
+        Lr[m] = lj;
+#pragma unroll
+        for (int i = 0; i < P; i++) S[i] = fma(-(colb[i] * r1), lj, S[i]);
+        dg = fma(-lj, lj, dg);
+        done = done || isp;
+        merge_lds_sync();                                     // (the next step's column must not overtake these reads)
+    });
+    // ---- T = Db L  (= -Y L):  T_im = sum_k Db_ik L_km, row i in lane i (Db_ik = this lane's kfs[k]: symmetric), L_km by broadcast
+    double T[P];
+#pragma unroll
+    for (int m = 0; m < P; m++) T[m] = 0.0;
     static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        // pivot row: the largest |col_i|, i >= k, of column k (lane ND + k decides)
-        int idx = k;
-        double best = fabs(col[k]);
 #pragma unroll
-        for (int i = k + 1; i < P; i++) {
-            const double v = fabs(col[i]);
-            const bool gt = v > best;
-            best = gt ? v : best;
-            idx = gt ? i : idx;
-        }
-        idx = Grp<16>::template bcast_c<ND + k>(idx);
-        double ck = col[k];
-#pragma unroll
-        for (int i = k + 1; i < P; i++) {
-            const bool sel = idx == i;
-            const double ci = col[i];
-            col[i] = sel ? col[k] : ci;
-            ck = sel ? ci : ck;
-        }
-        col[k] = ck;
-        if (l == ND + k) piv = ck;
-        const double r = -recip(ck);
-#pragma unroll
-        for (int i = k + 1; i < P + 2; i++) {
-            const double li = Grp<16>::template bcast_c<ND + k>(col[i] * r);    // -(multiplier of row i), from the pivot column's lane
-            col[i] = fma(li, ck, col[i]);
-        }
+        for (int m = 0; m < P; m++) T[m] = fma(kfs[k], Grp<16>::template bcast_c<ND + k>(Lr[m]), T[m]);
     });
-    if (bwd) {
-        if (virt) acc.add_var(fabs(piv));
-        // border: col[P] in lane ND - 1 = -(w.N^-1 a), col[P + 1] in lane ND - 2 = -(beta/2).N^-1 (Da beta);  l += Q  <=>  chi2 -= 2 Q
-        acc.chi2 += l == ND - 1 ? 2.0 * col[P] : (l == ND - 2 ? 2.0 * col[P + 1] : 0.0);
+    // u = Y a - beta (lane j: u_j, from its own column of Db)
+    double dba = 0.0;
+#pragma unroll
+    for (int k = 0; k < P; k++) dba = fma(kfs[k], av[k], dba);                 // (Db a)_j
+    const double uj = -nu - dba;
+    // ---- W = I - L^T Y L = I + L^T T and the border v = L^T u, column m to lane m (pivot order) through LDS
+    if (bwd && virt) {
+        double* lb = mrg + Geo::MRG_L + j * ST;
+        double* tb = mrg + Geo::MRG_T + j * ST;
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+            lb[m] = Lr[m];
+            tb[m] = T[m];
+        }
+        tb[P] = uj;
+    }
+    merge_lds_sync();
+    double Wc[P + 1];
+    {
+        double tm[P], lm[P], v = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            tm[i] = mrg[Geo::MRG_T + i * ST + j];             // T_ij: row i, this lane's column
+            lm[i] = mrg[Geo::MRG_L + i * ST + j];             // L_ij
+            v = fma(lm[i], mrg[Geo::MRG_T + i * ST + P], v);  // v_j = sum_i L_ij u_i
+        }
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            double w = j == k ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < P; i++) w = fma(mrg[Geo::MRG_L + i * ST + k], tm[i], w);      // W_kj = delta + sum_i L_ik T_ij
+            Wc[k] = w;
+        }
+        Wc[P] = v;
+    }
+    // ---- W = C C^T as L D L^T with the border row riding along: s_k^2 = (border entry of column k)^2 / d_k
+    double piv = 1.0, s2 = 0.0;
+    static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const double dk = Grp<16>::template bcast_c<ND + k>(Wc[k]);
+        const double rk = recip(dk);
+        if (l == ND + k) {
+            piv = Wc[k];
+            s2 = Wc[P] * Wc[P] * rk;
+        }
+        const double f = l > ND + k ? Wc[k] * rk : 0.0;
+#pragma unroll
+        for (int i = k + 1; i < P + 1; i++) Wc[i] = fma(-Grp<16>::template bcast_c<ND + k>(Wc[i]), f, Wc[i]);
+    });
+#if defined(CARMA_MERGE_DEBUG)
+    if (blockIdx.x == 0 && q < 2 && virt) {
+        printf("merge %s lane %d: in kf %.17g %.17g %.17g nu %.17g | sj %d Lr %.6g %.6g %.6g | T %.6g %.6g %.6g | W %.6g %.6g %.6g border %.6g | piv %.17g s2 %.6g dba %.6g aj %.6g\n",
+               bwd ? "bwd" : "fwd", j, kf[0], kf[1], kf[P - 1], nu, sj, Lr[0], Lr[1], Lr[P - 1], T[0], T[1], T[P - 1], Wc[0], Wc[1], Wc[P - 1], Wc[P], piv, s2, dba, aj);
+    }
+#endif
+    if (bwd && virt) {
+        acc.add_var(piv);                                                       // -1/2 log det W
+        // beta.a - 1/2 a.Y a = sum_j a_j (beta_j + 1/2 (Db a)_j);  - 1/2 s^2;   l += Q  <=>  chi2 -= 2 Q
+        acc.chi2 += s2 - 2.0 * aj * fma(0.5, dba, nu);
     }
 }
 
-// wave A.  Returns the log-likelihood of the row's evaluation (row-uniform; TS: of the two rows of an evaluation together).
 template <int P, bool TS = false>
-__device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<P>& rc, double2* __restrict__ ring)
+__device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<P>& rc, double2* __restrict__ ring, long long* mk = nullptr)
 {
     using Geo = PipeWGeom<P>;
     using WA = WinAsm<P>;
@@ -503,18 +619,23 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
         return TS && (hdr & 256ull) != 0ull;
     };
     __syncthreads();                                          // barrier 0
+    PIPEW_MARK(3);
     load(0, en, hdr);
     start(0, ka, kb, hb);
+    PIPEW_MARK(4);
     for (int c = 0;; c += 2) {
         if (chunk(kb, hb, ka, ha, c)) {
+            PIPEW_MARK(5);
             if constexpr (TS) pipew_merge<P>(lane, ka, nuA, ring, acc);
             break;
         }
         if (chunk(ka, ha, kb, hb, c + 1)) {
+            PIPEW_MARK(5);
             if constexpr (TS) pipew_merge<P>(lane, kb, nuA, ring, acc);
             break;
         }
     }
+    PIPEW_MARK(6);
     double ll = Grp<16>::sum(acc.total());
     if constexpr (TS) ll += __shfl_xor(ll, 16, 64);           // forward + backward row (+ the merge, in the backward row's sums)
     return ll;

@@ -32,10 +32,19 @@ def _json_line(out):
 
 def test_single_gpu_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5", "--mcmc-iters", "200",
-                        "--cpu-seconds", "1", "--ladder-iters", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-seconds", "1", "--ladder-iters", "20", "--api-scale", "0.02"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert KEYS | {"cpu_baseline"} <= set(j)
+    # the reference's own workloads through the drop-in Python API (round 6; scaled down here)
+    assert "api_legs_error" not in j, j.get("api_legs_error")
+    for k, call in (("quickstart_ogle", "p=6, q=0"), ("readme_run", "p=5, q=3")):
+        a = j[k]
+        assert call in a["call"] and a["wall_s"] > 0 and a["logpost_finite"] and a["temperatures"] == 10 and a["samples"] >= 200
+        assert set(a["split_s"]) == {"sampler_call", "post_hoc_loglik_batch", "sigma_noise_batch", "carma_sample_rest"}
+        assert abs(sum(a["split_s"].values()) - a["wall_s"]) < 1e-6 * max(1.0, a["wall_s"]) and min(a["split_s"].values()) >= 0.0
+        assert a["cpu_port_single_thread_estimate_s"] > 0
+    assert j["choose_order"]["orders"] == 28 and j["choose_order"]["wall_s"] > 0 and 1 <= j["choose_order"]["chosen"][0] <= 7
     assert j["n_gpus"] == 1 and j["steps"] == 50 and j["unit"] == "evals/s" and j["dtype"] == "f64"
     assert j["finite_in_last_batch"] == 1024 and j["value"] > 1e6           # north_star target on one GPU
     rf, cb = j["roofline"], j["cpu_baseline"]
@@ -43,7 +52,7 @@ def test_single_gpu_line():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 1024) < 1e-6 * 1024
     # the kernel label comes from the library's own launch table, the counters from a profile of that very kernel
-    assert rf["kernel"] == "k_logdens_carma_w<5>" and rf["binding_resource"] == "fp64_valu_issue"      # (round 5: the windowed pipeline)
+    assert rf["kernel"] == "k_logdens_carma_w2<5>" and rf["binding_resource"] == "fp64_valu_issue"      # (round 6: the two-sided windowed pipeline)
     assert rf["traffic"] is None or (rf["traffic_source"] and rf["traffic"] < rf["algorithmic_bytes_per_launch"])
     # no fraction on the line may exceed 1, and counters are attached only when they were measured on the running build
     def fracs(o, path=""):

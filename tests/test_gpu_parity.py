@@ -307,7 +307,7 @@ def test_launch_shapes_agree(cpa, p, q):
     # each the same bits whatever the launch size; CARMA_TUNE_WIN_ROWS=0 (the suite's cross-section on the one-datum pipeline)
     # puts all five on the latter
     win = os.environ.get("CARMA_TUNE_WIN_ROWS") != "0"
-    assert ctx.kernel_name(1000) == ("k_logdens_carma_w<%d>" if win else "k_logdens_carma_p3l<%d>") % p
+    assert ctx.kernel_name(1000) == ("k_logdens_carma_w2<%d>" if win else "k_logdens_carma_p3l<%d>") % p
     assert ctx.kernel_name(1100) == "k_logdens_carma_p3l<%d>" % p
     assert np.array_equal(res["p3"], res["p3b"], equal_nan=True)
     for name in ("p3d", "p3e") + (() if win else ("p3",)):           # one kernel, whatever the number of workgroups per CU

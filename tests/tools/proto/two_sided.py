@@ -13,9 +13,23 @@ V^-1 + Db), both propagated to ONE meeting time.  With alpha, beta as random var
 Cov alpha = -Da, Cov beta = -Db, E[alpha beta^T] = Da E[u z^T] Db = Da Db (the halves are independent given z_m), and
 alpha / beta are sufficient for z_m, so with N = I - Da Db
 
-    log p(y) = l_a + l_b - 1/2 log det N + beta.N^-1 a + 1/2 beta.N^-1 Da beta + 1/2 (Db a).N^-1 a
+    log p(y) = l_a + l_b - 1/2 log det N + beta.N^-1 a + 1/2 beta.N^-1 Da beta + 1/2 (Db a).N^-1 a            (merge)
 
 -- one p x p factorisation per evaluation, again without V.  (N has its eigenvalues in (0, 1]: -Da < V, -Db < V^-1.)
+
+What the DEVICE evaluates is the same quantity through a congruence (merge_chol): with X = -Da = L L^T, Y = -Db,
+W = I - L^T Y L = C C^T (symmetric, eigenvalues in (0, 1])
+
+    log p(y) = l_a + l_b - 1/2 log det W + beta.a - 1/2 a.Y a - 1/2 |C^-1 L^T (Y a - beta)|^2
+
+because in modal coordinates of nearly coincident roots X has entries ~ 1 / separation^2 which cancel in the product X Y,
+and the plain N loses what the two recursions kept (roots 1e-6 apart: 1.5e-3 from the exact value, the one-pass filter
+3e-6, merge_chol 4e-6).  X = L L^T takes DIAGONAL PIVOTING: X is numerically rank deficient as a rule (a half of the series
+says nothing about modes that have decayed by the meeting time; the two coordinates of a pair can carry one direction), and
+in a fixed order a pivot at rounding level met before an informative one grows into it.  lane_merge_chol is the computation
+as the lanes do it (carma_pipew.h pipew_merge): X read symmetric bit for bit and equilibrated by powers of two, right-looking
+l_i l_j updates with both factors from the pivot column (so that the Schur complement stays symmetric), what is left when
+the pivots reach rounding level dropped, the border row v = L^T (Y a - beta) riding along in the factorisation of W.
 
 loglik_two_sided(...) below is the plain recursion on both sides (loglik_std of lazy_frame.py); the window / lane forms of
 the device run the same two recursions chunk by chunk."""
@@ -70,12 +84,96 @@ def merge(Da, a, Db, beta):
     return -0.5 * logdet + beta @ x1 + 0.5 * beta @ x2 + 0.5 * (Db @ a) @ x1
 
 
-def loglik_two_sided(t, y, yerr, theta, p, q, m=None, where="left"):
-    """m data on the forward side (default n // 2); meeting time t[m-1] ("left"), t[m] ("right") or halfway ("mid")."""
+def chol_psd(X, tau=1e-15):
+    """X = L L^T (columns in pivot order) with diagonal pivoting: the largest remaining diagonal is the pivot; what is left when
+    the pivots reach rounding level (<= tau x the largest original diagonal) is dropped."""
+    p = X.shape[0]
+    A = X.copy()
+    L = np.zeros((p, p))
+    done = np.zeros(p, bool)
+    top = max(np.max(np.diag(X)), 0.0)
+    for m in range(p):
+        dgs = np.where(done, -np.inf, np.diag(A))
+        k = int(np.argmax(dgs))
+        if not dgs[k] > tau * top:
+            break
+        L[:, m] = np.where(done, 0.0, A[:, k] / np.sqrt(dgs[k]))
+        A -= np.outer(L[:, m], L[:, m])
+        done[k] = True
+    return L
+
+
+def merge_chol(Da, a, Db, beta):
+    """The same quantity as merge() through the congruence by the Cholesky factor of X = -Da (see the module text)."""
+    X, Y = -0.5 * (Da + Da.T), -Db
+    d = 1.0 / np.sqrt(np.where(np.diag(X) > 0, np.diag(X), 1.0))
+    L = chol_psd(X * d[:, None] * d[None, :]) / d[:, None]      # (equilibrated, so that the threshold has a meaning)
+    T = Y @ L
+    W = np.eye(a.size) - L.T @ T
+    v = T.T @ a - L.T @ beta
+    C = np.linalg.cholesky(W)
+    s = np.linalg.solve(C, v)
+    return -np.sum(np.log(np.diag(C))) + beta @ a - 0.5 * a @ (Y @ a) - 0.5 * s @ s
+
+
+def lane_merge_chol(Da, a, Db, beta):
+    """merge_chol as pipew_merge lays it out: lane j holds column j of the Schur complement and ROW j of L (Lr[j][m] = L_jm, m the
+    step); the pivot of a step is the largest remaining diagonal, its column is what every lane updates with."""
+    P = a.size
+    S = np.array([[-(Da[i, j] if i >= j else Da[j, i]) for i in range(P)] for j in range(P)])      # S[j][i] = X_ij, lane j
+    kf = np.array([[Db[i, j] for i in range(P)] for j in range(P)])
+    # equilibration by powers of two (X <- D X D, Y <- D^-1 Y D^-1, a <- D a, beta <- D^-1 beta: every term is invariant), so that
+    # "a pivot at rounding level" has a meaning: the diagonal of X is in [1, 4) wherever it is positive
+    sj = np.array([-(int(np.frexp(S[j][j])[1]) >> 1) if S[j][j] > 0 and np.isfinite(S[j][j]) else 0 for j in range(P)])
+    S = np.array([[np.ldexp(S[j][i], int(sj[i] + sj[j])) for i in range(P)] for j in range(P)])
+    kf = np.array([[np.ldexp(kf[j][i], int(-sj[i] - sj[j])) for i in range(P)] for j in range(P)])
+    a = np.ldexp(a, sj)
+    beta = np.ldexp(beta, -sj)
+    dg = np.array([S[j][j] for j in range(P)])
+    done = np.zeros(P, bool)
+    Lr = np.zeros((P, P))
+    for m in range(P):
+        cand = np.where(~done & (dg > 4e-15), dg, -1.0)
+        pc = int(np.argmax(cand))
+        if cand[pc] <= 0.0:
+            continue                                              # nothing above rounding level left: zero columns
+        col = S[pc].copy()
+        r1 = 1.0 / np.sqrt(col[pc])
+        lj = np.where(done, 0.0, col * r1)
+        Lr[:, m] = lj
+        for j in range(P):
+            S[j] = S[j] - (col * r1) * lj[j]
+        dg = dg - lj * lj
+        done[pc] = True
+    T = np.array([[sum(kf[i][k] * Lr[k][m] for k in range(P)) for m in range(P)] for i in range(P)])      # T[i][m] = (Db L)_im
+    dba = np.array([kf[j] @ a for j in range(P)])
+    u = -beta - dba
+    W = np.zeros((P, P + 1))                                                                         # W[j][k] = W_kj, lane j
+    for j in range(P):
+        for k in range(P):
+            W[j][k] = (1.0 if j == k else 0.0) + sum(Lr[i][k] * T[i][j] for i in range(P))
+        W[j][P] = sum(Lr[i][j] * u[i] for i in range(P))
+    piv, s2 = np.ones(P), np.zeros(P)
+    for k in range(P):
+        dk = W[k][k]
+        piv[k], s2[k] = dk, W[k][P] ** 2 / dk
+        f = np.array([W[j][k] / dk if j > k else 0.0 for j in range(P)])
+        bc = W[k].copy()
+        for i in range(k + 1, P + 1):
+            for j in range(P):
+                W[j][i] -= bc[i] * f[j]
+    return -0.5 * np.sum(np.log(piv)) - 0.5 * np.sum(s2 - 2.0 * a * (0.5 * dba + beta))
+
+
+def loglik_two_sided(t, y, yerr, theta, p, q, m=None, where="left", merge_fn=None):
+    """m data on the forward side (default (n + 1) // 2, the device's split); meeting time t[m-1] ("left", the device's), t[m]
+    ("right") or halfway ("mid")."""
+    if merge_fn is None:
+        merge_fn = merge_chol
     om, h, Vz, pairs = real_model(theta, p, q)
     n = t.size
     if m is None:
-        m = n // 2
+        m = (n + 1) // 2
     yc = y - theta[2]
     e = theta[1] * yerr ** 2
     c = Vz @ h
@@ -85,7 +183,7 @@ def loglik_two_sided(t, y, yerr, theta, p, q, m=None, where="left"):
     tm = {"left": t[m - 1], "right": t[m], "mid": 0.5 * (t[m - 1] + t[m])}[where]
     la, Da, a = half_filter(om, pairs, p, h, c, s0, t[:m], yc[:m], e[:m], tm, False)
     lb, Db, beta = half_filter(om, pairs, p, c, h, s0, t[m:][::-1], yc[m:][::-1], e[m:][::-1], tm, True)
-    return la + lb + merge(Da, a, Db, beta)
+    return la + lb + merge_fn(Da, a, Db, beta)
 
 
 def loglik_one_pass(t, y, yerr, theta, p, q):

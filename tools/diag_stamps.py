@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import carma_pack_amd._lib as L0  # product lib (for Context class)
 import ctypes as C
-diag = os.path.join(ROOT, "build_diag", "libcarma_mi355_diag.so")
+diag = os.environ.get("CARMA_DIAG_LIB") or os.path.join(ROOT, "build_diag", "libcarma_mi355_diag.so")
 L0.LIB_PATH = diag
 L0.lib = L0._load()
 from carma_pack_amd.synth import theta_batch

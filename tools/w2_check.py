@@ -20,6 +20,15 @@ def rel(a, b):
     out[fin] = np.abs(a[fin] - b[fin]) / np.maximum(1.0, np.abs(b[fin]))
     out[~fin] = np.where((a[~fin] == b[~fin]) | (np.isnan(a[~fin]) & np.isnan(b[~fin])), 0.0, np.inf)
     return out
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import loglik_truth
+th0 = g["theta"][0]
+ill = []
+for eps in (1e-3, 1e-4, 1e-5, 1e-6):
+    x = th0.copy(); x[5:7] = th0[3:5] + eps; ill.append(x)
+ill = np.array(ill)
+tr = np.array([loglik_truth(t, y, e, x, 5, 3)[0] for x in ill])
+orc_ill = m.logdensity_batch(ill, ignore_prior=True)
 for name, env in (("w2", {}), ("w", {"CARMA_TUNE_WIN2_EVALS": "0"}), ("p3l", {"CARMA_TUNE_WIN2_EVALS": "0", "CARMA_TUNE_WIN_ROWS": "0"})):
     for k in ("CARMA_TUNE_WIN2_EVALS", "CARMA_TUNE_WIN_ROWS"):
         os.environ.pop(k, None)
@@ -27,6 +36,9 @@ for name, env in (("w2", {}), ("w", {"CARMA_TUNE_WIN2_EVALS": "0"}), ("p3l", {"C
     got = ctx.logdensity(th)
     r = rel(got, ref)
     print(name, ctx.kernel_name(th.shape[0]), "max rel %.2e  median %.2e  >1e-10: %d  nonfinite mismatch %d" % (np.max(r[np.isfinite(r)]), np.median(r), np.sum(r > 1e-10), np.sum(~np.isfinite(r))), flush=True)
+    gi = ctx.logdensity(ill, ignore_prior=True)
+    print("  roots 1e-3 .. 1e-6 apart, distance from the exact value: device", ["%.1e" % v for v in np.abs(gi - tr) / np.abs(tr)],
+          "oracle", ["%.1e" % v for v in np.abs(orc_ill - tr) / np.abs(tr)])
     if name == "w2":
         bad = np.argsort(r)[-5:]
         print("  worst:", [(int(i), float(got[i]), float(ref[i])) for i in bad])
