@@ -116,6 +116,8 @@ def _load():
     L.carma_logdensity_batch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
     L.carma_logdensity_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.carma_logdensity_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.carma_tune_set.argtypes = [C.c_char_p, C.c_long]
+    L.carma_tune_set.restype = C.c_int
     L.carma_mle_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
                                     C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.carma_mle_batched.restype = C.c_int
@@ -189,8 +191,21 @@ EXPORTS = [
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_sample_sharded", "carma_pt_boundary_stats",
     "carma_pt_boundary_check", "carma_pt_sweep", "carma_pt_kernel_in_use", "carma_pt_debug_draws", "carma_pt_get_factor",
-    "carma_pt_set_factor",
+    "carma_pt_set_factor", "carma_tune_set",
 ]
+
+
+def tune_set(name, value):
+    """Move a launch-shape switch ("WIN_ROWS", "WIN2_EVALS", "PT_ROW_WIN": carma_tune_set; measurements and parity tests).
+    value None: back to the library's default."""
+    check(lib.carma_tune_set(str(name).encode(), -2 ** 63 if value is None else int(value)), "carma_tune_set")
+
+
+def tune_reset():
+    """Every switch back to what the environment said when the library read it (CARMA_TUNE_<name>), or to the default."""
+    for name in ("WIN_ROWS", "WIN2_EVALS", "PT_ROW_WIN"):
+        e = os.environ.get("CARMA_TUNE_" + name)
+        tune_set(name, None if e is None else int(e))
 
 
 def last_error():

@@ -444,6 +444,8 @@ int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len)
     return logdens_kernel_name(c->p, B, c->n, buf, len, c->series_flags()) > 0 ? CARMA_OK : CARMA_EINVAL;
 }
 
+int carma_tune_set(const char* name, long value) { return tune_set(name, value) == 0 ? CARMA_OK : CARMA_EINVAL; }
+
 int carma_normalize_roots(int p, const double* omega_re_im, double* out)
 {
     if (p < 1 || p > CARMA_PMAX || !omega_re_im || !out) return CARMA_EINVAL;

@@ -468,14 +468,17 @@ struct RhoPair {
 #define CARMA_STAMP_DECL unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sa = 0, sb = 0, sc = 0, sd = 0
 #define CARMA_STAMP_ACC(acc, a, b) acc += (b) - (a)
 // phase marks of a whole wave (core clock, relative to the wave's first mark), printed by workgroup 0
-#define CARMA_MARK_DECL long long mark_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CARMA_MARK_DECL long long mark_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define CARMA_MARK(i) do { __builtin_amdgcn_sched_barrier(0); mark_[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define CARMA_MARK_DUMP(who, k)                                                                                   \
     do {                                                                                                            \
         if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                                             \
-            printf("%s %d: start %lld | +%lld +%lld +%lld +%lld +%lld +%lld +%lld cycles\n", who, k, mark_[0], mark_[1] ? mark_[1] - mark_[0] : 0, \
-                   mark_[2] ? mark_[2] - mark_[0] : 0, mark_[3] ? mark_[3] - mark_[0] : 0, mark_[4] ? mark_[4] - mark_[0] : 0,   \
-                   mark_[5] ? mark_[5] - mark_[0] : 0, mark_[6] ? mark_[6] - mark_[0] : 0, mark_[7] ? mark_[7] - mark_[0] : 0);   \
+            printf("%s %d: start %lld | +%lld +%lld +%lld +%lld +%lld +%lld +%lld | +%lld +%lld +%lld +%lld +%lld +%lld cycles\n", who, k, mark_[0],   \
+                   mark_[1] ? mark_[1] - mark_[0] : 0, mark_[2] ? mark_[2] - mark_[0] : 0, mark_[3] ? mark_[3] - mark_[0] : 0,           \
+                   mark_[4] ? mark_[4] - mark_[0] : 0, mark_[5] ? mark_[5] - mark_[0] : 0, mark_[6] ? mark_[6] - mark_[0] : 0,           \
+                   mark_[7] ? mark_[7] - mark_[0] : 0, mark_[8] ? mark_[8] - mark_[0] : 0, mark_[9] ? mark_[9] - mark_[0] : 0,           \
+                   mark_[10] ? mark_[10] - mark_[0] : 0, mark_[11] ? mark_[11] - mark_[0] : 0, mark_[12] ? mark_[12] - mark_[0] : 0,     \
+                   mark_[13] ? mark_[13] - mark_[0] : 0);                                                                                 \
     } while (0)
 #else
 #define CARMA_STAMP(var) do { } while (0)

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "grp_device.h"
 #include "carma_core.h"
@@ -677,22 +678,58 @@ static long p3l_max_rows()
 
 // Launch shape for B evaluations of order P (one table for the launcher and for carma_logdensity_kernel_name)
 enum class LdShape { P3L, PC1, PC2, PLAIN1, PLAIN4, LANE, LPC, WIN, WIN2 };
+// The launch-shape switches (carma_launch.h): environment read once, atomics afterwards.
+static const char* const TUNE_NAMES[TUNE_COUNT] = {"CARMA_TUNE_WIN_ROWS", "CARMA_TUNE_WIN2_EVALS", "CARMA_TUNE_PT_ROW_WIN"};
+static std::atomic<long> g_tune[TUNE_COUNT];
+static std::atomic<int> g_tune_init{0};
+static void tune_init()
+{
+    if (g_tune_init.load(std::memory_order_acquire) == 2) return;
+    int expect = 0;
+    if (g_tune_init.compare_exchange_strong(expect, 1)) {
+        for (int i = 0; i < TUNE_COUNT; i++) {
+            const char* e = getenv(TUNE_NAMES[i]);
+            g_tune[i].store(e ? atol(e) : TUNE_UNSET, std::memory_order_relaxed);
+        }
+        g_tune_init.store(2, std::memory_order_release);
+    } else {
+        while (g_tune_init.load(std::memory_order_acquire) != 2) {}
+    }
+}
+long tune_get(int which)
+{
+    tune_init();
+    return which >= 0 && which < TUNE_COUNT ? g_tune[which].load(std::memory_order_relaxed) : TUNE_UNSET;
+}
+int tune_set(const char* name, long value)
+{
+    if (!name) return -1;
+    tune_init();
+    for (int i = 0; i < TUNE_COUNT; i++)
+        if (!strcmp(name, TUNE_NAMES[i]) || !strcmp(name, TUNE_NAMES[i] + 11)) {       // (+ 11: behind "CARMA_TUNE_")
+            g_tune[i].store(value, std::memory_order_relaxed);
+            return 0;
+        }
+    return -1;
+}
 // Largest launch (in workgroups of four evaluations) that takes the windowed wave pipeline (carma_pipew.h): one workgroup per CU
 // (measured per order at 1024 evaluations, profiles/r05/window_pipeline_v1.txt: 1-10 % ahead of the one-datum pipeline; with two
-// or three workgroups per CU that one is ahead).  CARMA_TUNE_WIN_ROWS overrides (0: never) -- read at EVERY launch, so that one
-// test process can run both pipelines.
+// or three workgroups per CU that one is ahead).  CARMA_TUNE_WIN_ROWS overrides (0: never, also for the two-sided kernel), so that
+// one test process can run both pipelines (carma_tune_set).
 static long win_max_rows()
 {
-    const char* e = getenv("CARMA_TUNE_WIN_ROWS");
-    return e ? atol(e) : (long)device_cus();
+    const long v = tune_get(TUNE_WIN_ROWS);
+    return v != TUNE_UNSET ? v : (long)device_cus();
 }
 // Largest launch (in EVALUATIONS) that takes the two-sided window pipeline: two workgroups of two evaluations per CU.
-// CARMA_TUNE_WIN2_EVALS overrides (0: never) -- read at every launch, as above.
+// CARMA_TUNE_WIN2_EVALS overrides (0: never).
 static long win2_max_evals()
 {
-    const char* e = getenv("CARMA_TUNE_WIN2_EVALS");
-    return e ? atol(e) : 4L * device_cus();
+    const long v = tune_get(TUNE_WIN2_EVALS);
+    return v != TUNE_UNSET ? v : 4L * device_cus();
 }
+// (an override of CARMA_TUNE_WIN_ROWS also lifts the series criterion: the tests force the window pipelines onto series that fail it)
+static bool win_forced() { return tune_get(TUNE_WIN_ROWS) != TUNE_UNSET; }
 // smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
 static long lane_min_evals(int p = 5)
 {
@@ -767,9 +804,9 @@ static LdShape logdens_shape(long B, int n, int series_flags)
     constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
-    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS")))
+    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && ((series_flags & SERIES_WINDOW_OK) || win_forced()))
         return LdShape::WIN2;                         // (CARMA_TUNE_WIN_ROWS = 0: no window pipeline of either kind)
-    if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || getenv("CARMA_TUNE_WIN_ROWS"))) return LdShape::WIN;
+    if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || win_forced())) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
     if (B > lpc_min_evals<P>() && B <= lpc_max_evals<P>() && n >= 8) return LdShape::LPC;
     if (B >= lane_min_evals(P)) return LdShape::LANE;

@@ -9,6 +9,14 @@ namespace carma {
 // compute units of the current device (cached per device)
 int device_cus();
 
+// Launch-shape switches that measurements and the parity tests move: read from the environment ONCE, when the
+// first launch asks (CARMA_TUNE_WIN_ROWS, CARMA_TUNE_WIN2_EVALS, CARMA_TUNE_PT_ROW_WIN), held in atomics, and moved afterwards through
+// carma_tune_set only -- no getenv() in the launch path (it raced with setenv() in multi-threaded callers).  TUNE_UNSET: the default.
+enum { TUNE_WIN_ROWS = 0, TUNE_WIN2_EVALS = 1, TUNE_PT_ROW_WIN = 2, TUNE_COUNT = 3 };
+constexpr long TUNE_UNSET = -0x7fffffffffffffffL - 1;
+long tune_get(int which);                    // TUNE_UNSET or the override
+int tune_set(const char* name, long value);  // "WIN_ROWS" / "WIN2_EVALS" / "PT_ROW_WIN" (or the full CARMA_TUNE_ name); 0 or -1
+
 // repeated_dt: a good part of the series' time steps equal their predecessor (regular cadence): the throughput kernels
 // then run the variant that re-uses the transition factors of such steps (carma_core.h, RhoInline DTC)
 hipError_t launch_logdens_carma(int p, const double* theta, int B, int d, int q, const double4* series, int n,

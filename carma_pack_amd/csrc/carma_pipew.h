@@ -63,10 +63,7 @@ struct PipeWGeom {
     static constexpr int MRG_OFF = TAB_OFF + MATH_TAB_N / 2;  // two-sided kernels, per evaluation (2): the merge's exchange area (pipew_merge)
     static constexpr int MRG_STRIDE = P + 1 + ((P + 1) & 1);  // (doubles per column: an even count, so that columns are double2 aligned)
     static constexpr int MRG_X = 0;                           //   double[P][ST]  the forward row's columns of Da and -a
-    static constexpr int MRG_COL = MRG_X + P * MRG_STRIDE;    //   double[ST]     the pivot column of a step
-    static constexpr int MRG_L = MRG_COL + MRG_STRIDE;        //   double[P][ST]  L, row i = lane ND + i's
-    static constexpr int MRG_T = MRG_L + P * MRG_STRIDE;      //   double[P][ST]  T = Db L, row i = lane ND + i's; [i][P] = u_i
-    static constexpr int MRG_DOUBLES = MRG_T + P * MRG_STRIDE;
+    static constexpr int MRG_DOUBLES = MRG_X + P * MRG_STRIDE;
     static constexpr int TH_OFF = MRG_OFF + (2 * MRG_DOUBLES + 1) / 2;   // two-sided log-density kernel: double[4 waves][4 rows][16], theta per row
     static constexpr int ENTRIES = TH_OFF + 128;
     static constexpr int NPROD = 3;                           // producer waves: P0, P1 and the set-up wave once it is through
@@ -160,39 +157,15 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     // schedule state of this row (row-uniform)
     int j0 = 0;
     double base = t_first;
-    PIPEW_MARK(1);
-    __syncthreads();                                          // the recursion wave has published (h_r, c_r)
-    PIPEW_MARK(2);
-    double2 hc_own, hc_par;
-    {
-        const double2* cst = ring + Geo::CONST_OFF + rowb;
-        hc_own = cst[jr];
-        hc_par = cst[jr + 1 < 16 ? jr + 1 : 15];
-        // every coordinate rescaled by an exact power of two so that |h_r| ~ sigma_y (carma_pipe3l.h)
-        const double m0 = fmax(fabs(hc_own.x), realpair ? 0.0 : fabs(hc_par.x)), m1 = realpair ? fabs(hc_par.x) : m0;
-        int e0, e1x;
-        (void)frexp(m0, &e0);
-        (void)frexp(m1, &e1x);
-        if (!(m0 > 0.0 && m0 < 1.0 / 0.0)) e0 = 0;
-        if (!(m1 > 0.0 && m1 < 1.0 / 0.0)) e1x = 0;
-        hc_own = make_double2(ldexp(hc_own.x, esig - e0), ldexp(hc_own.y, e0 - esig));
-        hc_par = make_double2(ldexp(hc_par.x, esig - e1x), ldexp(hc_par.y, e1x - esig));
-        if (bwd) {                                            // dual coordinates: h' = c, c' = V^-1 c = h (the same powers of two)
-            hc_own = make_double2(hc_own.y, hc_own.x);
-            hc_par = make_double2(hc_par.y, hc_par.x);
-        }
-    }
-#if defined(CARMA_WIN_STAMPS)
-    unsigned long long ps_work = 0, ps_wait = 0, ps_t0 = 0, ps_t1 = 0;
-    int ps_n = 0;
-#define WIN_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
-#endif
-    bool fin = false;                                         // TS: the final chunk (no data, the rotation to the meeting time)
-    for (int c = 0;; c++) {
-        const int b = c % NB;
-#if defined(CARMA_WIN_STAMPS)
-        WIN_STAMP(ps_t0);
-#endif
+    // ---- A chunk is PREPARED (its schedule and its exponentials: nothing that needs h, c) one barrier before its entries are formed:
+    // chunk 0 in front of the first barrier, while the recursion wave still sets the model up -- behind that barrier only the
+    // entries are left (round 6: the first chunk reaches the recursion wave 1.4 k cycles earlier, profiles/r06/w2_stamps_v7.txt).
+    int len = 0;
+    bool rot = false, last = false, fin = false;              // fin (TS): the final chunk (no data, the rotation to the meeting time)
+    double2 dslot = make_double2(1.0, 0.0);                   // {scale yerr^2, y - mu} of this lane's datum (pw == 0)
+    unsigned long long rbits = 0ull;
+    double ecv[NIT], esv[NIT], e1v[NIT];
+    auto prepare = [&]() __attribute__((always_inline)) {
         // --- schedule of this row's chunk: lane s looks at datum j0 + s
         const int jl = j0 + l;
         double4 rec;
@@ -221,25 +194,21 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         const double t0 = fin ? t_meet : __shfl(tj, rowb, 64);
         const double t_lastc = __shfl(tj, rowb + (ncand > 0 ? ncand - 1 : 0), 64);
         const double W = sc > 0.0 ? 1.0 / sc : 1.0 / 0.0;
-        const bool rot = fin || (ncand > 0 && (t_lastc - base) > W);
+        rot = fin || (ncand > 0 && (t_lastc - base) > W);
         const double base_old = base;
         base = rot ? t0 : base;
         // (the difference of two time stamps is exact unless the base is much the smaller of the two: carma_pipe3l.h)
         const double dta_l = tj - base;
         const unsigned long long flb = __ballot(dta_l > W && l < ncand);
         const unsigned cut = (unsigned)(flb >> (16 * q)) & 0xffffu;            // (bit 0 never: dta = 0 or <= W at slot 0)
-        const int len = cut ? __builtin_ctz(cut) : ncand;
+        len = cut ? __builtin_ctz(cut) : ncand;
         const bool row_done = j0 + len >= n;
-        const bool last = __ballot(!row_done) == 0ull;
+        last = __ballot(!row_done) == 0ull;
         if (pw == 0) {
-            const unsigned long long rb = __ballot(rot);
-            if (lane == 0)
-                reinterpret_cast<unsigned long long*>(ring + Geo::HDR_OFF)[b] =
-                    ((rb & 1ull) | ((rb >> 15) & 2ull) | ((rb >> 30) & 4ull) | ((rb >> 45) & 8ull)) | ((TS ? fin : last) ? 256ull : 0ull);
-            if (l < ND)
-                ring[Geo::RING_OFF + (b * ENT + P) * 64 + lane] = l < len ? make_double2(rec.z * scale, rec.y - mu) : make_double2(1.0, 0.0);
+            rbits = __ballot(rot);
+            dslot = l < len ? make_double2(rec.z * scale, rec.y - mu) : make_double2(1.0, 0.0);
         }
-        // --- entries
+        // --- exponentials
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int slot = it * NPROD * PPL + pw * PPL + sub;
@@ -251,6 +220,65 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
             if (live) cexp_step_tab<true>(w.re, w.im, dt, &ec, &es, tab);
             e1 = ec;
             if (realpair && live) e1 = exp_neg_tab(w1.re * dt, tab);
+            ecv[it] = ec;
+            esv[it] = es;
+            e1v[it] = e1;
+        }
+        j0 += len;
+        if (j0 - jw >= 16) {                                  // (at most one shift per chunk: len < 16)
+            rw0 = rw1;
+            rw1 = rw2;
+            rw2 = rw3;
+            jw += 16;
+            rw3 = recat(jw + 48 + l);
+        }
+    };
+    prepare();
+    PIPEW_MARK(1);
+    __syncthreads();                                          // the recursion wave has published (h_r, c_r)
+    PIPEW_MARK(2);
+    double2 hc_own, hc_par;
+    {
+        const double2* cst = ring + Geo::CONST_OFF + rowb;
+        hc_own = cst[jr];
+        hc_par = cst[jr + 1 < 16 ? jr + 1 : 15];
+        // every coordinate rescaled by an exact power of two so that |h_r| ~ sigma_y (carma_pipe3l.h)
+        const double m0 = fmax(fabs(hc_own.x), realpair ? 0.0 : fabs(hc_par.x)), m1 = realpair ? fabs(hc_par.x) : m0;
+        int e0, e1x;
+        (void)frexp(m0, &e0);
+        (void)frexp(m1, &e1x);
+        if (!(m0 > 0.0 && m0 < 1.0 / 0.0)) e0 = 0;
+        if (!(m1 > 0.0 && m1 < 1.0 / 0.0)) e1x = 0;
+        hc_own = make_double2(ldexp(hc_own.x, esig - e0), ldexp(hc_own.y, e0 - esig));
+        hc_par = make_double2(ldexp(hc_par.x, esig - e1x), ldexp(hc_par.y, e1x - esig));
+        if (bwd) {                                            // dual coordinates: h' = c, c' = V^-1 c = h (the same powers of two)
+            hc_own = make_double2(hc_own.y, hc_own.x);
+            hc_par = make_double2(hc_par.y, hc_par.x);
+        }
+    }
+#if defined(CARMA_WIN_STAMPS)
+    unsigned long long ps_work = 0, ps_wait = 0, ps_t0 = 0, ps_t1 = 0;
+    int ps_n = 0;
+#define WIN_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#endif
+    for (int c = 0;; c++) {
+        const int b = c % NB;
+#if defined(CARMA_WIN_STAMPS)
+        WIN_STAMP(ps_t0);
+#endif
+        // --- the prepared chunk's header, data slots and entries
+        if (pw == 0) {
+            if (lane == 0)
+                reinterpret_cast<unsigned long long*>(ring + Geo::HDR_OFF)[b] =
+                    ((rbits & 1ull) | ((rbits >> 15) & 2ull) | ((rbits >> 30) & 4ull) | ((rbits >> 45) & 8ull)) | ((TS ? fin : last) ? 256ull : 0ull);
+            if (l < ND) ring[Geo::RING_OFF + (b * ENT + P) * 64 + lane] = dslot;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int slot = it * NPROD * PPL + pw * PPL + sub;
+            const bool is_rot = slot == ND;
+            const bool live = worker && (is_rot ? rot : slot < len);
+            const double ec = ecv[it], es = esv[it], e1 = e1v[it];
             if (worker && slot < ND) {
                 // h~_r = (A^T h)_r = E (cos h_r + sin h_partner) ;  c~_r = (A^-1 c)_r = (cos c_r + sin c_partner) / E
                 const double gc = ec * g0, gs = es * g0;
@@ -275,14 +303,6 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
                 if (two) dst[4] = make_double2(e1 * f1, -es * f1);
             }
         }
-        j0 += len;
-        if (j0 - jw >= 16) {                                  // (at most one shift per chunk: len < 16)
-            rw0 = rw1;
-            rw1 = rw2;
-            rw2 = rw3;
-            jw += 16;
-            rw3 = recat(jw + 48 + l);
-        }
 #if defined(CARMA_WIN_STAMPS)
         WIN_STAMP(ps_t1);
         ps_work += ps_t1 - ps_t0;
@@ -297,6 +317,7 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
 #endif
         if (TS ? fin : last) break;
         fin = last;
+        prepare();                                            // the next chunk: schedule and exponentials
     }
 #if defined(CARMA_WIN_STAMPS)
     if (blockIdx.x == 0 && lane == 0)
@@ -350,7 +371,8 @@ CARMA_DEV void merge_lds_sync()
 #endif
 }
 template <int P>
-__device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], double nu, double2* __restrict__ ring, LogLikAcc& acc)
+__device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], double nu, double2* __restrict__ ring, LogLikAcc& acc,
+                                            long long* mk = nullptr)
 {
     using Geo = PipeWGeom<P>;
     constexpr int ND = Geo::ND, ST = Geo::MRG_STRIDE;
@@ -358,7 +380,6 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     const bool bwd = (q & 1) != 0, virt = l >= ND;
     const int j = virt ? l - ND : 0;                          // this lane's column (the other lanes' results are not used)
     double* mrg = reinterpret_cast<double*>(ring + Geo::MRG_OFF) + (q >> 1) * Geo::MRG_DOUBLES;
-    double* colb = mrg + Geo::MRG_COL;
     // forward row: column s of Da and -a_s to LDS
     if (!bwd && virt) {
         double* dst = mrg + Geo::MRG_X + j * ST;
@@ -399,84 +420,79 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     });
     aj = ldexp(aj, sj);
     nu = ldexp(nu, -sj);
-    // ---- X = L L^T with diagonal pivoting.  Lane j keeps ROW j of L: Lr[m] = L_jm, m the step.
-    double Lr[P];
-    bool done = !virt;
-    static_for<0, P>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int m = decltype(mc)::value;
-        // the largest remaining diagonal (a key of its upper 28 bits and the lane: the lowest lane wins a tie); nothing above
-        // rounding level left: no pivot, a zero column
-        unsigned key = (!done && dg > 4e-15) ? (((unsigned)__double2hiint(dg) & ~0xFu) | (unsigned)(15 - l)) : 0u;
-#ifdef __HIPCC__
-        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_QUAD_XOR1, 0xf, 0xf, true));
-        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_QUAD_XOR2, 0xf, 0xf, true));
-        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true));
-        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_ROW_MIRROR, 0xf, 0xf, true));
-#endif
-        const bool any = key != 0u;
-        const int pl = 15 - (int)(key & 15u);                 // the pivot's lane in the row (row-uniform)
-        const bool isp = any && l == pl;
-        if (isp && bwd) {
+    PIPEW_MARK(8);
+    // ---- X = L L^T, lanes = columns (lane k's column is column k of L), THRESHOLD PIVOTING: the coordinates are taken in their own
+    // order, but only those whose remaining diagonal is above the level's threshold -- 4e-3, 4e-6, ... of the equilibrated scale --,
+    // the others wait for a later level.  A pivot taken at a level is within 1e3 of everything taken after it, which bounds what
+    // its rounding can grow into (the diagonal-pivoting guarantee up to that factor), and every step broadcasts from a lane known at
+    // compile time: no register index is a run-time value, nothing goes through LDS (the first version pivoted on the largest
+    // diagonal and sent the pivot column through LDS: 610 cycles a step, profiles/r06/w2_stamps_v6.txt).  Empty levels and steps
+    // are skipped wave-uniformly; what is left at rounding level (4e-15) is dropped.
+    double rs_own = 0.0;                                      // 1 / sqrt(pivot) of this lane's column (0: never taken, a zero column)
+    unsigned alive_own = 0u, donemask = 0u;                   // rows alive when this lane's column was taken; coordinates taken (row-uniform)
+    bool done_own = !virt;
+    double thr = 4e-3;
+    for (int lev = 0; lev < 5; lev++, thr *= 1e-3) {
+        if (__builtin_amdgcn_ballot_w64(!done_own && dg > 4e-15) == 0ull) break;          // nothing above rounding level anywhere
+        if (__builtin_amdgcn_ballot_w64(!done_own && dg > thr) == 0ull) continue;         // nothing at this level
+        static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double dk = Grp<16>::template bcast_c<ND + k>(dg);
+            const bool take = ((donemask >> k) & 1u) == 0u && dk > thr;                   // row-uniform
+            if (__builtin_amdgcn_ballot_w64(take) == 0ull) return;
+            const double r1 = take ? rsqrt_pos(dk) : 0.0;
+            if (take && l == ND + k) {
+                rs_own = r1;
+                alive_own = ~donemask;
+                done_own = true;
+            }
+            // X_ij -= l_i l_j with l_j = X_kj / sqrt(d_k) from the lane's own row-k entry and l_i = X_ik / sqrt(d_k) from the pivot
+            // column: both members of a symmetric pair get the same two factors, so the Schur complement stays symmetric bit for bit
+            const double lj = (take && !done_own) ? S[k] * r1 : 0.0;                       // (taken lanes and the pivot's own: 0)
 #pragma unroll
-            for (int i = 0; i < P; i++) colb[i] = S[i];
-        }
-        merge_lds_sync();
-        const int pc = any ? pl - ND : 0;
-        const double dpiv = colb[pc];
-        const double r1 = any ? rsqrt_pos(dpiv) : 0.0;
-        // X_ij -= l_i l_j, l = (pivot column) / sqrt(pivot): the same two factors for both members of a symmetric pair
-        const double lj = done ? 0.0 : colb[j] * r1;          // (the pivot's own: sqrt(pivot))
-        Lr[m] = lj;
+            for (int i = 0; i < P; i++) S[i] = fma(-(Grp<16>::template bcast_c<ND + k>(S[i]) * r1), lj, S[i]);
+            dg = fma(-lj, lj, dg);
+            donemask |= take ? (1u << k) : 0u;
+        });
+    }
+    // L[:, j]: this lane's column, rows that were alive when it was taken
+    double Lc[P];
 #pragma unroll
-        for (int i = 0; i < P; i++) S[i] = fma(-(colb[i] * r1), lj, S[i]);
-        dg = fma(-lj, lj, dg);
-        done = done || isp;
-        merge_lds_sync();                                     // (the next step's column must not overtake these reads)
-    });
-    // ---- T = Db L  (= -Y L):  T_im = sum_k Db_ik L_km, row i in lane i (Db_ik = this lane's kfs[k]: symmetric), L_km by broadcast
+    for (int i = 0; i < P; i++) Lc[i] = ((alive_own >> i) & 1u) ? S[i] * rs_own : 0.0;
+    PIPEW_MARK(9);
+    // ---- T = Db L  (= -Y L):  T_ij = sum_k Db_ik L_kj, Db_ik = kfs[i] of lane ND + k
     double T[P];
 #pragma unroll
-    for (int m = 0; m < P; m++) T[m] = 0.0;
+    for (int i = 0; i < P; i++) T[i] = 0.0;
     static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
 #pragma unroll
-        for (int m = 0; m < P; m++) T[m] = fma(kfs[k], Grp<16>::template bcast_c<ND + k>(Lr[m]), T[m]);
+        for (int i = 0; i < P; i++) T[i] = fma(Grp<16>::template bcast_c<ND + k>(kfs[i]), Lc[k], T[i]);
     });
-    // u = Y a - beta (lane j: u_j, from its own column of Db)
+    PIPEW_MARK(10);
+    // ---- W = I - L^T Y L = I + L^T T:  W_ij = delta_ij + sum_k L_ki T_kj, L_ki = Lc[k] of lane ND + i;  row P: the border v
+    double Wc[P + 1];
+    static_for<0, P>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        double w = j == i ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < P; k++) w = fma(Grp<16>::template bcast_c<ND + i>(Lc[k]), T[k], w);
+        Wc[i] = w;
+    });
+    // u = Y a - beta (lane j: u_j, from its own column of Db);  v = L^T u:  v_j = sum_k L_kj u_k
     double dba = 0.0;
 #pragma unroll
     for (int k = 0; k < P; k++) dba = fma(kfs[k], av[k], dba);                 // (Db a)_j
     const double uj = -nu - dba;
-    // ---- W = I - L^T Y L = I + L^T T and the border v = L^T u, column m to lane m (pivot order) through LDS
-    if (bwd && virt) {
-        double* lb = mrg + Geo::MRG_L + j * ST;
-        double* tb = mrg + Geo::MRG_T + j * ST;
-#pragma unroll
-        for (int m = 0; m < P; m++) {
-            lb[m] = Lr[m];
-            tb[m] = T[m];
-        }
-        tb[P] = uj;
-    }
-    merge_lds_sync();
-    double Wc[P + 1];
     {
-        double tm[P], lm[P], v = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-            tm[i] = mrg[Geo::MRG_T + i * ST + j];             // T_ij: row i, this lane's column
-            lm[i] = mrg[Geo::MRG_L + i * ST + j];             // L_ij
-            v = fma(lm[i], mrg[Geo::MRG_T + i * ST + P], v);  // v_j = sum_i L_ij u_i
-        }
-#pragma unroll
-        for (int k = 0; k < P; k++) {
-            double w = j == k ? 1.0 : 0.0;
-#pragma unroll
-            for (int i = 0; i < P; i++) w = fma(mrg[Geo::MRG_L + i * ST + k], tm[i], w);      // W_kj = delta + sum_i L_ik T_ij
-            Wc[k] = w;
-        }
+        double v = 0.0;
+        static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            v = fma(Lc[k], Grp<16>::template bcast_c<ND + k>(uj), v);
+        });
         Wc[P] = v;
     }
+    PIPEW_MARK(11);
     // ---- W = C C^T as L D L^T with the border row riding along: s_k^2 = (border entry of column k)^2 / d_k
     double piv = 1.0, s2 = 0.0;
     static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
@@ -493,8 +509,8 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     });
 #if defined(CARMA_MERGE_DEBUG)
     if (blockIdx.x == 0 && q < 2 && virt) {
-        printf("merge %s lane %d: in kf %.17g %.17g %.17g nu %.17g | sj %d Lr %.6g %.6g %.6g | T %.6g %.6g %.6g | W %.6g %.6g %.6g border %.6g | piv %.17g s2 %.6g dba %.6g aj %.6g\n",
-               bwd ? "bwd" : "fwd", j, kf[0], kf[1], kf[P - 1], nu, sj, Lr[0], Lr[1], Lr[P - 1], T[0], T[1], T[P - 1], Wc[0], Wc[1], Wc[P - 1], Wc[P], piv, s2, dba, aj);
+        printf("merge %s lane %d: in kf %.17g %.17g %.17g nu %.17g | sj %d rs %.6g alive %x | Lc %.6g %.6g %.6g | W %.6g %.6g %.6g border %.6g | piv %.17g s2 %.6g dba %.6g aj %.6g\n",
+               bwd ? "bwd" : "fwd", j, kf[0], kf[1], kf[P - 1], nu, sj, rs_own, alive_own, Lc[0], Lc[1], Lc[P - 1], Wc[0], Wc[1], Wc[P - 1], Wc[P], piv, s2, dba, aj);
     }
 #endif
     if (bwd && virt) {
@@ -626,12 +642,12 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
     for (int c = 0;; c += 2) {
         if (chunk(kb, hb, ka, ha, c)) {
             PIPEW_MARK(5);
-            if constexpr (TS) pipew_merge<P>(lane, ka, nuA, ring, acc);
+            if constexpr (TS) pipew_merge<P>(lane, ka, nuA, ring, acc, mk);
             break;
         }
         if (chunk(ka, ha, kb, hb, c + 1)) {
             PIPEW_MARK(5);
-            if constexpr (TS) pipew_merge<P>(lane, kb, nuA, ring, acc);
+            if constexpr (TS) pipew_merge<P>(lane, kb, nuA, ring, acc, mk);
             break;
         }
     }

@@ -653,10 +653,10 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     const long grid = (long)L.R * S.wpl;
     const int minw = grid > 2L * S.ncu ? 3 : 2;             // the 168-register build only where three workgroups share a CU
     // the windowed pipeline where the WHOLE ladder's grid is at most one workgroup per CU (from T_global: a sharded ladder's blocks
-    // decide as the one-GPU run does, so both stay on one arithmetic); CARMA_TUNE_PT_ROW_WIN=0 / 1 overrides, read per launch
+    // decide as the one-GPU run does, so both stay on one arithmetic); CARMA_TUNE_PT_ROW_WIN=0 / 1 overrides (carma_tune_set)
     const long grid_global = (long)L.R * (((long)L.T_global + 3) / 4);
     bool win = grid_global <= (long)S.ncu && S.window_ok;       // (and the series suits it: carma_types.h, SERIES_WINDOW_OK)
-    if (const char* ew = getenv("CARMA_TUNE_PT_ROW_WIN")) win = atoi(ew) != 0 && minw < 3;
+    if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) win = ew != 0 && minw < 3;
     const void* fn = pt_row_fn<P>(minw, win);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

@@ -103,6 +103,11 @@ int carma_mle_batched(carma_ctx* h, const double* x0, int B, const double* lo, c
  * the name as rocprofv3 lists it, without namespace and argument list.  For measurement scripts. */
 int carma_logdensity_kernel_name(const carma_ctx* h, int B, char* buf, int len);
 
+/* Launch-shape switches for measurements and the parity tests (no counterpart in the reference): "WIN_ROWS", "WIN2_EVALS",
+ * "PT_ROW_WIN" -- the CARMA_TUNE_* environment variables of the same names give their initial values, read once when the first
+ * launch asks; afterwards only this call moves them (process-wide, thread-safe).  CARMA_EINVAL for an unknown name. */
+int carma_tune_set(const char* name, long value);
+
 /* getLogPrior (carpack.hpp:118-126, wrapper :50,58,67); host arithmetic, one vector. */
 double carma_logprior(const carma_ctx* h, const double* theta);
 

@@ -606,14 +606,22 @@ def test_pair_shared_factors_and_real_pairs(cpa, p, q):
         assert v == res["mixed"][key] or (np.isnan(v) and np.isnan(res["mixed"][key]))
 
 
-@pytest.mark.parametrize("pipeline", ["window", "one-datum"])
+@pytest.mark.parametrize("pipeline", ["two-sided", "window", "one-datum"])
 @pytest.mark.parametrize("p,q", [(2, 0), (4, 1), (5, 3), (6, 0), (7, 2)])
-def test_wave_pipeline_real_pairs(cpa, monkeypatch, p, q, pipeline):
-    """(Both wave pipelines: the windowed one, which small launches take since round 5, and -- CARMA_TUNE_WIN_ROWS=0, read at
-    every launch -- the one-datum pipeline.)  The wave pipeline's producer lanes evaluate ONE exp/sincos per root pair; a quadratic factor with two real roots
+def test_wave_pipeline_real_pairs(cpa, p, q, pipeline):
+    """(All three wave pipelines: the two-sided windowed one, which small launches take since round 6, the one-sided windowed one of
+    round 5 -- carma_tune_set("WIN2_EVALS", 0) -- and, with "WIN_ROWS" at 0, the one-datum pipeline.)  The wave pipeline's producer lanes
+    evaluate ONE exp/sincos per root pair; a quadratic factor with two real roots
     is the pair whose members do not share a modulus and gets a second exponential.  Real-pair thetas alone, next to
     complex-pair ones in the same workgroup (the re-base grid of a workgroup is the finest of its four evaluations),
     and alone in a launch: same value every time, parity with the oracle."""
+    try:
+        _real_pairs(cpa, p, q, pipeline)
+    finally:
+        cpa._lib.tune_reset()
+
+
+def _real_pairs(cpa, p, q, pipeline):
     from helpers import loglik_truth
     t, y, yerr = irregular_series(150, seed=170 + p)
     rng = np.random.default_rng(1700 + 10 * p + q)
@@ -625,10 +633,12 @@ def test_wave_pipeline_real_pairs(cpa, monkeypatch, p, q, pipeline):
         real[:, 3 + 2 * f] = np.log(r1 * r2)
         real[:, 4 + 2 * f] = np.log(r1 + r2)
     if pipeline == "one-datum" or os.environ.get("CARMA_TUNE_WIN_ROWS") == "0":
-        monkeypatch.setenv("CARMA_TUNE_WIN_ROWS", "0")
+        cpa._lib.tune_set("WIN_ROWS", 0)
         pipeline = "one-datum"
+    elif pipeline == "window":
+        cpa._lib.tune_set("WIN2_EVALS", 0)
     ctx = cpa.Context(t, y, yerr, p, q)
-    assert ctx.kernel_name(64).startswith("k_logdens_carma_w" if pipeline == "window" else "k_logdens_carma_p3l")
+    assert ctx.kernel_name(64).startswith({"two-sided": "k_logdens_carma_w2<", "window": "k_logdens_carma_w<", "one-datum": "k_logdens_carma_p3l"}[pipeline])
     m = orc.OracleModel(t, y, yerr, p, q, max_stdev=ctx.prior()[0])
     mixed = np.concatenate([cplx, real])[rng.permutation(64)]
     got_r, got_m = ctx.logdensity(real, ignore_prior=True), ctx.logdensity(mixed, ignore_prior=True)

@@ -27,9 +27,11 @@ and the plain N loses what the two recursions kept (roots 1e-6 apart: 1.5e-3 fro
 3e-6, merge_chol 4e-6).  X = L L^T takes DIAGONAL PIVOTING: X is numerically rank deficient as a rule (a half of the series
 says nothing about modes that have decayed by the meeting time; the two coordinates of a pair can carry one direction), and
 in a fixed order a pivot at rounding level met before an informative one grows into it.  lane_merge_chol is the computation
-as the lanes do it (carma_pipew.h pipew_merge): X read symmetric bit for bit and equilibrated by powers of two, right-looking
-l_i l_j updates with both factors from the pivot column (so that the Schur complement stays symmetric), what is left when
-the pivots reach rounding level dropped, the border row v = L^T (Y a - beta) riding along in the factorisation of W.
+as the lanes do it (carma_pipew.h pipew_merge): X read symmetric bit for bit and equilibrated by powers of two, THRESHOLD
+pivoting (coordinates in their own order, but only those above the level's threshold 4e-3, 4e-6, ...: within 1e3 of diagonal
+pivoting's guarantee, and no index is a run-time value), right-looking l_i l_j updates with both factors from the pivot column
+(so that the Schur complement stays symmetric), what is left at rounding level dropped, the border row v = L^T (Y a - beta)
+riding along in the factorisation of W.
 
 loglik_two_sided(...) below is the plain recursion on both sides (loglik_std of lazy_frame.py); the window / lane forms of
 the device run the same two recursions chunk by chunk."""
@@ -116,43 +118,56 @@ def merge_chol(Da, a, Db, beta):
     return -np.sum(np.log(np.diag(C))) + beta @ a - 0.5 * a @ (Y @ a) - 0.5 * s @ s
 
 
-def lane_merge_chol(Da, a, Db, beta):
-    """merge_chol as pipew_merge lays it out: lane j holds column j of the Schur complement and ROW j of L (Lr[j][m] = L_jm, m the
-    step); the pivot of a step is the largest remaining diagonal, its column is what every lane updates with."""
+LEVELS = (4e-3, 4e-6, 4e-9, 4e-12, 4e-15)
+
+
+def lane_merge_chol(Da, a, Db, beta, stats=None):
+    """merge_chol as pipew_merge lays it out: lane j holds column j of the Schur complement and, once it has been taken, column j
+    of L.  THRESHOLD PIVOTING: the coordinates are taken in their own order, but only those whose remaining diagonal is above the
+    level's threshold; the others wait for a later level.  A pivot is then within 1e3 of everything taken after it (the guarantee
+    of diagonal pivoting up to that factor) and every broadcast comes from a lane known in advance."""
     P = a.size
-    S = np.array([[-(Da[i, j] if i >= j else Da[j, i]) for i in range(P)] for j in range(P)])      # S[j][i] = X_ij, lane j
+    A = np.array([[-(Da[i, j] if i >= j else Da[j, i]) for i in range(P)] for j in range(P)])      # A[j][i] = X_ij, lane j
     kf = np.array([[Db[i, j] for i in range(P)] for j in range(P)])
     # equilibration by powers of two (X <- D X D, Y <- D^-1 Y D^-1, a <- D a, beta <- D^-1 beta: every term is invariant), so that
-    # "a pivot at rounding level" has a meaning: the diagonal of X is in [1, 4) wherever it is positive
-    sj = np.array([-(int(np.frexp(S[j][j])[1]) >> 1) if S[j][j] > 0 and np.isfinite(S[j][j]) else 0 for j in range(P)])
-    S = np.array([[np.ldexp(S[j][i], int(sj[i] + sj[j])) for i in range(P)] for j in range(P)])
+    # the levels have a meaning: the diagonal of X is in [1, 4) wherever it is positive
+    sj = np.array([-(int(np.frexp(A[j][j])[1]) >> 1) if A[j][j] > 0 and np.isfinite(A[j][j]) else 0 for j in range(P)])
+    A = np.array([[np.ldexp(A[j][i], int(sj[i] + sj[j])) for i in range(P)] for j in range(P)])
     kf = np.array([[np.ldexp(kf[j][i], int(-sj[i] - sj[j])) for i in range(P)] for j in range(P)])
     a = np.ldexp(a, sj)
     beta = np.ldexp(beta, -sj)
-    dg = np.array([S[j][j] for j in range(P)])
     done = np.zeros(P, bool)
-    Lr = np.zeros((P, P))
-    for m in range(P):
-        cand = np.where(~done & (dg > 4e-15), dg, -1.0)
-        pc = int(np.argmax(cand))
-        if cand[pc] <= 0.0:
-            continue                                              # nothing above rounding level left: zero columns
-        col = S[pc].copy()
-        r1 = 1.0 / np.sqrt(col[pc])
-        lj = np.where(done, 0.0, col * r1)
-        Lr[:, m] = lj
+    rs = np.zeros(P)
+    alive = np.zeros((P, P), bool)
+    order = []
+    for thr in LEVELS:
+        for k in range(P):
+            dk = A[k][k]
+            if done[k] or not dk > thr:
+                continue
+            rs[k] = 1.0 / np.sqrt(dk)
+            alive[k] = ~done                                  # rows alive at this pivot (k itself among them)
+            lj = np.array([A[j][k] * rs[k] if (not done[j] and j != k) else 0.0 for j in range(P)])
+            li = A[k] * rs[k]
+            for j in range(P):
+                A[j] = A[j] - li * lj[j]
+            done[k] = True
+            order.append((k, dk))
+    if stats is not None:
+        stats.append(order)
+    Lc = np.array([[A[j][i] * rs[j] if alive[j][i] else 0.0 for i in range(P)] for j in range(P)])      # Lc[j][i] = L_ij
+    T = np.zeros((P, P))                                                                            # T[j][i] = (Db L)_ij
+    for k in range(P):
         for j in range(P):
-            S[j] = S[j] - (col * r1) * lj[j]
-        dg = dg - lj * lj
-        done[pc] = True
-    T = np.array([[sum(kf[i][k] * Lr[k][m] for k in range(P)) for m in range(P)] for i in range(P)])      # T[i][m] = (Db L)_im
+            T[j] += kf[k] * Lc[j][k]
+    W = np.zeros((P, P + 1))
+    for i in range(P):
+        for j in range(P):
+            W[j][i] = (1.0 if i == j else 0.0) + sum(Lc[i][k] * T[j][k] for k in range(P))
     dba = np.array([kf[j] @ a for j in range(P)])
     u = -beta - dba
-    W = np.zeros((P, P + 1))                                                                         # W[j][k] = W_kj, lane j
     for j in range(P):
-        for k in range(P):
-            W[j][k] = (1.0 if j == k else 0.0) + sum(Lr[i][k] * T[i][j] for i in range(P))
-        W[j][P] = sum(Lr[i][j] * u[i] for i in range(P))
+        W[j][P] = sum(Lc[j][k] * u[k] for k in range(P))
     piv, s2 = np.ones(P), np.zeros(P)
     for k in range(P):
         dk = W[k][k]

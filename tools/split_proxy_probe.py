@@ -18,8 +18,9 @@ Bs = [int(x) for x in sys.argv[1:]] or [256, 512, 1024, 2048]
 res = []
 for nuse in (270, 135, 68):
     ctx = cpa.Context(t[:nuse], y[:nuse], e[:nuse], 5, 3, max_stdev=10.0 * y.std())
-    for mode, env in (("win", "1000000"), ("p3l", "0")):
-        os.environ["CARMA_TUNE_WIN_ROWS"] = env
+    for mode, env in (("win", 1000000), ("p3l", 0)):
+        cpa._lib.tune_set("WIN2_EVALS", 0)
+        cpa._lib.tune_set("WIN_ROWS", env)
         for B in Bs:
             th = theta_batch(np.random.default_rng(2), B, 5, 3, t, y, theta_center=g["theta"][0])
             dev = torch.from_numpy(th).cuda()

@@ -29,10 +29,10 @@ for eps in (1e-3, 1e-4, 1e-5, 1e-6):
 ill = np.array(ill)
 tr = np.array([loglik_truth(t, y, e, x, 5, 3)[0] for x in ill])
 orc_ill = m.logdensity_batch(ill, ignore_prior=True)
-for name, env in (("w2", {}), ("w", {"CARMA_TUNE_WIN2_EVALS": "0"}), ("p3l", {"CARMA_TUNE_WIN2_EVALS": "0", "CARMA_TUNE_WIN_ROWS": "0"})):
-    for k in ("CARMA_TUNE_WIN2_EVALS", "CARMA_TUNE_WIN_ROWS"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+for name, env in (("w2", {}), ("w", {"WIN2_EVALS": 0}), ("p3l", {"WIN2_EVALS": 0, "WIN_ROWS": 0})):
+    cpa._lib.tune_reset()
+    for k, v in env.items():
+        cpa._lib.tune_set(k, v)
     got = ctx.logdensity(th)
     r = rel(got, ref)
     print(name, ctx.kernel_name(th.shape[0]), "max rel %.2e  median %.2e  >1e-10: %d  nonfinite mismatch %d" % (np.max(r[np.isfinite(r)]), np.median(r), np.sum(r > 1e-10), np.sum(~np.isfinite(r))), flush=True)
