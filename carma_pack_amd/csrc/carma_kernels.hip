@@ -245,12 +245,20 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         th = s_th;
     }
+    // the series into LDS (producers: carma_pipew.h, SLDS): {y, yerr^2}[n], then t[n]; visible behind the producers' first barrier
+    double2* lds_yz = ring + Geo::SER_OFF;
+    double* lds_t = reinterpret_cast<double*>(lds_yz + n + (n & 1));
+    for (int i = tid; i < n; i += 256) {
+        const double4 r = series[i];
+        lds_yz[i] = make_double2(r.y, r.z);
+        lds_t[i] = r.w;
+    }
     if (wave >= 2) {
 #if defined(CARMA_STAMPS)
-        pipew_produce<P, true>(g, wave - 2, th, series, n, ring, [](int) {}, mark_);
+        pipew_produce<P, true, true>(g, wave - 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
         CARMA_MARK_DUMP("two-sided producer: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", wave - 2);
 #else
-        pipew_produce<P, true>(g, wave - 2, th, series, n, ring, [](int) {});
+        pipew_produce<P, true, true>(g, wave - 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
 #endif
         __syncthreads();                                      // (the set-up wave's hand-over, below)
         return;
@@ -261,10 +269,10 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
         // very end only, and in front of the pipeline they kept the first chunk waiting (the other waves were at the first barrier
         // 3.5 k cycles before this one: profiles/r06/w2_stamps_v3.txt); now they run while the recursion wave merges
 #if defined(CARMA_STAMPS)
-        pipew_produce<P, true>(g, 2, th, series, n, ring, [](int) {}, mark_);
+        pipew_produce<P, true, true>(g, 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
         CARMA_MARK_DUMP("two-sided set-up wave: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", 2);
 #else
-        pipew_produce<P, true>(g, 2, th, series, n, ring, [](int) {});
+        pipew_produce<P, true, true>(g, 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
 #endif
         model_from_theta<P, 16, MODEL_FLAGS>(g, th, q, pr, ignore_prior, m);
         const double lpri = log_prior(m.scale, pr.measerr_dof);
@@ -730,6 +738,8 @@ static long win2_max_evals()
 }
 // (an override of CARMA_TUNE_WIN_ROWS also lifts the series criterion: the tests force the window pipelines onto series that fail it)
 static bool win_forced() { return tune_get(TUNE_WIN_ROWS) != TUNE_UNSET; }
+// longest series the two-sided kernel keeps in LDS beside its rings (24 bytes a datum; 5000: 137 KiB, one workgroup per CU)
+constexpr int W2_MAX_N = 5000;
 // smallest launch that takes one evaluation per lane (measured: tools/tput_probe.py; CARMA_TUNE_LANE_MIN overrides, read once)
 static long lane_min_evals(int p = 5)
 {
@@ -804,7 +814,7 @@ static LdShape logdens_shape(long B, int n, int series_flags)
     constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
-    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && ((series_flags & SERIES_WINDOW_OK) || win_forced()))
+    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && n <= W2_MAX_N && ((series_flags & SERIES_WINDOW_OK) || win_forced()))
         return LdShape::WIN2;                         // (CARMA_TUNE_WIN_ROWS = 0: no window pipeline of either kind)
     if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || win_forced())) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
@@ -848,9 +858,17 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
                                series, n, pr, ignore_prior, out, device_cus());
             return hipGetLastError();
         case LdShape::WIN2:
-            hipLaunchKernelGGL((k_logdens_carma_w2<P>), dim3((unsigned)(((long)B + 1) / 2)), dim3(256), PipeWGeom<P>::BYTES, st, theta, B, d, q,
-                               series, n, pr, ignore_prior, out, device_cus());
+        {
+            const size_t lds = PipeWGeom<P>::bytes_with_series(n);
+            if (lds > 64 * 1024) {
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_w2<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    160 * 1024);
+                if (ea != hipSuccess) return ea;
+            }
+            hipLaunchKernelGGL((k_logdens_carma_w2<P>), dim3((unsigned)(((long)B + 1) / 2)), dim3(256), lds, st, theta, B, d, q, series, n, pr,
+                               ignore_prior, out, device_cus());
             return hipGetLastError();
+        }
         case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);
         case LdShape::PC2: return launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);
         case LdShape::PLAIN1:

@@ -63,9 +63,15 @@ struct PipeWGeom {
     static constexpr int MRG_OFF = TAB_OFF + MATH_TAB_N / 2;  // two-sided kernels, per evaluation (2): the merge's exchange area (pipew_merge)
     static constexpr int MRG_STRIDE = P + 1 + ((P + 1) & 1);  // (doubles per column: an even count, so that columns are double2 aligned)
     static constexpr int MRG_X = 0;                           //   double[P][ST]  the forward row's columns of Da and -a
-    static constexpr int MRG_DOUBLES = MRG_X + P * MRG_STRIDE;
+    static constexpr int MRG_COL = MRG_X + P * MRG_STRIDE;    //   double[ST]     the pivot column of a step; [P]: 1 / sqrt(pivot)
+    static constexpr int MRG_L = MRG_COL + MRG_STRIDE;        //   double[P][ST]  L, row i = lane ND + i's
+    static constexpr int MRG_T = MRG_L + P * MRG_STRIDE;      //   double[P][ST]  T = Db L, row i = lane ND + i's; [i][P] = u_i
+    static constexpr int MRG_DOUBLES = MRG_T + P * MRG_STRIDE;
     static constexpr int TH_OFF = MRG_OFF + (2 * MRG_DOUBLES + 1) / 2;   // two-sided log-density kernel: double[4 waves][4 rows][16], theta per row
     static constexpr int ENTRIES = TH_OFF + 128;
+    // two-sided log-density kernel: the series behind everything else, double2 {y, yerr^2}[n] then double t[n]
+    static constexpr int SER_OFF = ENTRIES;
+    static __host__ __device__ size_t bytes_with_series(int n) { return BYTES + (size_t)(n + (n & 1)) * 24; }
     static constexpr int NPROD = 3;                           // producer waves: P0, P1 and the set-up wave once it is through
     static constexpr size_t BYTES = (size_t)ENTRIES * sizeof(double2);
     static constexpr double LIM_RE = Pipe3LGeom<P>::LIM_RE, LIM_IM = Pipe3LGeom<P>::LIM_IM;
@@ -78,10 +84,14 @@ struct PipeWGeom {
 // coordinates u = V^-1 z, where the observation vector is c = V h and "V h" is h; tests/tools/proto/two_sided.py) -- and one more
 // chunk after the data, the FINAL chunk, carries nothing but the rotation of both states to the meeting time in true
 // coordinates (frame factor g included), where pipew_recur merges them.
-template <int P, bool TS = false, class Tail>
+// SLDS (the two-sided log-density kernel): the series is in LDS -- times lds_t[n_all], {y, yerr^2} lds_yz[n_all], copied by the kernel,
+// visible behind the first barrier -- and a chunk's records are read where they are needed; elsewhere each row keeps a window of 64
+// records in registers (below).
+template <int P, bool TS = false, bool SLDS = false, class Tail>
 __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
                                               const double4* __restrict__ series, int n_all, double2* __restrict__ ring, Tail&& tail,
-                                              long long* mk = nullptr)
+                                              long long* mk = nullptr, const double* __restrict__ lds_t = nullptr,
+                                              const double2* __restrict__ lds_yz = nullptr)
 {
     using Geo = PipeWGeom<P>;
     constexpr int ND = Geo::ND, NB = Geo::NB, ENT = Geo::ENT;
@@ -89,6 +99,10 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     // a lane works on a conjugate PAIR of roots (jr, jr + 1) of one slot: both share |E|, cos and sin
     constexpr int NPAIR = (P + 1) / 2, PPL = 16 / NPAIR;
     constexpr int NPROD = Geo::NPROD;
+    // which producer forms the data slots {scale yerr^2, y - mu}: in the two-sided log-density kernel the third one -- the set-up wave,
+    // which has nothing else in front of the pipeline there -- so that producer 0 (header, the virtual lanes' constant entries) is
+    // not the one the others wait for; elsewhere producer 0
+    constexpr int PWD = TS ? 2 : 0;
     constexpr int NIT = (ND + 1 + NPROD * PPL - 1) / (NPROD * PPL);   // slot ND is the re-base rotation
     const double* tab = reinterpret_cast<const double*>(ring + Geo::TAB_OFF);
     const int lane = g.lane64, l = lane & 15, rowb = lane & ~15, q = lane >> 4;
@@ -114,9 +128,24 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     // (Requested FIRST: nothing in front of the first barrier depends on them, and behind the roots' exponentials their L2 round
     // trip was one more serial latency of the prologue.)
     int jw = 0;
-    double4 rw0 = recat(l), rw1 = recat(16 + l), rw2 = recat(32 + l), rw3 = recat(48 + l);
-    const double t_first = recat(0).w;
-    const double t_meet = TS ? (bwd ? -series[nfwd - 1].w : series[nfwd - 1].w) : 0.0;    // the last forward datum's time
+    double4 rw0, rw1, rw2, rw3;
+    if constexpr (!SLDS) {
+        rw0 = recat(l);
+        rw1 = recat(16 + l);
+        rw2 = recat(32 + l);
+        rw3 = recat(48 + l);
+    }
+    // SLDS: record j of this row (clamped) -- series index and the sign of its time
+    auto sidx = [=](int j) {
+        const int jj = j < n ? j : n - 1;
+        return bwd ? n_all - 1 - jj : jj;
+    };
+    const double tsgn = bwd ? -1.0 : 1.0;
+    double t_first = 0.0, t_meet = 0.0;
+    if constexpr (!SLDS) {
+        t_first = recat(0).w;
+        t_meet = TS ? (bwd ? -series[nfwd - 1].w : series[nfwd - 1].w) : 0.0;    // the last forward datum's time
+    }
     Cx w = own_ar_root<P>(theta, jr);
     Cx w1 = two ? own_ar_root<P>(theta, jr + 1) : w;
     if (bwd) {                                                // F^T instead of F: the conjugate roots
@@ -156,10 +185,11 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     }
     // schedule state of this row (row-uniform)
     int j0 = 0;
-    double base = t_first;
-    // ---- A chunk is PREPARED (its schedule and its exponentials: nothing that needs h, c) one barrier before its entries are formed:
-    // chunk 0 in front of the first barrier, while the recursion wave still sets the model up -- behind that barrier only the
-    // entries are left (round 6: the first chunk reaches the recursion wave 1.4 k cycles earlier, profiles/r06/w2_stamps_v7.txt).
+    double base = t_first;                                    // (SLDS: read behind the first barrier, below)
+    // ---- A chunk in two parts: prepare() -- its schedule and its exponentials, nothing that needs h, c -- and the entries.  (Round 6
+    // tried chunk 0's prepare() in front of the first barrier and every later one behind the barrier of the chunk before: the producers
+    // start up to 1.4 k cycles after the recursion wave and reach that barrier no earlier than it does, so nothing was hidden --
+    // 18.55 against 18.51 us per launch, the row sampler 31.7 against 32.4 k it/s on one box, profiles/r06/ab_rotation_v1.txt.)
     int len = 0;
     bool rot = false, last = false, fin = false;              // fin (TS): the final chunk (no data, the rotation to the meeting time)
     double2 dslot = make_double2(1.0, 0.0);                   // {scale yerr^2, y - mu} of this lane's datum (pw == 0)
@@ -169,17 +199,28 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         // --- schedule of this row's chunk: lane s looks at datum j0 + s
         const int jl = j0 + l;
         double4 rec;
-        {
+        if constexpr (SLDS) {
+            const int si = sidx(jl);
+            rec.x = rec.y = rec.z = 0.0;
+            rec.w = tsgn * lds_t[si];
+            if (pw == PWD) {                                  // (wave-uniform: the data slots are ONE producer's)
+                const double2 yz = lds_yz[si];
+                rec.y = yz.x;
+                rec.z = yz.y;
+            }
+        } else {
             const int pos = jl - jw, src = rowb + (pos & 15);
             const bool hi = pos >= 16;
             // (both fetches by every lane: a ds_bpermute under a divergent branch would read inactive lanes)
-            const double y0 = __shfl(rw0.y, src, 64), y1 = __shfl(rw1.y, src, 64);
-            const double z0 = __shfl(rw0.z, src, 64), z1 = __shfl(rw1.z, src, 64);
             const double w0 = __shfl(rw0.w, src, 64), w1_ = __shfl(rw1.w, src, 64);
-            rec.x = 0.0;
-            rec.y = hi ? y1 : y0;
-            rec.z = hi ? z1 : z0;
+            rec.x = rec.y = rec.z = 0.0;
             rec.w = hi ? w1_ : w0;
+            if (pw == PWD) {                                  // (wave-uniform: the data slots are ONE producer's)
+                const double y0 = __shfl(rw0.y, src, 64), y1 = __shfl(rw1.y, src, 64);
+                const double z0 = __shfl(rw0.z, src, 64), z1 = __shfl(rw1.z, src, 64);
+                rec.y = hi ? y1 : y0;
+                rec.z = hi ? z1 : z0;
+            }
         }
         const double tj = rec.w;
         // RE-BASE RULE (round 5, second version): look a chunk ahead.  The frame of a window carries scale factors e^(+-LIM_RE / 2)
@@ -191,8 +232,8 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         // slowest row (34.1 us per 1024 evaluations, profiles/r05/window_pipeline_v1.txt).
         const int left = n - j0;
         const int ncand = left < ND ? (left > 0 ? left : 0) : ND;
-        const double t0 = fin ? t_meet : __shfl(tj, rowb, 64);
-        const double t_lastc = __shfl(tj, rowb + (ncand > 0 ? ncand - 1 : 0), 64);
+        const double t0 = fin ? t_meet : Grp<16>::template bcast_c<0>(tj);
+        const double t_lastc = SLDS ? tsgn * lds_t[sidx(j0 + (ncand > 0 ? ncand - 1 : 0))] : __shfl(tj, rowb + (ncand > 0 ? ncand - 1 : 0), 64);
         const double W = sc > 0.0 ? 1.0 / sc : 1.0 / 0.0;
         rot = fin || (ncand > 0 && (t_lastc - base) > W);
         const double base_old = base;
@@ -204,16 +245,14 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         len = cut ? __builtin_ctz(cut) : ncand;
         const bool row_done = j0 + len >= n;
         last = __ballot(!row_done) == 0ull;
-        if (pw == 0) {
-            rbits = __ballot(rot);
-            dslot = l < len ? make_double2(rec.z * scale, rec.y - mu) : make_double2(1.0, 0.0);
-        }
+        if (pw == 0) rbits = __ballot(rot);
+        if (pw == PWD) dslot = l < len ? make_double2(rec.z * scale, rec.y - mu) : make_double2(1.0, 0.0);
         // --- exponentials
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int slot = it * NPROD * PPL + pw * PPL + sub;
             const bool is_rot = slot == ND;
-            const double dts = __shfl(dta_l, rowb + (slot < ND ? slot : 0), 64);
+            const double dts = SLDS ? tsgn * lds_t[sidx(j0 + (slot < ND ? slot : 0))] - base : __shfl(dta_l, rowb + (slot < ND ? slot : 0), 64);
             const double dt = is_rot ? t0 - base_old : dts;
             const bool live = worker && (is_rot ? rot : slot < len);
             double ec = 1.0, es = 0.0, e1 = 1.0;
@@ -225,7 +264,7 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
             e1v[it] = e1;
         }
         j0 += len;
-        if (j0 - jw >= 16) {                                  // (at most one shift per chunk: len < 16)
+        if (!SLDS && j0 - jw >= 16) {                         // (at most one shift per chunk: len < 16)
             rw0 = rw1;
             rw1 = rw2;
             rw2 = rw3;
@@ -233,10 +272,13 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
             rw3 = recat(jw + 48 + l);
         }
     };
-    prepare();
     PIPEW_MARK(1);
     __syncthreads();                                          // the recursion wave has published (h_r, c_r)
     PIPEW_MARK(2);
+    if constexpr (SLDS) {
+        base = tsgn * lds_t[sidx(0)];
+        t_meet = tsgn * lds_t[nfwd - 1];
+    }
     double2 hc_own, hc_par;
     {
         const double2* cst = ring + Geo::CONST_OFF + rowb;
@@ -266,13 +308,12 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
 #if defined(CARMA_WIN_STAMPS)
         WIN_STAMP(ps_t0);
 #endif
+        prepare();
         // --- the prepared chunk's header, data slots and entries
-        if (pw == 0) {
-            if (lane == 0)
-                reinterpret_cast<unsigned long long*>(ring + Geo::HDR_OFF)[b] =
-                    ((rbits & 1ull) | ((rbits >> 15) & 2ull) | ((rbits >> 30) & 4ull) | ((rbits >> 45) & 8ull)) | ((TS ? fin : last) ? 256ull : 0ull);
-            if (l < ND) ring[Geo::RING_OFF + (b * ENT + P) * 64 + lane] = dslot;
-        }
+        if (pw == 0 && lane == 0)
+            reinterpret_cast<unsigned long long*>(ring + Geo::HDR_OFF)[b] =
+                ((rbits & 1ull) | ((rbits >> 15) & 2ull) | ((rbits >> 30) & 4ull) | ((rbits >> 45) & 8ull)) | ((TS ? fin : last) ? 256ull : 0ull);
+        if (pw == PWD && l < ND) ring[Geo::RING_OFF + (b * ENT + P) * 64 + lane] = dslot;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int slot = it * NPROD * PPL + pw * PPL + sub;
@@ -317,7 +358,6 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
 #endif
         if (TS ? fin : last) break;
         fin = last;
-        prepare();                                            // the next chunk: schedule and exponentials
     }
 #if defined(CARMA_WIN_STAMPS)
     if (blockIdx.x == 0 && lane == 0)
@@ -380,6 +420,7 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     const bool bwd = (q & 1) != 0, virt = l >= ND;
     const int j = virt ? l - ND : 0;                          // this lane's column (the other lanes' results are not used)
     double* mrg = reinterpret_cast<double*>(ring + Geo::MRG_OFF) + (q >> 1) * Geo::MRG_DOUBLES;
+    double* colb = mrg + Geo::MRG_COL;
     // forward row: column s of Da and -a_s to LDS
     if (!bwd && virt) {
         double* dst = mrg + Geo::MRG_X + j * ST;
@@ -421,75 +462,90 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     aj = ldexp(aj, sj);
     nu = ldexp(nu, -sj);
     PIPEW_MARK(8);
-    // ---- X = L L^T, lanes = columns (lane k's column is column k of L), THRESHOLD PIVOTING: the coordinates are taken in their own
-    // order, but only those whose remaining diagonal is above the level's threshold -- 4e-3, 4e-6, ... of the equilibrated scale --,
-    // the others wait for a later level.  A pivot taken at a level is within 1e3 of everything taken after it, which bounds what
-    // its rounding can grow into (the diagonal-pivoting guarantee up to that factor), and every step broadcasts from a lane known at
-    // compile time: no register index is a run-time value, nothing goes through LDS (the first version pivoted on the largest
-    // diagonal and sent the pivot column through LDS: 610 cycles a step, profiles/r06/w2_stamps_v6.txt).  Empty levels and steps
-    // are skipped wave-uniformly; what is left at rounding level (4e-15) is dropped.
-    double rs_own = 0.0;                                      // 1 / sqrt(pivot) of this lane's column (0: never taken, a zero column)
-    unsigned alive_own = 0u, donemask = 0u;                   // rows alive when this lane's column was taken; coordinates taken (row-uniform)
-    bool done_own = !virt;
-    double thr = 4e-3;
-    for (int lev = 0; lev < 5; lev++, thr *= 1e-3) {
-        if (__builtin_amdgcn_ballot_w64(!done_own && dg > 4e-15) == 0ull) break;          // nothing above rounding level anywhere
-        if (__builtin_amdgcn_ballot_w64(!done_own && dg > thr) == 0ull) continue;         // nothing at this level
-        static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value;
-            const double dk = Grp<16>::template bcast_c<ND + k>(dg);
-            const bool take = ((donemask >> k) & 1u) == 0u && dk > thr;                   // row-uniform
-            if (__builtin_amdgcn_ballot_w64(take) == 0ull) return;
-            const double r1 = take ? rsqrt_pos(dk) : 0.0;
-            if (take && l == ND + k) {
-                rs_own = r1;
-                alive_own = ~donemask;
-                done_own = true;
-            }
-            // X_ij -= l_i l_j with l_j = X_kj / sqrt(d_k) from the lane's own row-k entry and l_i = X_ik / sqrt(d_k) from the pivot
-            // column: both members of a symmetric pair get the same two factors, so the Schur complement stays symmetric bit for bit
-            const double lj = (take && !done_own) ? S[k] * r1 : 0.0;                       // (taken lanes and the pivot's own: 0)
+    // ---- X = L L^T with diagonal pivoting.  Lane j keeps ROW j of L: Lr[m] = L_jm, m the step.
+    double Lr[P];
+    bool done = !virt;
+    static_for<0, P>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        // the largest remaining diagonal (a key of its upper 28 bits and the lane: the lowest lane wins a tie); nothing above
+        // rounding level left: no pivot, a zero column.  Every candidate takes 1 / sqrt of its own diagonal meanwhile -- off the
+        // step's serial chain -- and the pivot's lane sends its column already divided: l = (pivot column) / sqrt(pivot)
+        const bool cand = !done && dg > 4e-15;
+        unsigned key = cand ? (((unsigned)__double2hiint(dg) & ~0xFu) | (unsigned)(15 - l)) : 0u;
+        const double r_own = cand ? rsqrt_pos(dg) : 0.0;
+#ifdef __HIPCC__
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_QUAD_XOR1, 0xf, 0xf, true));
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_QUAD_XOR2, 0xf, 0xf, true));
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true));
+        key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, DPP_ROW_MIRROR, 0xf, 0xf, true));
+#endif
+        const bool any = key != 0u;
+        // (no row of the wave has anything left above rounding level -- the numerical rank of X is below P as a rule --: the
+        // remaining steps are zero columns everywhere)
+        if (__builtin_amdgcn_ballot_w64(any) == 0ull) {
+            Lr[m] = 0.0;
+            return;
+        }
+        const int pl = 15 - (int)(key & 15u);                 // the pivot's lane in the row (row-uniform)
+        const bool isp = any && l == pl;
+        if (isp && bwd) {
 #pragma unroll
-            for (int i = 0; i < P; i++) S[i] = fma(-(Grp<16>::template bcast_c<ND + k>(S[i]) * r1), lj, S[i]);
-            dg = fma(-lj, lj, dg);
-            donemask |= take ? (1u << k) : 0u;
-        });
-    }
-    // L[:, j]: this lane's column, rows that were alive when it was taken
-    double Lc[P];
+            for (int i = 0; i < P; i++) colb[i] = S[i] * r_own;
+        }
+        merge_lds_sync();
+        // X_ij -= l_i l_j: the same two factors for both members of a symmetric pair
+        const double lj = (any && !done) ? colb[j] : 0.0;     // (the pivot's own: sqrt(pivot))
+        Lr[m] = lj;
 #pragma unroll
-    for (int i = 0; i < P; i++) Lc[i] = ((alive_own >> i) & 1u) ? S[i] * rs_own : 0.0;
+        for (int i = 0; i < P; i++) S[i] = fma(-colb[i], lj, S[i]);
+        dg = fma(-lj, lj, dg);
+        done = done || isp;
+        merge_lds_sync();                                     // (the next step's column must not overtake these reads)
+    });
     PIPEW_MARK(9);
-    // ---- T = Db L  (= -Y L):  T_ij = sum_k Db_ik L_kj, Db_ik = kfs[i] of lane ND + k
+    // ---- T = Db L  (= -Y L):  T_im = sum_k Db_ik L_km, row i in lane i (Db_ik = this lane's kfs[k]: symmetric), L_km by broadcast
     double T[P];
 #pragma unroll
-    for (int i = 0; i < P; i++) T[i] = 0.0;
+    for (int m = 0; m < P; m++) T[m] = 0.0;
     static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
 #pragma unroll
-        for (int i = 0; i < P; i++) T[i] = fma(Grp<16>::template bcast_c<ND + k>(kfs[i]), Lc[k], T[i]);
+        for (int m = 0; m < P; m++) T[m] = fma(kfs[k], Grp<16>::template bcast_c<ND + k>(Lr[m]), T[m]);
     });
-    PIPEW_MARK(10);
-    // ---- W = I - L^T Y L = I + L^T T:  W_ij = delta_ij + sum_k L_ki T_kj, L_ki = Lc[k] of lane ND + i;  row P: the border v
-    double Wc[P + 1];
-    static_for<0, P>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        double w = j == i ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < P; k++) w = fma(Grp<16>::template bcast_c<ND + i>(Lc[k]), T[k], w);
-        Wc[i] = w;
-    });
-    // u = Y a - beta (lane j: u_j, from its own column of Db);  v = L^T u:  v_j = sum_k L_kj u_k
+    // u = Y a - beta (lane j: u_j, from its own column of Db)
     double dba = 0.0;
 #pragma unroll
     for (int k = 0; k < P; k++) dba = fma(kfs[k], av[k], dba);                 // (Db a)_j
     const double uj = -nu - dba;
+    PIPEW_MARK(10);
+    // ---- W = I - L^T Y L = I + L^T T and the border v = L^T u, column m to lane m (pivot order) through LDS
+    if (bwd && virt) {
+        double* lb = mrg + Geo::MRG_L + j * ST;
+        double* tb = mrg + Geo::MRG_T + j * ST;
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+            lb[m] = Lr[m];
+            tb[m] = T[m];
+        }
+        tb[P] = uj;
+    }
+    merge_lds_sync();
+    double Wc[P + 1];
     {
-        double v = 0.0;
-        static_for<0, P>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value;
-            v = fma(Lc[k], Grp<16>::template bcast_c<ND + k>(uj), v);
-        });
+        double tm[P], lm[P], v = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            tm[i] = mrg[Geo::MRG_T + i * ST + j];             // T_ij: row i, this lane's column
+            lm[i] = mrg[Geo::MRG_L + i * ST + j];             // L_ij
+            v = fma(lm[i], mrg[Geo::MRG_T + i * ST + P], v);  // v_j = sum_i L_ij u_i
+        }
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            double w = j == k ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < P; i++) w = fma(mrg[Geo::MRG_L + i * ST + k], tm[i], w);      // W_kj = delta + sum_i L_ik T_ij
+            Wc[k] = w;
+        }
         Wc[P] = v;
     }
     PIPEW_MARK(11);
@@ -509,8 +565,8 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     });
 #if defined(CARMA_MERGE_DEBUG)
     if (blockIdx.x == 0 && q < 2 && virt) {
-        printf("merge %s lane %d: in kf %.17g %.17g %.17g nu %.17g | sj %d rs %.6g alive %x | Lc %.6g %.6g %.6g | W %.6g %.6g %.6g border %.6g | piv %.17g s2 %.6g dba %.6g aj %.6g\n",
-               bwd ? "bwd" : "fwd", j, kf[0], kf[1], kf[P - 1], nu, sj, rs_own, alive_own, Lc[0], Lc[1], Lc[P - 1], Wc[0], Wc[1], Wc[P - 1], Wc[P], piv, s2, dba, aj);
+        printf("merge %s lane %d: in kf %.17g %.17g %.17g nu %.17g | sj %d Lr %.6g %.6g %.6g | T %.6g %.6g %.6g | W %.6g %.6g %.6g border %.6g | piv %.17g s2 %.6g dba %.6g aj %.6g\n",
+               bwd ? "bwd" : "fwd", j, kf[0], kf[1], kf[P - 1], nu, sj, Lr[0], Lr[1], Lr[P - 1], T[0], T[1], T[P - 1], Wc[0], Wc[1], Wc[P - 1], Wc[P], piv, s2, dba, aj);
     }
 #endif
     if (bwd && virt) {
@@ -639,17 +695,21 @@ __device__ __forceinline__ double pipew_recur(const Grp<16>& g, const RowConsts<
     load(0, en, hdr);
     start(0, ka, kb, hb);
     PIPEW_MARK(4);
+    bool fin_in_a = true;                                     // which register set the final chunk's start wrote (wave-uniform)
     for (int c = 0;; c += 2) {
-        if (chunk(kb, hb, ka, ha, c)) {
-            PIPEW_MARK(5);
-            if constexpr (TS) pipew_merge<P>(lane, ka, nuA, ring, acc, mk);
-            break;
-        }
+        if (chunk(kb, hb, ka, ha, c)) break;
         if (chunk(ka, ha, kb, hb, c + 1)) {
-            PIPEW_MARK(5);
-            if constexpr (TS) pipew_merge<P>(lane, kb, nuA, ring, acc, mk);
+            fin_in_a = false;
             break;
         }
+    }
+    PIPEW_MARK(5);
+    if constexpr (TS) {
+        // (ONE call site: the merge runs once per launch out of a cold instruction cache, and two copies of it were 11 KB of code)
+        double kf[P];
+#pragma unroll
+        for (int r = 0; r < P; r++) kf[r] = fin_in_a ? ka[r] : kb[r];
+        pipew_merge<P>(lane, kf, nuA, ring, acc, mk);
     }
     PIPEW_MARK(6);
     double ll = Grp<16>::sum(acc.total());
