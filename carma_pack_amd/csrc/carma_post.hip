@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void k_sigma_noise(int p, int nma, const doubl
     double b[POST_PMAX];
     for (int k = 0; k < p; k++) r[k] = Cd{roots[(s * p + k) * 2], roots[(s * p + k) * 2 + 1]};
     for (int l = 0; l < nma; l++) b[l] = ma[s * nma + l];
-    Cd total{0.0, 0.0};
+    // Re of the sum only, accumulated with its rounding errors carried along (Neumaier's compensated sum): the p terms are of order
+    // 1 / (root differences)^2 and cancel -- a plain sum of a CARMA(6,0) sample with two nearby pairs was 1.8e-10 from the exact
+    // value where the reference's (numpy, another order) happened to be at 2.5e-11 (round 5 review); the terms' own rounding stays
+    double tsum = 0.0, tcomp = 0.0;
     for (int k = 0; k < p; k++) {
         Cd den{-2.0 * r[k].re, 0.0};
         for (int l = 0; l < p; l++)
@@ -74,9 +77,12 @@ __global__ __launch_bounds__(256) void k_sigma_noise(int p, int nma, const doubl
             pw = cmul(pw, r[k]);
             pm = cmul(pm, mr);
         }
-        total = cadd(total, cdiv(cmul(s1, s2), den));
+        const double x = cdiv(cmul(s1, s2), den).re;
+        const double t = tsum + x;
+        tcomp += fabs(tsum) >= fabs(x) ? (tsum - t) + x : (x - t) + tsum;
+        tsum = t;
     }
-    sigma[s] = sqrt(var[s] / total.re);
+    sigma[s] = sqrt(var[s] / (tsum + tcomp));
 }
 
 // psd[f][s] = sigma_s^2 |delta_s(i 2 pi f)|^2 / |alpha_s(i 2 pi f)|^2     (carma_pack.py:596-618)

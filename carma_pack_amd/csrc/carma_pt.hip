@@ -276,14 +276,19 @@ __device__ __forceinline__ unsigned long long pt_tag(unsigned long long iter, un
 // over through LDS, is the third producer, and keeps the sweep.  Taken where the whole ladder's grid is at most one workgroup per
 // CU (launch_pt_row_p): 16 x 64 ladders 31.1 -> 32.9 * 10^3 it/s on one box (profiles/r05/window_pipeline_v1.txt); with more
 // workgroups per CU the one-datum pipeline is ahead, as for the log-density kernels.
-template <int P, int MINW, bool WIN = false>
+// TWO (round 6, with WIN): the TWO-SIDED window pipeline (carma_pipew.h, TS) -- a chain takes two DPP rows, the even one filters the
+// first half of the series forward, the odd one the second half backward, and the chain wave merges the two states; two chains per
+// workgroup, a ladder over ceil(T / 2) of them.  Both rows carry the chain's state (the same values, formed twice), the even row
+// publishes it.  The series sits in LDS for the producers (copied once per launch).
+template <int P, int MINW, bool WIN = false, bool TWO = false>
 __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
                                                    const double* __restrict__ temps, double* __restrict__ theta,
                                                    double* __restrict__ logpost, double* __restrict__ chol,
                                                    unsigned* __restrict__ naccept, unsigned* __restrict__ nswap,
                                                    double* __restrict__ samples, double* __restrict__ sample_lp)
 {
-    constexpr int G = 16, CPW = 4;                         // lanes per chain, chains per workgroup
+    static_assert(!TWO || WIN, "the two-sided form is the window pipeline's");
+    constexpr int G = 16, CPW = TWO ? 2 : 4;               // lanes per chain row, chains per workgroup
     extern __shared__ double4 smem4[];
     const int tid = threadIdx.x, lane64 = tid & 63;
     // which wave plays which part: as in k_logdens_carma_p3l (workgroups i, i + ncu, i + 2 ncu share a CU)
@@ -308,6 +313,17 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     double* s_lu = s_z + 64;                               // [64] this exchange's log-uniforms (T <= 64), producer wave 1
     double* s_step = s_lu + 64;                            // [1] this iteration's adaptation step length (+ pad), same
     double* s_tha = s_step + 2;                            // [T][d + 1] the ladder's staged (theta, log-posterior), validated copy
+    // TWO: the series for the producers, {y, yerr^2}[n] then t[n] (16-byte aligned behind s_tha)
+    double2* lds_yz = reinterpret_cast<double2*>(reinterpret_cast<char*>(smem4) +
+                                                 ((reinterpret_cast<char*>(s_tha + T * (PT_DMAX + 1)) - reinterpret_cast<char*>(smem4) + 15) & ~(ptrdiff_t)15));
+    double* lds_t = reinterpret_cast<double*>(lds_yz + L.n + (L.n & 1));
+    if constexpr (TWO) {
+        for (int i = tid; i < L.n; i += 256) {
+            const double4 r = series[i];
+            lds_yz[i] = make_double2(r.y, r.z);
+            lds_t[i] = r.w;
+        }
+    }
     // Which ladder, which part of it.  Workgroups are dealt to the eight XCDs (each with its own L2) round-robin by
     // blockIdx, and the swap step is an exchange between the workgroups of ONE ladder: S.xcd_map = 8 puts a ladder's wpl
     // workgroups on blockIdx b, b + 8, b + 16, ... -- the same XCD -- instead of b, b + 1, ... (eight different ones).
@@ -333,11 +349,13 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
 
     Grp<G> g{nullptr, lane64, nullptr};
     const int row = lane64 >> 4, j = lane64 & 15;
-    const int c = part * CPW + row;                        // chain (temperature index) of this row
+    const int crow = TWO ? row >> 1 : row;                 // chain of the workgroup this row works for
+    const bool pub = !TWO || (row & 1) == 0;               // the row that publishes / stores the chain
+    const int c = part * CPW + crow;                       // chain (temperature index) of this row
     const bool active = c < T;
     // rows past the ladder's end shadow its last chain: uniform control flow, nothing written back
     const int cc = active ? c : T - 1;
-    double* thn_lds = s_thn + row * PT_DMAX;
+    double* thn_lds = s_thn + crow * PT_DMAX;
     const uint32_t chain_base = (uint32_t)((L.replica0 + lad) * L.T_global + L.slot0);
     const RngKey key{L.seed0, L.seed1, chain_base + (uint32_t)cc};
     const int npad = p3l_pad(L.n);                         // neutral pad data completing the last chunk (carma_types.h)
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             const uint64_t iter = L.iter0 + (uint64_t)it;
             __syncthreads();                               // proposals visible
             if constexpr (WIN)
-                pipew_produce<P>(g, wave - 2, thn_lds, series, L.n, ringw, [](int) {});
+                pipew_produce<P, TWO, TWO>(g, wave - 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
             else
                 pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [](int) {});
             if (wave == 2) {
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                     s_lu[lane64] = i > 0 ? log(rng_uniform(k2, iter, RNG_SWAP, 0)) : 0.0;
                 }
                 const double ua = rng_uniform(key, iter, RNG_ACCEPT, 0);     // the rows' Metropolis uniforms
-                if (j == 0) s_ua[row] = ua;
+                if (j == 0) s_ua[crow] = ua;
             }
             __syncthreads();                               // log-densities (and these draws) visible
             __syncthreads();                               // sweep done
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 if constexpr (WIN) {
                     const double lpri = log_prior(m.scale, pr.measerr_dof);
                     if (j == 0) ringw[PipeWGeom<P>::OUT_OFF + row] = make_double2(lpri, m.valid ? 1.0 : 0.0);
-                    pipew_produce<P>(g, 2, thn_lds, series, L.n, ringw, [](int) {});
+                    pipew_produce<P, TWO, TWO>(g, 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
                 } else {
                 double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], m.scale, series[L.n - 1].y, m.mu);
                 asm volatile("" : "+v"(lpri));
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 double ll = pipe3l_mean<P>(g, m.mu, series, L.n + npad, npad, ring, &sing);
                 ll += lpri;
                 if (sing || !m.valid) ll = -1.0 / 0.0;
-                if (j == 0) s_ll[row] = ll;
+                if (j == 0) s_ll[crow] = ll;
                 }
             }
             __syncthreads();                               // log-densities visible to the chain wave
@@ -512,11 +530,11 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             RowConsts<P> rc;
             row_consts<P>(g, m, fc, rc);
             if constexpr (WIN) {
-                double llw = pipew_recur<P>(g, rc, ringw);
+                double llw = pipew_recur<P, TWO>(g, rc, ringw);
                 const double2 o = ringw[PipeWGeom<P>::OUT_OFF + row];
                 llw += o.x;
                 if (m.sing || o.y == 0.0) llw = -1.0 / 0.0;
-                if (j == 0) s_ll[row] = llw;
+                if (j == 0) s_ll[crow] = llw;
             } else {
                 pipe3l_cov<P>(g, m, rc, series, L.n + npad, npad, ring);
             }
@@ -525,14 +543,14 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
         __syncthreads();                                   // log-densities visible
         CARMA_STAMP(st3);
         double alpha;
-        if (ram_accept_row(ch, temperature, iter, key, s_ll[row], &lp, &alpha, s_ua + row)) nacc++;
+        if (ram_accept_row(ch, temperature, iter, key, s_ll[crow], &lp, &alpha, s_ua + crow)) nacc++;
         if (exch) {
             // publish this workgroup's chains as tagged words (see "tagged staging"): fire and forget
             const size_t nval = nchain_all * (size_t)(d + 1);
             unsigned long long* st_a = S.stage + (size_t)buf * 2 * nval + (size_t)(ch0 + c) * (d + 1);
             unsigned long long* st_b = st_a + nval;
             const unsigned long long tg1 = pt_tag(iter, S.epoch, 1), tg2 = pt_tag(iter, S.epoch, 2);
-            if (active) {
+            if (active && pub) {
                 if (j < d) {
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(ch.th);
                     __hip_atomic_store(&st_a[j], bits ^ tg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -577,7 +595,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             }
         }
     }
-    if (active) {
+    if (active && pub) {
         if (j < d) {
             theta[(ch0 + c) * d + j] = ch.th;
 #pragma unroll
@@ -591,17 +609,19 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     }
 }
 
-static size_t pt_row_lds(int d, int T)
+static size_t pt_row_lds(int d, int T, int n_series = 0)
 {
     (void)d;
+    if (n_series > 0) return ((pt_row_lds(d, T) + 15) & ~(size_t)15) + 16 + (size_t)(n_series + (n_series & 1)) * 24;   // (two-sided: + the series)
     // rings, proposals [4][16], s_ll [4], s_ua [4], s_lp / s_dbeta / s_logu [T], s_nswap + s_src [T] (4 B each), flag, s_z / s_lu [64], step, s_tha
     return Pipe3LGeom<2>::BYTES + (4 * (size_t)PT_DMAX + 8 + 3 * (size_t)T) * 8 + (size_t)T * 8 + 16 + 128 * 8 + 16 +
            (size_t)T * (PT_DMAX + 1) * 8;
 }
 
 template <int P>
-static const void* pt_row_fn(int minw, bool win = false)
+static const void* pt_row_fn(int minw, bool win = false, bool two = false)
 {
+    if (two && minw < 3) return reinterpret_cast<const void*>(&k_pt_row<P, 2, true, true>);
     if (win && minw < 3) return reinterpret_cast<const void*>(&k_pt_row<P, 2, true>);
     return minw >= 3 ? reinterpret_cast<const void*>(&k_pt_row<P, 3>) : reinterpret_cast<const void*>(&k_pt_row<P, 2>);
 }
@@ -649,15 +669,24 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
                                   const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
                                   unsigned* nswap, double* samples, double* sample_lp, hipStream_t st)
 {
-    const size_t lds = pt_row_lds(L.d, L.T);
-    const long grid = (long)L.R * S.wpl;
+    // the TWO-SIDED window pipeline (a chain = two rows, ceil(T / 2) workgroups a ladder) where the WHOLE ladder set's grid in that form
+    // is at most two workgroups per CU, the series suits the window pipeline and fits the LDS beside the rings; from T_global, so
+    // that a sharded ladder's blocks decide as the one-GPU run does.  CARMA_TUNE_PT_ROW_WIN = 0 / 1 (one-datum / one-sided window)
+    // or 2 (two-sided) overrides.
+    const long grid2_global = (long)L.R * (((long)L.T_global + 1) / 2);
+    bool two = grid2_global <= 2L * S.ncu && S.window_ok && L.n >= 32 && L.n <= 1024;    // (24 KiB of series: two workgroups still share a CU)
+    if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) two = ew == 2 && grid2_global <= 2L * S.ncu && L.n >= 32 && L.n <= 1024;
+    const int wpl = two ? (L.T + 1) / 2 : S.wpl;
+    const size_t lds = pt_row_lds(L.d, L.T, two ? L.n : 0);
+    const long grid = (long)L.R * wpl;
     const int minw = grid > 2L * S.ncu ? 3 : 2;             // the 168-register build only where three workgroups share a CU
     // the windowed pipeline where the WHOLE ladder's grid is at most one workgroup per CU (from T_global: a sharded ladder's blocks
     // decide as the one-GPU run does, so both stay on one arithmetic); CARMA_TUNE_PT_ROW_WIN=0 / 1 overrides (carma_tune_set)
     const long grid_global = (long)L.R * (((long)L.T_global + 3) / 4);
     bool win = grid_global <= (long)S.ncu && S.window_ok;       // (and the series suits it: carma_types.h, SERIES_WINDOW_OK)
     if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) win = ew != 0 && minw < 3;
-    const void* fn = pt_row_fn<P>(minw, win);
+    two = two && minw < 3;
+    const void* fn = pt_row_fn<P>(minw, win, two);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     PtLaunch La = L;
@@ -671,17 +700,18 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
         const char* e = getenv("CARMA_TUNE_PT_ROW_ROT");                        // measurements only; read once
         return e ? strtol(e, nullptr, 16) : -1L;
     }();
-    Sa.rot = S.wpl == 1 ? 0x36D2 : 0xB14E;
+    Sa.wpl = wpl;
+    Sa.rot = wpl == 1 ? 0x36D2 : 0xB14E;
     if (tune_rot >= 0) Sa.rot = (int)tune_rot;
     static const long tune_xcd = [] {
         const char* e = getenv("CARMA_TUNE_PT_ROW_XCD_MAP");                    // measurements only; read once
         return e ? atol(e) : -1L;
     }();
-    Sa.xcd_map = (S.wpl > 1 && L.R % 8 == 0) ? 8 : 1;
+    Sa.xcd_map = (wpl > 1 && L.R % 8 == 0) ? 8 : 1;
     if (tune_xcd >= 0) Sa.xcd_map = (tune_xcd > 1 && L.R % tune_xcd == 0) ? (int)tune_xcd : 1;
     Prior pra = pr;
     void* args[] = {&La, &Sa, (void*)&series, &pra, (void*)&temps, &theta, &logpost, &chol, &naccept, &nswap, &samples, &sample_lp};
-    if (S.wpl == 1)
+    if (wpl == 1)
         // the whole ladder (block) in one workgroup: the rendezvous has a single participant, no co-residency needed --
         // an ordinary launch (a cooperative one costs ~2 ms on this stack, which matters when the ladder is sharded
         // across GPUs and every iteration is a launch of its own)
