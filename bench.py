@@ -377,7 +377,9 @@ def main():
         kernel_name = ctx.kernel_name(B)
         ids = cpa._lib.build_ids()
         traffic_gbs_bytes, traffic_src, pmc_extra = None, None, None
-        pj, pmc_path = committed_pmc(kernel_name, ((B + 3) // 4) * 256, ids)       # same kernel, same launch shape, same build
+        # (grid in threads: the two-sided kernel takes two evaluations per 256-thread workgroup, the other wave pipelines four)
+        wgs = (B + 1) // 2 if kernel_name.startswith("k_logdens_carma_w2<") else (B + 3) // 4
+        pj, pmc_path = committed_pmc(kernel_name, wgs * 256, ids)                   # same kernel, same launch shape, same build
         if pj is not None and "FETCH_SIZE" in pj and "WRITE_SIZE" in pj:
             traffic_gbs_bytes = (2.0 * pj["FETCH_SIZE"]["mean"] + pj["WRITE_SIZE"]["mean"]) * 1024.0
             traffic_src = "%s (rocprofv3 --pmc of this command on this build, not live): upper bound 2*FETCH_SIZE+WRITE_SIZE bytes per launch" % pmc_path
@@ -388,13 +390,19 @@ def main():
             # per ITERATION: the iteration's wall time is what the counters are set against
             mcmc["pmc_per_iteration"] = pmc_digest(*committed_pmc("k_pt_row<%d," % p, None, ids), 1e6 / mcmc["iters_per_s"])
         if tput is not None:
-            tput["pmc_per_launch"] = pmc_digest(*committed_pmc(tput["kernel"], None, ids), tput["kernel_avg_us"])
+            tput["pmc_per_launch"] = pmc_digest(*committed_pmc(tput["kernel"], tput["batch_per_gpu"], ids), tput["kernel_avg_us"])
             ceilings(tput, tput["pmc_per_launch"])
         if tput1m is not None:
             # counters scale with the number of evaluations (same kernel, same per-wave instruction stream): the 65 536-evaluation
             # record, scaled by the ratio of the batch sizes, against THIS leg's launch time
-            tput1m["pmc_per_launch"] = pmc_digest(*committed_pmc(tput1m["kernel"], None, ids), tput1m["kernel_avg_us"],
-                                                  scale=tput1m["batch_per_gpu"] / 65536.0)
+            pj1, path1 = committed_pmc(tput1m["kernel"], tput1m["batch_per_gpu"], ids)      # counters of the 2^20-evaluation launches themselves
+            if pj1 is not None:
+                tput1m["pmc_per_launch"] = pmc_digest(pj1, path1, tput1m["kernel_avg_us"])
+                tput1m["ceilings_source"] = "measured at this launch size"
+            else:
+                tput1m["pmc_per_launch"] = pmc_digest(*committed_pmc(tput1m["kernel"], 65536, ids), tput1m["kernel_avg_us"],
+                                                      scale=tput1m["batch_per_gpu"] / 65536.0)
+                tput1m["ceilings_source"] = "scaled from the 65 536-evaluation record"
             ceilings(tput1m, tput1m["pmc_per_launch"])
         if mcmc is not None:
             ceilings(mcmc, mcmc["pmc_per_iteration"])

@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Condenses the rocprofv3 output of tools/profile_round.sh into the files committed under profiles/:
    kernel_stats_<tag>.csv       (the --stats kernel summary, verbatim)
-   pmc_<tag>.json               headline kernel k_logdens_carma_w<5> (round 5; before: k_logdens_carma_p3l<5>): per-LAUNCH mean/min/max of each counter
+   pmc_<tag>.json               headline kernel k_logdens_carma_w2<5> (round 6: two-sided; round 5: k_logdens_carma_w<5>; before: k_logdens_carma_p3l<5>):
+                                per-LAUNCH mean/min/max of each counter
    pmc_<tag>_ptrow.json         sampler kernel k_pt_row<5,...>: counters summed over its dispatches / iterations run
                                 (the bench's sampler leg under --mcmc-iters 200: 100 warm-up + 200 timed = 300) -> per ITERATION
    pmc_<tag>_tput.json          throughput kernel k_logdens_carma_lane<5> (one evaluation per lane): per launch of 65 536 evaluations
+   pmc_<tag>_tput1m.json        the same kernel's launches of 2^20 evaluations (the throughput_1m leg)
 usage: summarize_prof.py <tag> [outdir] [sampler-iterations-in-the-pmc-run (300)]"""
 import csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r05")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r06")
 pt_iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 os.makedirs(dst, exist_ok=True)
 sys.path.insert(0, root)
@@ -54,8 +56,9 @@ def collect(kern, grid=None, per_iteration=0):
     return res
 
 
-for name, kern, grid, it in (("", "k_logdens_carma_w<5>", 65536, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),
-                             ("_tput", "k_logdens_carma_lane<5", 65536, 0)):      # (the 65 536-evaluation launches, not the 2^20 ones of throughput_1m)
+for name, kern, grid, it in (("", "k_logdens_carma_w2<5>", 131072, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),      # (1024 evaluations: 512 workgroups x 256 threads)
+                             ("_tput", "k_logdens_carma_lane<5", 65536, 0), ("_tput1m", "k_logdens_carma_lane<5", 1 << 20, 0)):
+    # (the 65 536-evaluation launches and, separately, the 2^20 ones of throughput_1m)
     r = collect(kern, grid, it)
     if r["_dispatch"] is None:
         print("no dispatches of", kern)
