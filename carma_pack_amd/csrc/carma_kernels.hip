@@ -729,12 +729,14 @@ static long win_max_rows()
     const long v = tune_get(TUNE_WIN_ROWS);
     return v != TUNE_UNSET ? v : (long)device_cus();
 }
-// Largest launch (in EVALUATIONS) that takes the two-sided window pipeline: two workgroups of two evaluations per CU.
+// Largest launch (in EVALUATIONS) that takes the two-sided window pipeline: three workgroups of two evaluations per CU (measured
+// per order, profiles/r06/w2_sizes_v1.txt: p = 5 at 1280 / 1536 evaluations 29.6 us against the one-datum pipeline's 35.3 / 35.4,
+// p = 7 34.4 against 37.4, p = 3 23.6 against 26.9; at 2048 -- four per CU -- 38.2 against 35.5, 47.8 against 37.5, 31.3 against 27.0).
 // CARMA_TUNE_WIN2_EVALS overrides (0: never).
 static long win2_max_evals()
 {
     const long v = tune_get(TUNE_WIN2_EVALS);
-    return v != TUNE_UNSET ? v : 4L * device_cus();
+    return v != TUNE_UNSET ? v : 6L * device_cus();
 }
 // (an override of CARMA_TUNE_WIN_ROWS also lifts the series criterion: the tests force the window pipelines onto series that fail it)
 static bool win_forced() { return tune_get(TUNE_WIN_ROWS) != TUNE_UNSET; }

@@ -290,7 +290,7 @@ def test_launch_shapes_agree(cpa, p, q):
     res = {}
     lpc = 12000 if p >= 5 else 20000                                # one evaluation per lane + producer waves (round 3)
     assert ctx.kernel_name(lpc) == "k_logdens_carma_lpc<%d,3>" % p and ctx.kernel_name(70000) == "k_logdens_carma_lane<%d>" % p
-    shapes = [("p3", 48), ("p3b", 1000), ("p3c", 1100), ("p3d", 2000), ("p3e", 3072), ("plain", 70000), ("lpc", lpc)]
+    shapes = [("p3", 48), ("p3b", 1000), ("p3w", 1500), ("p3c", 1600), ("p3d", 2000), ("p3e", 3072), ("plain", 70000), ("lpc", lpc)]
     if pc_big > pc_small:
         shapes += [("pc", pc_small), ("pc2", pc_big)]
     for name, B in shapes:
@@ -308,8 +308,9 @@ def test_launch_shapes_agree(cpa, p, q):
     # puts all five on the latter
     win = os.environ.get("CARMA_TUNE_WIN_ROWS") != "0"
     assert ctx.kernel_name(1000) == ("k_logdens_carma_w2<%d>" if win else "k_logdens_carma_p3l<%d>") % p
-    assert ctx.kernel_name(1100) == "k_logdens_carma_p3l<%d>" % p
-    assert np.array_equal(res["p3"], res["p3b"], equal_nan=True)
+    assert ctx.kernel_name(1500) == ("k_logdens_carma_w2<%d>" if win else "k_logdens_carma_p3l<%d>") % p      # (three workgroups per CU)
+    assert ctx.kernel_name(1600) == "k_logdens_carma_p3l<%d>" % p
+    assert np.array_equal(res["p3"], res["p3b"], equal_nan=True) and np.array_equal(res["p3"], res["p3w"], equal_nan=True)
     for name in ("p3d", "p3e") + (() if win else ("p3",)):           # one kernel, whatever the number of workgroups per CU
         assert np.array_equal(res["p3c"], res[name], equal_nan=True), name
     if "pc" in res:
@@ -364,7 +365,7 @@ def test_series_lengths_around_chunk_boundaries(cpa, p, q):
         arb = lambda i: loglik_truth(t, y, yerr, th[i % 12], p, q)[0]   # noqa: E731
         # four-wave pipeline, one and two workgroups per CU / G-lane producer-consumer / one evaluation per lane with producer
         # waves (a six-step ring: n - 1 around its multiples too) and without
-        for B in (12, 1100, 3200, 12001 if p >= 5 else 20001, 50001):
+        for B in (12, 1100, 1600, 3200, 12001 if p >= 5 else 20001, 50001):     # (12, 1100: the two-sided window pipeline where n >= 16; 1600: the one-datum one)
             big = np.tile(th, (B // 12 + 1, 1))[:B]
             got = ctx.logdensity(big, ignore_prior=True)
             assert np.array_equal(got, np.tile(got[:12], B // 12 + 1)[:B], equal_nan=True), (n, B)

@@ -91,7 +91,8 @@ def test_series_window_criterion():
         pytest.skip("the dispatch under test is overridden by CARMA_TUNE_WIN_ROWS / CARMA_TUNE_WIN2_EVALS")
     g = np.load(os.path.join(ROOT, "tests", "golden", "carma53_readme.npz"))
     ctx = cpa.Context(g["t"], g["y"], g["yerr"], 5, 3)
-    assert ctx.kernel_name(1024) == "k_logdens_carma_w2<5>" and ctx.kernel_name(1025) == "k_logdens_carma_p3l<5>"
+    assert ctx.kernel_name(1024) == "k_logdens_carma_w2<5>" and ctx.kernel_name(1536) == "k_logdens_carma_w2<5>"
+    assert ctx.kernel_name(1537) == "k_logdens_carma_p3l<5>"
     t, y, e, _ = config4_series(1500, seed=4)
     ms = 10.0 * y.std()
     c4 = cpa.Context(t, y, e, 7, 6, max_stdev=ms)
