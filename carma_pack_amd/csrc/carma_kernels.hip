@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w(const double* __restric
 // Which wave plays which part: as k_logdens_carma_w.  (Measured and dropped, profiles/r06/w2_check_v2.txt: with two workgroups per
 // CU, two producer waves per workgroup on the SIMDs without a recursion wave and the set-up wave idle -- one producer then makes two
 // passes per chunk, and the recursion wave waits for it: 28.0 against 25.1 us per 1024 evaluations.)
-template <int P>
+// HO: the producers' schedule hand-over (carma_pipew.h, SSCHED) -- launches of more than one workgroup per CU.
+template <int P, bool HO>
 __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restrict__ theta, int B, int d, int q,
                                                           const double4* __restrict__ series, int n, Prior pr,
                                                           int ignore_prior, double* __restrict__ out, int ncu)
@@ -255,10 +256,10 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
     }
     if (wave >= 2) {
 #if defined(CARMA_STAMPS)
-        pipew_produce<P, true, true>(g, wave - 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
+        pipew_produce<P, true, true, HO>(g, wave - 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
         CARMA_MARK_DUMP("two-sided producer: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", wave - 2);
 #else
-        pipew_produce<P, true, true>(g, wave - 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
+        pipew_produce<P, true, true, HO>(g, wave - 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
 #endif
         __syncthreads();                                      // (the set-up wave's hand-over, below)
         return;
@@ -269,10 +270,10 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
         // very end only, and in front of the pipeline they kept the first chunk waiting (the other waves were at the first barrier
         // 3.5 k cycles before this one: profiles/r06/w2_stamps_v3.txt); now they run while the recursion wave merges
 #if defined(CARMA_STAMPS)
-        pipew_produce<P, true, true>(g, 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
+        pipew_produce<P, true, true, HO>(g, 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
         CARMA_MARK_DUMP("two-sided set-up wave: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", 2);
 #else
-        pipew_produce<P, true, true>(g, 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
+        pipew_produce<P, true, true, HO>(g, 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
 #endif
         model_from_theta<P, 16, MODEL_FLAGS>(g, th, q, pr, ignore_prior, m);
         const double lpri = log_prior(m.scale, pr.measerr_dof);
@@ -862,14 +863,16 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
         case LdShape::WIN2:
         {
             const size_t lds = PipeWGeom<P>::bytes_with_series(n);
-            if (lds > 64 * 1024) {
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logdens_carma_w2<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    160 * 1024);
-                if (ea != hipSuccess) return ea;
-            }
-            hipLaunchKernelGGL((k_logdens_carma_w2<P>), dim3((unsigned)(((long)B + 1) / 2)), dim3(256), lds, st, theta, B, d, q, series, n, pr,
-                               ignore_prior, out, device_cus());
-            return hipGetLastError();
+            const long wgs = ((long)B + 1) / 2;
+            auto go = [&](auto kern) -> hipError_t {
+                if (lds > 64 * 1024) {
+                    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (ea != hipSuccess) return ea;
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, st, theta, B, d, q, series, n, pr, ignore_prior, out, device_cus());
+                return hipGetLastError();
+            };
+            return wgs > device_cus() ? go(&k_logdens_carma_w2<P, true>) : go(&k_logdens_carma_w2<P, false>);
         }
         case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);
         case LdShape::PC2: return launch_pc(&k_logdens_carma_pc<P, G, 2>, waves, 2);

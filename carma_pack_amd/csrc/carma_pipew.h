@@ -68,7 +68,8 @@ struct PipeWGeom {
     static constexpr int MRG_T = MRG_L + P * MRG_STRIDE;      //   double[P][ST]  T = Db L, row i = lane ND + i's; [i][P] = u_i
     static constexpr int MRG_DOUBLES = MRG_T + P * MRG_STRIDE;
     static constexpr int TH_OFF = MRG_OFF + (2 * MRG_DOUBLES + 1) / 2;   // two-sided log-density kernel: double[4 waves][4 rows][16], theta per row
-    static constexpr int ENTRIES = TH_OFF + 128;
+    static constexpr int SCH_OFF = TH_OFF + 128;              // two-sided kernels: double2[NB][4 rows][2], the schedule's hand-over (pipew_produce)
+    static constexpr int ENTRIES = SCH_OFF + NB * 4 * 2;
     // two-sided log-density kernel: the series behind everything else, double2 {y, yerr^2}[n] then double t[n]
     static constexpr int SER_OFF = ENTRIES;
     static __host__ __device__ size_t bytes_with_series(int n) { return BYTES + (size_t)(n + (n & 1)) * 24; }
@@ -87,7 +88,7 @@ struct PipeWGeom {
 // SLDS (the two-sided log-density kernel): the series is in LDS -- times lds_t[n_all], {y, yerr^2} lds_yz[n_all], copied by the kernel,
 // visible behind the first barrier -- and a chunk's records are read where they are needed; elsewhere each row keeps a window of 64
 // records in registers (below).
-template <int P, bool TS = false, bool SLDS = false, class Tail>
+template <int P, bool TS = false, bool SLDS = false, bool HANDOVER = false, class Tail>
 __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const double* __restrict__ theta,
                                               const double4* __restrict__ series, int n_all, double2* __restrict__ ring, Tail&& tail,
                                               long long* mk = nullptr, const double* __restrict__ lds_t = nullptr,
@@ -186,17 +187,27 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
     // schedule state of this row (row-uniform)
     int j0 = 0;
     double base = t_first;                                    // (SLDS: read behind the first barrier, below)
-    // ---- A chunk in two parts: prepare() -- its schedule and its exponentials, nothing that needs h, c -- and the entries.  (Round 6
-    // tried chunk 0's prepare() in front of the first barrier and every later one behind the barrier of the chunk before: the producers
+    // ---- A chunk in three parts: its schedule, its exponentials (neither needs h, c) and the entries.  (Round 6 tried schedule and
+    // exponentials of chunk 0 in front of the first barrier and every later one's behind the barrier of the chunk before: the producers
     // start up to 1.4 k cycles after the recursion wave and reach that barrier no earlier than it does, so nothing was hidden --
     // 18.55 against 18.51 us per launch, the row sampler 31.7 against 32.4 k it/s on one box, profiles/r06/ab_rotation_v1.txt.)
-    int len = 0;
+    // SSCHED (the two-sided kernels, series in LDS, instantiated with HANDOVER where workgroups SHARE a CU): the schedule of chunk c + 1 is formed by ONE
+    // producer -- the one that also forms the data slots -- while chunk c is in the making, and reaches the other two through LDS
+    // behind chunk c's barrier (chunk 0's by everyone); three copies of it were 225 of a workgroup's 780 producer instructions per
+    // chunk, and with two or three workgroups on a CU its VALU issue slots are what the launch runs out of: 24.2 -> 22.3 us per 1024
+    // evaluations, 29.6 -> 27.8 per 1536, the row sampler at 16 x 64 39.6 -> 41.5 k it/s.  With a CU to itself a workgroup waits for
+    // its slowest producer instead, and the scheduling one is then longer than the three equal ones were (17.8 -> 18.5 us; as a RUN-TIME
+    // switch the code alone cost that much): not there, a template parameter (profiles/r06/ab_ssched_v1.txt).
+    constexpr bool SSCHED = TS && SLDS && HANDOVER;
+    int len = 0, jc = 0;                                      // jc: first datum of the chunk
     bool rot = false, last = false, fin = false;              // fin (TS): the final chunk (no data, the rotation to the meeting time)
-    double2 dslot = make_double2(1.0, 0.0);                   // {scale yerr^2, y - mu} of this lane's datum (pw == 0)
+    double dt_rot = 0.0, dta_keep = 0.0;                      // time from the closing window's base to the chunk's first datum
+    double2 dslot = make_double2(1.0, 0.0);                   // {scale yerr^2, y - mu} of this lane's datum (producer PWD)
     unsigned long long rbits = 0ull;
     double ecv[NIT], esv[NIT], e1v[NIT];
-    auto prepare = [&]() __attribute__((always_inline)) {
+    auto sched = [&](bool finflag) __attribute__((always_inline)) {
         // --- schedule of this row's chunk: lane s looks at datum j0 + s
+        jc = j0;
         const int jl = j0 + l;
         double4 rec;
         if constexpr (SLDS) {
@@ -232,28 +243,62 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         // slowest row (34.1 us per 1024 evaluations, profiles/r05/window_pipeline_v1.txt).
         const int left = n - j0;
         const int ncand = left < ND ? (left > 0 ? left : 0) : ND;
-        const double t0 = fin ? t_meet : Grp<16>::template bcast_c<0>(tj);
+        const double t0 = finflag ? t_meet : Grp<16>::template bcast_c<0>(tj);
         const double t_lastc = SLDS ? tsgn * lds_t[sidx(j0 + (ncand > 0 ? ncand - 1 : 0))] : __shfl(tj, rowb + (ncand > 0 ? ncand - 1 : 0), 64);
         const double W = sc > 0.0 ? 1.0 / sc : 1.0 / 0.0;
-        rot = fin || (ncand > 0 && (t_lastc - base) > W);
-        const double base_old = base;
+        rot = finflag || (ncand > 0 && (t_lastc - base) > W);
+        dt_rot = t0 - base;
         base = rot ? t0 : base;
         // (the difference of two time stamps is exact unless the base is much the smaller of the two: carma_pipe3l.h)
         const double dta_l = tj - base;
+        dta_keep = dta_l;
         const unsigned long long flb = __ballot(dta_l > W && l < ncand);
         const unsigned cut = (unsigned)(flb >> (16 * q)) & 0xffffu;            // (bit 0 never: dta = 0 or <= W at slot 0)
         len = cut ? __builtin_ctz(cut) : ncand;
         const bool row_done = j0 + len >= n;
         last = __ballot(!row_done) == 0ull;
-        if (pw == 0) rbits = __ballot(rot);
         if (pw == PWD) dslot = l < len ? make_double2(rec.z * scale, rec.y - mu) : make_double2(1.0, 0.0);
-        // --- exponentials
+        j0 += len;
+        if (!SLDS && j0 - jw >= 16) {                         // (at most one shift per chunk: len < 16)
+            rw0 = rw1;
+            rw1 = rw2;
+            rw2 = rw3;
+            jw += 16;
+            rw3 = recat(jw + 48 + l);
+        }
+    };
+    // the schedule's hand-over (SSCHED): per ring buffer and row {(first datum | len << 16 | rot << 24 | last << 25), new base}, {dt_rot, -}
+    double2* schb = ring + Geo::SCH_OFF;
+    auto sched_put = [&](int b) __attribute__((always_inline)) {
+        if (l == 0) {
+            const int bits = jc | (len << 16) | (rot ? 1 << 24 : 0) | (last ? 1 << 25 : 0);
+            schb[(b * 4 + q) * 2] = make_double2(__hiloint2double(0, bits), base);
+            schb[(b * 4 + q) * 2 + 1] = make_double2(dt_rot, 0.0);
+        }
+    };
+    auto sched_get = [&](int b) __attribute__((always_inline)) {
+        const double2 s0 = schb[(b * 4 + q) * 2], s1 = schb[(b * 4 + q) * 2 + 1];
+        const int bits = __double2loint(s0.x);
+        jc = bits & 0xffff;
+        len = (bits >> 16) & 0xff;
+        rot = ((bits >> 24) & 1) != 0;
+        last = ((bits >> 25) & 1) != 0;
+        base = s0.y;
+        dt_rot = s1.x;
+    };
+    auto exps = [&]() __attribute__((always_inline)) {
+        if (pw == 0) rbits = __ballot(rot);
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int slot = it * NPROD * PPL + pw * PPL + sub;
             const bool is_rot = slot == ND;
-            const double dts = SLDS ? tsgn * lds_t[sidx(j0 + (slot < ND ? slot : 0))] - base : __shfl(dta_l, rowb + (slot < ND ? slot : 0), 64);
-            const double dt = is_rot ? t0 - base_old : dts;
+            double dts;
+            if constexpr (SLDS) {
+                dts = tsgn * lds_t[sidx(jc + (slot < ND ? slot : 0))] - base;
+            } else {
+                dts = __shfl(dta_keep, rowb + (slot < ND ? slot : 0), 64);    // (lane `slot` of the row looked at that datum in sched())
+            }
+            const double dt = is_rot ? dt_rot : dts;
             const bool live = worker && (is_rot ? rot : slot < len);
             double ec = 1.0, es = 0.0, e1 = 1.0;
             if (live) cexp_step_tab<true>(w.re, w.im, dt, &ec, &es, tab);
@@ -262,14 +307,6 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
             ecv[it] = ec;
             esv[it] = es;
             e1v[it] = e1;
-        }
-        j0 += len;
-        if (!SLDS && j0 - jw >= 16) {                         // (at most one shift per chunk: len < 16)
-            rw0 = rw1;
-            rw1 = rw2;
-            rw2 = rw3;
-            jw += 16;
-            rw3 = recat(jw + 48 + l);
         }
     };
     PIPEW_MARK(1);
@@ -308,8 +345,13 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
 #if defined(CARMA_WIN_STAMPS)
         WIN_STAMP(ps_t0);
 #endif
-        prepare();
-        // --- the prepared chunk's header, data slots and entries
+        // --- schedule (chunk 0, or no hand-over: everyone's; else the scheduling producer has it from the chunk before) and exponentials
+        if (!SSCHED || c == 0)
+            sched(fin);
+        else if (pw != PWD)
+            sched_get(b);
+        exps();
+        // --- the chunk's header, data slots and entries
         if (pw == 0 && lane == 0)
             reinterpret_cast<unsigned long long*>(ring + Geo::HDR_OFF)[b] =
                 ((rbits & 1ull) | ((rbits >> 15) & 2ull) | ((rbits >> 30) & 4ull) | ((rbits >> 45) & 8ull)) | ((TS ? fin : last) ? 256ull : 0ull);
@@ -348,6 +390,11 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         WIN_STAMP(ps_t1);
         ps_work += ps_t1 - ps_t0;
 #endif
+        const bool last_c = last, fin_c = fin;
+        if (SSCHED && pw == PWD && !(TS ? fin_c : last_c)) {  // the next chunk's schedule, for everyone
+            sched(last_c);
+            sched_put((c + 1) % NB);
+        }
         if (c < 3) PIPEW_MARK(3 + 2 * c - (c == 2));           // chunk 0, 1: arrival at the barrier (marks 3, 5); chunk 2: mark 6
         __syncthreads();                                      // barrier c: chunk c is in the ring
         if (c == 0) PIPEW_MARK(4);
@@ -356,8 +403,8 @@ __device__ __forceinline__ void pipew_produce(const Grp<16>& g, int pw, const do
         ps_wait += ps_t0 - ps_t1;
         ps_n++;
 #endif
-        if (TS ? fin : last) break;
-        fin = last;
+        if (TS ? fin_c : last_c) break;
+        fin = last_c;
     }
 #if defined(CARMA_WIN_STAMPS)
     if (blockIdx.x == 0 && lane == 0)

@@ -280,7 +280,7 @@ __device__ __forceinline__ unsigned long long pt_tag(unsigned long long iter, un
 // first half of the series forward, the odd one the second half backward, and the chain wave merges the two states; two chains per
 // workgroup, a ladder over ceil(T / 2) of them.  Both rows carry the chain's state (the same values, formed twice), the even row
 // publishes it.  The series sits in LDS for the producers (copied once per launch).
-template <int P, int MINW, bool WIN = false, bool TWO = false>
+template <int P, int MINW, bool WIN = false, bool TWO = false, bool HO = false>
 __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
                                                    const double* __restrict__ temps, double* __restrict__ theta,
                                                    double* __restrict__ logpost, double* __restrict__ chol,
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             const uint64_t iter = L.iter0 + (uint64_t)it;
             __syncthreads();                               // proposals visible
             if constexpr (WIN)
-                pipew_produce<P, TWO, TWO>(g, wave - 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
+                pipew_produce<P, TWO, TWO, HO>(g, wave - 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
             else
                 pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [](int) {});
             if (wave == 2) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 if constexpr (WIN) {
                     const double lpri = log_prior(m.scale, pr.measerr_dof);
                     if (j == 0) ringw[PipeWGeom<P>::OUT_OFF + row] = make_double2(lpri, m.valid ? 1.0 : 0.0);
-                    pipew_produce<P, TWO, TWO>(g, 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
+                    pipew_produce<P, TWO, TWO, HO>(g, 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
                 } else {
                 double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], m.scale, series[L.n - 1].y, m.mu);
                 asm volatile("" : "+v"(lpri));
@@ -619,9 +619,10 @@ static size_t pt_row_lds(int d, int T, int n_series = 0)
 }
 
 template <int P>
-static const void* pt_row_fn(int minw, bool win = false, bool two = false)
+static const void* pt_row_fn(int minw, bool win = false, bool two = false, bool ho = false)
 {
-    if (two && minw < 3) return reinterpret_cast<const void*>(&k_pt_row<P, 2, true, true>);
+    // (HO: the two-sided form's schedule hand-over, where workgroups share a CU: carma_pipew.h SSCHED)
+    if (two && minw < 3) return ho ? reinterpret_cast<const void*>(&k_pt_row<P, 2, true, true, true>) : reinterpret_cast<const void*>(&k_pt_row<P, 2, true, true, false>);
     if (win && minw < 3) return reinterpret_cast<const void*>(&k_pt_row<P, 2, true>);
     return minw >= 3 ? reinterpret_cast<const void*>(&k_pt_row<P, 3>) : reinterpret_cast<const void*>(&k_pt_row<P, 2>);
 }
@@ -686,7 +687,7 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     bool win = grid_global <= (long)S.ncu && S.window_ok;       // (and the series suits it: carma_types.h, SERIES_WINDOW_OK)
     if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) win = ew != 0 && minw < 3;
     two = two && minw < 3;
-    const void* fn = pt_row_fn<P>(minw, win, two);
+    const void* fn = pt_row_fn<P>(minw, win, two, grid > (long)S.ncu);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     PtLaunch La = L;
