@@ -451,6 +451,8 @@ def main():
             "rccl_version": rccl_version,
             "ranks": ranks_info,
             "finite_in_last_batch": n_finite,
+            "timing": "K steps between torch.cuda.synchronize() calls; every rank reads its clock BEFORE the closing barrier, MAX over ranks "
+                      "(the barrier's own latency is not a step: changed in round 5, see NOTEBOOK.md)",
         }
         if mcmc is not None:
             res["mcmc"] = mcmc

@@ -212,3 +212,13 @@ def test_math_tables_are_the_generators_output():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_math_tables.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_window_asm_header_is_the_generators_output():
+    """carma_win_asm.h (the window pipeline's pivot and chunk-start blocks, one inline-asm statement each) is generated by
+    tools/gen_win_asm.py: regenerated IN MEMORY and compared (round-5 advice) -- the test never writes into csrc/."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_win_asm.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
