@@ -10,7 +10,7 @@ chunk():  for j = 0 .. ND-1  (EXEC = lanes >= j of every row, so that a finished
           the register its own pivot READ: m and nu alternate between two registers, pivot j reads A/B for j even/odd)
               G = sum_r kk_r@j hh_r ;  t = -G / m@j (v_rcp_f64 + one Newton step, folded into t) ;
               m' = m + G t ;  nu' = nu + nu@j t ;  kk_r += kk_r@j t
-          EXEC = all lanes again at the end.
+          EXEC is saved on entry and restored at the end.
           ALL pivots are one statement: between two statements the compiler may place copies, and a copy executed under
           the reduced EXEC would not reach the finished lanes.
 init():   kn_r += sum_s kk_r@(ND+s) hn_s   (kn_r preloaded with c~_r: k~ = S h~ + c~, kfilter.cpp:191 -- or with 0 at a re-base,
@@ -27,9 +27,11 @@ DPP = " row_newbcast:%d row_mask:0xf bank_mask:0xf"
 
 def chunk_block(P):
     ND = 16 - P
-    # operands: 0 G 1 rb 2 bnu 3 r0 4 e 5 t | 6 mA 7 mB 8 nuA 9 nuB | 10.. kk_r | 10+P.. hh_r
-    ikk, ihh = 10, 10 + P
-    L = []
+    # operands: 0 G 1 rb 2 bnu 3 r0 4 e 5 t | 6 mA 7 mB 8 nuA 9 nuB | 10.. kk_r | 10+P saved EXEC | 11+P.. hh_r
+    ikk, isave, ihh = 10, 10 + P, 11 + P
+    # (EXEC is narrowed per pivot; the statement SAVES it on entry and RESTORES it at the end -- not "-1" -- so that a caller under a
+    # partial EXEC gets its mask back: round-5 advice)
+    L = ["s_mov_b64 %%%d, exec" % isave]
     for j in range(ND):
         cur_m, alt_m, cur_n, alt_n = (6, 7, 8, 9) if j % 2 == 0 else (7, 6, 9, 8)
         mask = (0xFFFF << j) & 0xFFFF
@@ -55,9 +57,10 @@ def chunk_block(P):
             L.append("v_fmac_f64_dpp %%%d, %%%d, %%5" % (ikk + r, ikk + r) + DPP % j)
         if P < 3:
             L.append("s_nop %d" % (2 - P))          # kk_r written -> DPP read in the next pivot: keep two wait states
-    L.append("s_mov_b64 exec, -1")
+    L.append("s_mov_b64 exec, %%%d" % isave)
     outs = ['"=&v"(G)', '"=&v"(rb)', '"=&v"(bnu)', '"=&v"(r0)', '"=&v"(e)', '"=&v"(t)', '"+v"(mA)', '"+v"(mB)', '"+v"(nuA)', '"+v"(nuB)']
     outs += ['"+v"(kk[%d])' % r for r in range(P)]
+    outs += ['"=&s"(exec_save)']
     ins = ['"v"(hh[%d])' % r for r in range(P)]
     return L, ", ".join(outs), ", ".join(ins)
 
@@ -93,6 +96,7 @@ for P in range(2, 8):
     out.append('                                                 double& nuB)')
     out.append('    {')
     out.append('        double G, rb, bnu, r0, e, t;')
+    out.append('        unsigned long long exec_save;')
     out.append(emit(l, o, i).rstrip("\n"))
     out.append('    }')
     l, o, i = init_block(P)
