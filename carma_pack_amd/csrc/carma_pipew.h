@@ -467,7 +467,6 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     const bool bwd = (q & 1) != 0, virt = l >= ND;
     const int j = virt ? l - ND : 0;                          // this lane's column (the other lanes' results are not used)
     double* mrg = reinterpret_cast<double*>(ring + Geo::MRG_OFF) + (q >> 1) * Geo::MRG_DOUBLES;
-    double* colb = mrg + Geo::MRG_COL;
     // forward row: column s of Da and -a_s to LDS
     if (!bwd && virt) {
         double* dst = mrg + Geo::MRG_X + j * ST;
@@ -511,9 +510,16 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
     PIPEW_MARK(8);
     // ---- X = L L^T with diagonal pivoting.  Lane j keeps ROW j of L: Lr[m] = L_jm, m the step.
     double Lr[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) Lr[i] = 0.0;
     bool done = !virt;
+    // (P copies of the step, on purpose: as a rolled loop -- nothing in a step depends on its number but the register L's entry goes
+    // to -- it took 3.3 k cycles instead of 2.6 k; the step is a chain of dependent latencies, not instruction fetch:
+    // profiles/r06/merge_variants_v1.txt)
+    bool exhausted = false;
     static_for<0, P>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
+        if (exhausted) return;
         // the largest remaining diagonal (a key of its upper 28 bits and the lane: the lowest lane wins a tie); nothing above
         // rounding level left: no pivot, a zero column.  Every candidate takes 1 / sqrt of its own diagonal meanwhile -- off the
         // step's serial chain -- and the pivot's lane sends its column already divided: l = (pivot column) / sqrt(pivot)
@@ -530,24 +536,31 @@ __device__ __forceinline__ void pipew_merge(int lane, const double (&kf)[P], dou
         // (no row of the wave has anything left above rounding level -- the numerical rank of X is below P as a rule --: the
         // remaining steps are zero columns everywhere)
         if (__builtin_amdgcn_ballot_w64(any) == 0ull) {
-            Lr[m] = 0.0;
+            exhausted = true;
             return;
         }
         const int pl = 15 - (int)(key & 15u);                 // the pivot's lane in the row (row-uniform)
         const bool isp = any && l == pl;
-        if (isp && bwd) {
+        // the pivot's column, already divided, from the pivot's lane: ds_bpermute (the lane is a run-time value; every lane offers its
+        // own column times its own 1 / sqrt -- zero where it is no candidate).  Through LDS -- the pivot's lane writes, everybody reads --
+        // a step took 510 cycles, the write -> read round trip on its serial chain.
+        const int src = (lane & ~15) + pl;
+        double cb[P];
 #pragma unroll
-            for (int i = 0; i < P; i++) colb[i] = S[i] * r_own;
-        }
-        merge_lds_sync();
-        // X_ij -= l_i l_j: the same two factors for both members of a symmetric pair
-        const double lj = (any && !done) ? colb[j] : 0.0;     // (the pivot's own: sqrt(pivot))
+        for (int i = 0; i < P; i++) cb[i] = __shfl(S[i] * r_own, src, 64);
+        // X_ij -= l_i l_j with l_j = X_j,pivot / sqrt(pivot) from the lane's own row entry (the same bits as the pivot column's j-th
+        // entry: the Schur complement is symmetric bit for bit) -- picked while the column is on its way
+        const double r_piv = __shfl(r_own, src, 64);
+        const int pc = pl - ND;
+        double sp = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) sp = pc == i ? S[i] : sp;
+        const double lj = (any && !done) ? sp * r_piv : 0.0;  // (the pivot's own: sqrt(pivot))
         Lr[m] = lj;
 #pragma unroll
-        for (int i = 0; i < P; i++) S[i] = fma(-colb[i], lj, S[i]);
+        for (int i = 0; i < P; i++) S[i] = fma(-cb[i], lj, S[i]);
         dg = fma(-lj, lj, dg);
         done = done || isp;
-        merge_lds_sync();                                     // (the next step's column must not overtake these reads)
     });
     PIPEW_MARK(9);
     // ---- T = Db L  (= -Y L):  T_im = sum_k Db_ik L_km, row i in lane i (Db_ik = this lane's kfs[k]: symmetric), L_km by broadcast
