@@ -318,6 +318,15 @@ carma_ctx* carma_ctx_create(const double* time, const double* y, const double* y
         long over = 0, tot = 0;
         for (int k = 0; k + ND - 1 < c->n; k++, tot++) over += (c->t[k + ND - 1] - c->t[k]) > wmin;
         c->window_ok = tot > 0 && 10 * over <= tot;
+        // SERIES_WINDOW2_OK / _SMALL: chunks of the row with the shortest window against ceil(n / ND)
+        long chunks = 0;
+        for (int k = 0; k < c->n; chunks++) {
+            int j = k;
+            while (j + 1 < c->n && j + 1 - k < ND && c->t[j + 1] - c->t[k] <= wmin) j++;
+            k = j + 1;
+        }
+        const double r = (double)chunks / (double)((c->n + ND - 1) / ND);
+        c->window2 = r <= 2.0 ? 2 : (r <= 3.5 ? 1 : 0);
     }
     hipError_t e = dev_malloc(&c->d_series, sizeof(double) * s.size());
     if (e == hipSuccess) e = hipMemcpy(c->d_series, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice);

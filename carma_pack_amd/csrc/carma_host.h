@@ -67,7 +67,12 @@ struct Ctx {
     Prior pr{};
     bool repeated_dt = false;         // >= 25 % of the time steps equal their predecessor (regular cadence)
     bool window_ok = false;           // the series suits the windowed wave pipeline (carma_capi.hip, carma_ctx_create)
-    int series_flags() const { return (repeated_dt ? SERIES_REPEATED_DT : 0) | (window_ok ? SERIES_WINDOW_OK : 0); }
+    int window2 = 0;                  // the TWO-SIDED window pipeline: 2 = suits it, 1 = with a CU per workgroup only (carma_types.h)
+    int series_flags() const
+    {
+        return (repeated_dt ? SERIES_REPEATED_DT : 0) | (window_ok ? SERIES_WINDOW_OK : 0) | (window2 == 2 ? SERIES_WINDOW2_OK : 0) |
+               (window2 >= 1 ? SERIES_WINDOW2_SMALL : 0);
+    }
     double* d_series = nullptr;       // records {dt, y, yerr^2, t}[n + 16 pads], then yerr^2[n + 16], y[n + 16] (carma_types.h)
     double* d_theta = nullptr;        // staging for the host-pointer entry points
     double* d_out = nullptr;

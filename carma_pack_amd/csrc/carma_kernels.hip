@@ -817,7 +817,8 @@ static LdShape logdens_shape(long B, int n, int series_flags)
     constexpr int EPW = 64 / GroupOf<P>::value;       // evaluations per wave of the G-lane kernels
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
-    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && n <= W2_MAX_N && ((series_flags & SERIES_WINDOW_OK) || win_forced()))
+    const bool w2ok = (series_flags & SERIES_WINDOW2_OK) || ((series_flags & SERIES_WINDOW2_SMALL) && B <= 2L * device_cus());
+    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && n <= W2_MAX_N && (w2ok || win_forced()))
         return LdShape::WIN2;                         // (CARMA_TUNE_WIN_ROWS = 0: no window pipeline of either kind)
     if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || win_forced())) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;

@@ -675,7 +675,8 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     // that a sharded ladder's blocks decide as the one-GPU run does.  CARMA_TUNE_PT_ROW_WIN = 0 / 1 (one-datum / one-sided window)
     // or 2 (two-sided) overrides.
     const long grid2_global = (long)L.R * (((long)L.T_global + 1) / 2);
-    bool two = grid2_global <= 2L * S.ncu && S.window_ok && L.n >= 32 && L.n <= 1024;    // (24 KiB of series: two workgroups still share a CU)
+    const bool w2ok = (S.window_ok & SERIES_WINDOW2_OK) || ((S.window_ok & SERIES_WINDOW2_SMALL) && grid2_global <= (long)S.ncu);
+    bool two = grid2_global <= 2L * S.ncu && w2ok && L.n >= 32 && L.n <= 1024;    // (24 KiB of series: two workgroups still share a CU)
     if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) two = ew == 2 && grid2_global <= 2L * S.ncu && L.n >= 32 && L.n <= 1024;
     const int wpl = two ? (L.T + 1) / 2 : S.wpl;
     const size_t lds = pt_row_lds(L.d, L.T, two ? L.n : 0);
@@ -684,7 +685,7 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     // the windowed pipeline where the WHOLE ladder's grid is at most one workgroup per CU (from T_global: a sharded ladder's blocks
     // decide as the one-GPU run does, so both stay on one arithmetic); CARMA_TUNE_PT_ROW_WIN=0 / 1 overrides (carma_tune_set)
     const long grid_global = (long)L.R * (((long)L.T_global + 3) / 4);
-    bool win = grid_global <= (long)S.ncu && S.window_ok;       // (and the series suits it: carma_types.h, SERIES_WINDOW_OK)
+    bool win = grid_global <= (long)S.ncu && (S.window_ok & SERIES_WINDOW_OK);       // (and the series suits it: carma_types.h)
     if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) win = ew != 0 && minw < 3;
     two = two && minw < 3;
     const void* fn = pt_row_fn<P>(minw, win, two, grid > (long)S.ncu);

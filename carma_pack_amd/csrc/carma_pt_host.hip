@@ -167,7 +167,7 @@ static int pt_enqueue_one(Ctx* c, long ch, int do_exchange, int thin, long* save
     const PtLaunch L = pt_launch_args(c, ch, do_exchange, thin, save_offset ? *save_offset : 0);
     hipError_t e;
     if (s->use_row) {
-        PtRowSync S{s->d_stage, s->d_abort, ++s->epoch, s->wpl, device_cus(), 1, c->window_ok ? 1 : 0, 0};
+        PtRowSync S{s->d_stage, s->d_abort, ++s->epoch, s->wpl, device_cus(), 1, c->series_flags(), 0};
         e = launch_pt_row(c->p, L, S, reinterpret_cast<const double4*>(c->d_series), c->pr, s->d_temps, s->d_theta, s->d_lp,
                           s->d_chol, s->d_nacc, s->d_nswap, s->d_samples, s->d_slp, st);
         if (e == hipErrorCooperativeLaunchTooLarge) {      // the grid is not co-resident on this device: ladder kernel

@@ -37,7 +37,14 @@ inline
 //                       rows with short windows cut their chunks and re-base at every chunk start, and a launch -- or a ladder's
 //                       rendezvous -- waits for them: BASELINE configs[3]'s series (min dt 0.1, median 1.1) ran 464 instead of 780
 //                       sampler iterations/s on that pipeline.
-constexpr int SERIES_REPEATED_DT = 1, SERIES_WINDOW_OK = 2;
+//   SERIES_WINDOW2_OK / _SMALL   the TWO-SIDED window pipeline suits it (round 6, profiles/r06/window_criterion_v*.txt).  Measure:
+//                       r = (chunks a row with the SHORTEST window needs: greedy, at most 16 - p data and at most that window per
+//                       chunk) / ceil(n / (16 - p)).  README series r = 1.0-1.08, OGLE-LMC-LPV-00007 (seasons; 20-55 % of the spans
+//                       over the window) 1.14-1.41: two-sided 1.3-1.8 x faster than the one-datum pipeline at every order, launch
+//                       size and ensemble tried; configs[3]'s time steps r = 2.5-3.9: 17-20 % faster with a CU per workgroup, 5-15 %
+//                       slower with two; one close pair of data in the README series (max_freq x 100) r = 9-13: 2-2.7 x slower.
+//                       OK: r <= 2.  SMALL: r <= 3.5, used by launches of at most one workgroup per CU.
+constexpr int SERIES_REPEATED_DT = 1, SERIES_WINDOW_OK = 2, SERIES_WINDOW2_OK = 4, SERIES_WINDOW2_SMALL = 8;
 
 // Arguments of one launch of the persistent PT kernel.
 struct PtLaunch {
@@ -65,7 +72,7 @@ struct PtRowSync {
     int wpl;                 // workgroups per ladder = ceil(T / 4)
     int ncu;                 // compute units of the device: workgroups i, i + ncu, i + 2 ncu share a CU
     int xcd_map;             // > 1: a ladder's workgroups sit xcd_map blocks apart (same XCD), see k_pt_row
-    int window_ok;           // the context's series suits the windowed pipeline (SERIES_WINDOW_OK)
+    int window_ok;           // the context's series_flags(): SERIES_WINDOW_OK (one-sided window pipeline), SERIES_WINDOW2_OK / _SMALL
     int rot;                 // which wave plays which part in the second (bits 0-7) and third (bits 8-15) workgroup of a CU:
                              // 2 bits per wave, set by the launcher (the placement differs between launch kinds)
 };

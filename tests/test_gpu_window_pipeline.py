@@ -80,10 +80,12 @@ def test_window_pipeline_long_series(two_sided):
 
 
 def test_series_window_criterion():
-    """SERIES_WINDOW_OK (set at context creation: 90 % of the spans of 16 - p consecutive data within half a re-base window of the
-    prior's fastest root).  The README series has it: window pipeline up to one workgroup per CU.  BASELINE configs[3]'s series
-    (time steps 0.1 + |Cauchy|, max_freq = 10) does not: the one-datum pipeline at every size -- and the window pipeline, forced,
-    is still right on it (most of its chunks are cut short there: slow, not wrong)."""
+    """SERIES_WINDOW2_OK / _SMALL (set at context creation, carma_types.h: the chunks a row with the SHORTEST window the prior admits
+    needs, against ceil(n / (16 - p)): <= 2 / <= 3.5).  The README series (1.0-1.08) and the OGLE quick-start series (1.14-1.41:
+    seasons) have it: the two-sided window pipeline up to six evaluations per CU.  BASELINE configs[3]'s time steps (0.1 + |Cauchy|:
+    2.5 at p = 7) have the SMALL form only -- two-sided with a CU per workgroup, the one-datum pipeline beyond --, one close pair of
+    data in the README series (max_freq x 100: 9-13) has neither; and the window pipelines, forced, are still right on such series
+    (most of their chunks are cut short there: slow, not wrong)."""
     import carma_pack_amd as cpa
     from carma_pack_amd.synth import config4_series
     from helpers import assert_parity, loglik_truth, prior_like_theta
@@ -96,7 +98,14 @@ def test_series_window_criterion():
     t, y, e, _ = config4_series(1500, seed=4)
     ms = 10.0 * y.std()
     c4 = cpa.Context(t, y, e, 7, 6, max_stdev=ms)
-    assert c4.kernel_name(64) == "k_logdens_carma_p3l<7>" and c4.kernel_name(1024) == "k_logdens_carma_p3l<7>"
+    assert c4.kernel_name(64) == c4.kernel_name(512) == "k_logdens_carma_w2<7>" and c4.kernel_name(513) == c4.kernel_name(1024) == "k_logdens_carma_p3l<7>"
+    d = np.loadtxt(os.path.join(ROOT, "tests", "golden", "ogle_lmc_lpv_00007.dat"))
+    for p, q in ((2, 1), (6, 0), (7, 6)):
+        co = cpa.Context(d[:, 0], d[:, 1], d[:, 2], p, q)
+        assert co.kernel_name(64) == co.kernel_name(1536) == "k_logdens_carma_w2<%d>" % p, (p, co.kernel_name(64))
+    k = 100
+    cc = cpa.Context(np.insert(g["t"], k + 1, g["t"][k] + 0.01), np.insert(g["y"], k + 1, g["y"][k]), np.insert(g["yerr"], k + 1, g["yerr"][k]), 5, 3)
+    assert cc.kernel_name(64) == cc.kernel_name(1024) == "k_logdens_carma_p3l<5>"
     rng = np.random.default_rng(77)
     th = np.array([prior_like_theta(rng, 7, 6, t, y) for _ in range(40)])
     m = orc.OracleModel(t, y, e, 7, 6, max_stdev=ms)

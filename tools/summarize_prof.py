@@ -56,7 +56,7 @@ def collect(kern, grid=None, per_iteration=0):
     return res
 
 
-for name, kern, grid, it in (("", "k_logdens_carma_w2<5>", 131072, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),      # (1024 evaluations: 512 workgroups x 256 threads)
+for name, kern, grid, it in (("", "k_logdens_carma_w2<5,", 131072, 0), ("_ptrow", "k_pt_row<5,", None, pt_iters),      # (1024 evaluations: 512 workgroups x 256 threads)
                              ("_tput", "k_logdens_carma_lane<5", 65536, 0), ("_tput1m", "k_logdens_carma_lane<5", 1 << 20, 0)):
     # (the 65 536-evaluation launches and, separately, the 2^20 ones of throughput_1m)
     r = collect(kern, grid, it)
