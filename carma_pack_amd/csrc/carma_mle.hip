@@ -124,8 +124,8 @@ extern "C" int carma_mle_batched(carma_ctx* h, const double* x0, int B, const do
     }
 
     std::vector<int> idx, need, mv;
-    std::vector<double> dir, pg, slope, gam, tstep, xn, fn, cand, xmv, fnew, gnew;
-    std::vector<char> frozen;
+    std::vector<double> dir, pg, slope, gam, tstep, xn, fn, cand, xmv, fnew, gnew, gspec, xmv2, fnew2, gnew2;
+    std::vector<char> frozen, haveg;
     for (int iter = 0; iter < maxiter; iter++) {
         // --- projected gradient test
         idx.clear();
@@ -207,41 +207,81 @@ extern "C" int carma_mle_batched(carma_ctx* h, const double* x0, int B, const do
             gam[i] = gm;
         }
         // --- Armijo backtracking on the projected path: LS_K consecutive step lengths of every start per launch, the
-        // FIRST that satisfies the condition is taken -- the step sequential backtracking would take, in ~1 launch
+        // FIRST that satisfies the condition is taken -- the step sequential backtracking would take, in ~1 launch.
+        // The first launch also carries the difference stencils around its first KS step lengths: a start that takes one of
+        // them has its new gradient from the same launch, and the iteration costs it ONE round trip to the device instead of
+        // two -- the search is bound by the slowest start's iterations (up to 2000 where the mean is 300-500:
+        // tools/choose_order_profile.py), i.e. by round trips, not by evaluations.  KS = 1 (the full step) while many starts
+        // are active, up to all LS_K once the launch stays within ~1024 evaluations (the two-sided kernel's flat range).
         tstep.assign(na, 1.0);
         xn.assign((size_t)na * d, 0.0);
         fn.assign(na, 0.0);
         std::vector<char> needf(na, 1);
+        haveg.assign(na, 0);
+        gspec.resize((size_t)na * d);
         for (int ls = 0; ls < 32; ls += LS_K) {
             need.clear();
             for (int i = 0; i < na; i++)
                 if (needf[i]) need.push_back(i);
             if (need.empty()) break;
             const int nn = (int)need.size();
-            cand.resize((size_t)nn * LS_K * d);
+            const int KS = ls == 0 ? std::max(1, std::min(LS_K, (1024 / nn - LS_K) / (2 * d))) : 0;
+            const int wl = LS_K + KS * 2 * d;                      // points of one start in this launch
+            cand.resize((size_t)nn * wl * d);
+            up.resize((size_t)nn * KS * d);
+            dn.resize((size_t)nn * KS * d);
             for (int a = 0; a < nn; a++) {
                 const int i = need[a], b = idx[i];
+                double* ca = &cand[(size_t)a * wl * d];
                 double tk = tstep[i];
                 for (int k = 0; k < LS_K; k++, tk *= 0.5)
                     for (int j = 0; j < d; j++)
-                        cand[((size_t)a * LS_K + k) * d + j] = project(x[(size_t)b * d + j] + tk * dir[(size_t)i * d + j], j);
+                        ca[(size_t)k * d + j] = project(x[(size_t)b * d + j] + tk * dir[(size_t)i * d + j], j);
+                for (int c = 0; c < KS; c++) {                     // the stencil of f_and_g around candidate c
+                    const double* xc = ca + (size_t)c * d;
+                    double* st = ca + (size_t)(LS_K + 2 * d * c) * d;
+                    double* upc = &up[((size_t)a * KS + c) * d];
+                    double* dnc = &dn[((size_t)a * KS + c) * d];
+                    for (int k = 0; k < 2 * d; k++) std::memcpy(st + (size_t)k * d, xc, sizeof(double) * d);
+                    for (int j = 0; j < d; j++) {
+                        const double hstep = fd_step * std::max(1.0, std::fabs(xc[j]));
+                        upc[j] = std::min(xc[j] + hstep, hi[j]);
+                        dnc[j] = std::max(xc[j] - hstep, lo[j]);
+                        st[(size_t)j * d + j] = upc[j];
+                        st[(size_t)(d + j) * d + j] = dnc[j];
+                    }
+                }
             }
-            const int rc = fun(cand, nn * LS_K);
+            const int rc = fun(cand, nn * wl);
             if (rc != CARMA_OK) return rc;
             for (int a = 0; a < nn; a++) {
                 const int i = need[a], b = idx[i];
+                const double* ca = &cand[(size_t)a * wl * d];
+                const double* fa = &fun.out[(size_t)a * wl];
                 int first = -1;
                 for (int k = 0; k < LS_K && first < 0; k++) {
                     double lin = 0.0;
-                    for (int j = 0; j < d; j++)
-                        lin += (cand[((size_t)a * LS_K + k) * d + j] - x[(size_t)b * d + j]) * pg[(size_t)i * d + j];
-                    if (fun.out[(size_t)a * LS_K + k] <= f[b] + 1e-4 * lin) first = k;
+                    for (int j = 0; j < d; j++) lin += (ca[(size_t)k * d + j] - x[(size_t)b * d + j]) * pg[(size_t)i * d + j];
+                    if (fa[k] <= f[b] + 1e-4 * lin) first = k;
                 }
                 if (first >= 0) {
                     nfev[b] += first + 1;          // as sequential backtracking counts
-                    std::memcpy(&xn[(size_t)i * d], &cand[((size_t)a * LS_K + first) * d], sizeof(double) * d);
-                    fn[i] = fun.out[(size_t)a * LS_K + first];
+                    std::memcpy(&xn[(size_t)i * d], ca + (size_t)first * d, sizeof(double) * d);
+                    fn[i] = fa[first];
                     needf[i] = 0;
+                    if (first < KS) {
+                        haveg[i] = 1;
+                        const double* fs = fa + LS_K + 2 * d * first;
+                        const double* upc = &up[((size_t)a * KS + first) * d];
+                        const double* dnc = &dn[((size_t)a * KS + first) * d];
+                        for (int j = 0; j < d; j++) {
+                            const double fu = fs[j], fd_ = fs[d + j];
+                            double gj = (fu - fd_) / std::max(upc[j] - dnc[j], 1e-300);
+                            if (fu >= BIG || fd_ >= BIG) gj = 0.0;
+                            gspec[(size_t)i * d + j] = gj;
+                        }
+                        nfev[b] += 2 * d;           // (f_and_g counts 2 d + 1 with the centre: that one is the step's own)
+                    }
                 } else {
                     nfev[b] += LS_K;
                     tstep[i] *= std::ldexp(1.0, -LS_K);
@@ -258,16 +298,35 @@ extern "C" int carma_mle_batched(carma_ctx* h, const double* x0, int B, const do
             }
         }
         if (mv.empty()) continue;
-        // --- gradients at the new points, history update, stopping rule
+        // --- gradients at the new points (a launch for the starts that did not take the full step), history update, stopping rule
         const int nm = (int)mv.size();
-        std::vector<int> who(nm);
+        std::vector<int> who(nm), who2;
         xmv.resize((size_t)nm * d);
+        xmv2.clear();
         for (int a = 0; a < nm; a++) {
             who[a] = idx[mv[a]];
             std::memcpy(&xmv[(size_t)a * d], &xn[(size_t)mv[a] * d], sizeof(double) * d);
+            if (!haveg[mv[a]]) {
+                who2.push_back(who[a]);
+                xmv2.insert(xmv2.end(), &xn[(size_t)mv[a] * d], &xn[(size_t)mv[a] * d] + d);
+            }
         }
-        const int rc = f_and_g(who, xmv, fnew, gnew);
-        if (rc != CARMA_OK) return rc;
+        if (!who2.empty()) {
+            const int rc = f_and_g(who2, xmv2, fnew2, gnew2);
+            if (rc != CARMA_OK) return rc;
+        }
+        fnew.resize(nm);
+        gnew.resize((size_t)nm * d);
+        for (int a = 0, a2 = 0; a < nm; a++) {
+            if (haveg[mv[a]]) {
+                fnew[a] = fn[mv[a]];
+                std::memcpy(&gnew[(size_t)a * d], &gspec[(size_t)mv[a] * d], sizeof(double) * d);
+            } else {
+                fnew[a] = fnew2[a2];
+                std::memcpy(&gnew[(size_t)a * d], &gnew2[(size_t)a2 * d], sizeof(double) * d);
+                a2++;
+            }
+        }
         for (int a = 0; a < nm; a++) {
             const int b = who[a];
             double* Sb = &S[(size_t)b * m * d];
