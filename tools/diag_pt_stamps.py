@@ -17,6 +17,8 @@ else:
     t, y, yerr = g['t'], g['y'], g['yerr']
     ctx = L0.Context(t, y, yerr, 5, 3, max_stdev=10*np.sqrt(np.mean(y*y)-np.mean(y)**2))
     T_, Rs, temps = 16, (64,), None
+    if len(sys.argv) > 2:                                     # diag_pt_stamps.py T R: e.g. 10 1, the README's run_mcmc ladder
+        T_, Rs = int(sys.argv[1]), (int(sys.argv[2]),)
 for R in Rs:
     print("--- %d temperatures x %d replicas" % (T_, R), flush=True)
     ctx.pt_create(T_, R, adapt_iters=10**9, seed=17, temperatures=temps)
