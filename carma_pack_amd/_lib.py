@@ -171,6 +171,7 @@ def _load():
     L.carma_pt_boundary_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.carma_pt_boundary_check.argtypes = [C.c_void_p]
     L.carma_pt_kernel_in_use.argtypes = [C.c_void_p]
+    L.carma_pt_row_pipeline.argtypes = []
     L.carma_pt_sweep.argtypes = [C.c_void_p]
     L.carma_pt_debug_draws.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ulonglong, _dp, _dp, _dp]
     L.carma_pt_get_factor.argtypes = [C.c_void_p, _dp]
@@ -190,7 +191,7 @@ EXPORTS = [
     "carma_pt_start", "carma_pt_set_chains", "carma_pt_get_chains", "carma_pt_iterate", "carma_pt_sample",
     "carma_pt_stats", "carma_pt_iterations_done", "carma_comm_unique_id", "carma_comm_create", "carma_comm_destroy",
     "carma_comm_rank", "carma_comm_size", "carma_pt_iterate_sharded", "carma_pt_sample_sharded", "carma_pt_boundary_stats",
-    "carma_pt_boundary_check", "carma_pt_sweep", "carma_pt_kernel_in_use", "carma_pt_debug_draws", "carma_pt_get_factor",
+    "carma_pt_boundary_check", "carma_pt_sweep", "carma_pt_kernel_in_use", "carma_pt_row_pipeline", "carma_pt_debug_draws", "carma_pt_get_factor",
     "carma_pt_set_factor", "carma_tune_set",
 ]
 
@@ -414,6 +415,11 @@ class Context:
         """"row" (k_pt_row), "ladder" (k_pt) or "lane" (k_pt_lane, large ensembles): the sampler kernel this context is on
         (carma_pt_kernel_in_use)."""
         return {1: "row", 2: "lane"}.get(lib.carma_pt_kernel_in_use(self._h), "ladder")
+
+    @staticmethod
+    def pt_row_pipeline():
+        """Recursion of the process's last k_pt_row launch: "one-datum", "window", "two-sided" (carma_pt_row_pipeline); None before it."""
+        return {0: "one-datum", 1: "window", 2: "two-sided"}.get(lib.carma_pt_row_pipeline())
 
     def pt_iterations_done(self):
         return lib.carma_pt_iterations_done(self._h)

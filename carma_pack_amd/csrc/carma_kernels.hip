@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w(const double* __restric
 // CU, two producer waves per workgroup on the SIMDs without a recursion wave and the set-up wave idle -- one producer then makes two
 // passes per chunk, and the recursion wave waits for it: 28.0 against 25.1 us per 1024 evaluations.)
 // HO: the producers' schedule hand-over (carma_pipew.h, SSCHED) -- launches of more than one workgroup per CU.
-template <int P, bool HO>
+// SL: the series in LDS (up to W2_MAX_N data); without, a longer series is read from global memory through the rows' register windows.
+template <int P, bool HO, bool SL = true>
 __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restrict__ theta, int B, int d, int q,
                                                           const double4* __restrict__ series, int n, Prior pr,
                                                           int ignore_prior, double* __restrict__ out, int ncu)
@@ -249,17 +250,19 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
     // the series into LDS (producers: carma_pipew.h, SLDS): {y, yerr^2}[n], then t[n]; visible behind the producers' first barrier
     double2* lds_yz = ring + Geo::SER_OFF;
     double* lds_t = reinterpret_cast<double*>(lds_yz + n + (n & 1));
-    for (int i = tid; i < n; i += 256) {
-        const double4 r = series[i];
-        lds_yz[i] = make_double2(r.y, r.z);
-        lds_t[i] = r.w;
+    if constexpr (SL) {
+        for (int i = tid; i < n; i += 256) {
+            const double4 r = series[i];
+            lds_yz[i] = make_double2(r.y, r.z);
+            lds_t[i] = r.w;
+        }
     }
     if (wave >= 2) {
 #if defined(CARMA_STAMPS)
-        pipew_produce<P, true, true, HO>(g, wave - 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
+        pipew_produce<P, true, SL, HO>(g, wave - 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
         CARMA_MARK_DUMP("two-sided producer: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", wave - 2);
 #else
-        pipew_produce<P, true, true, HO>(g, wave - 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
+        pipew_produce<P, true, SL, HO>(g, wave - 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
 #endif
         __syncthreads();                                      // (the set-up wave's hand-over, below)
         return;
@@ -270,10 +273,10 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
         // very end only, and in front of the pipeline they kept the first chunk waiting (the other waves were at the first barrier
         // 3.5 k cycles before this one: profiles/r06/w2_stamps_v3.txt); now they run while the recursion wave merges
 #if defined(CARMA_STAMPS)
-        pipew_produce<P, true, true, HO>(g, 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
+        pipew_produce<P, true, SL, HO>(g, 2, th, series, n, ring, [](int) {}, mark_, lds_t, lds_yz);
         CARMA_MARK_DUMP("two-sided set-up wave: barrier 1 arrival, passed, chunk 0 done, barrier passed, chunk 1 done, chunk 2 done", 2);
 #else
-        pipew_produce<P, true, true, HO>(g, 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
+        pipew_produce<P, true, SL, HO>(g, 2, th, series, n, ring, [](int) {}, nullptr, lds_t, lds_yz);
 #endif
         model_from_theta<P, 16, MODEL_FLAGS>(g, th, q, pr, ignore_prior, m);
         const double lpri = log_prior(m.scale, pr.measerr_dof);
@@ -818,7 +821,7 @@ static LdShape logdens_shape(long B, int n, int series_flags)
     const long waves = (B + EPW - 1) / EPW;
     const long rows = (B + 3) / 4;                    // workgroups with one evaluation per 16-lane DPP row
     const bool w2ok = (series_flags & SERIES_WINDOW2_OK) || ((series_flags & SERIES_WINDOW2_SMALL) && B <= 2L * device_cus());
-    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && n <= W2_MAX_N && (w2ok || win_forced()))
+    if (B <= win2_max_evals() && win_max_rows() > 0 && n >= 16 && (w2ok || win_forced()))
         return LdShape::WIN2;                         // (CARMA_TUNE_WIN_ROWS = 0: no window pipeline of either kind)
     if (rows <= win_max_rows() && n >= 8 && ((series_flags & SERIES_WINDOW_OK) || win_forced())) return LdShape::WIN;
     if (rows <= p3l_max_rows() && n >= 8) return LdShape::P3L;
@@ -863,7 +866,8 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
             return hipGetLastError();
         case LdShape::WIN2:
         {
-            const size_t lds = PipeWGeom<P>::bytes_with_series(n);
+            const bool sl = n <= W2_MAX_N;                     // (longer: from global memory, the rings alone in LDS)
+            const size_t lds = sl ? PipeWGeom<P>::bytes_with_series(n) : PipeWGeom<P>::BYTES;
             const long wgs = ((long)B + 1) / 2;
             auto go = [&](auto kern) -> hipError_t {
                 if (lds > 64 * 1024) {
@@ -873,6 +877,7 @@ static hipError_t launch_logdens_p(const double* theta, int B, int d, int q, con
                 hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, st, theta, B, d, q, series, n, pr, ignore_prior, out, device_cus());
                 return hipGetLastError();
             };
+            if (!sl) return go(&k_logdens_carma_w2<P, false, false>);
             return wgs > device_cus() ? go(&k_logdens_carma_w2<P, true>) : go(&k_logdens_carma_w2<P, false>);
         }
         case LdShape::PC1: return launch_pc(&k_logdens_carma_pc<P, G, 1>, waves, 1);

@@ -56,6 +56,7 @@ size_t pt_lds_bytes(int P, int d, int T, int* nthreads_out, int* pc_out);
 // row variant (one chain per 16-lane DPP row, ladders spread over several workgroups): number of
 // workgroups that can be resident at once for this (p, d, T), 0 if the variant does not apply
 long pt_row_capacity(int p, int d, int T, int n);
+int pt_row_last_pipeline();     // 0 / 1 / 2 as carma_pt_row_pipeline (include/carma_mi355.h); -1 before the first launch
 hipError_t launch_pt_row(int p, const PtLaunch& L, const PtRowSync& S, const double4* series, const Prior& pr,
                          const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
                          unsigned* nswap, double* samples, double* sample_lp, hipStream_t st);

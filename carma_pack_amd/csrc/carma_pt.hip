@@ -15,6 +15,7 @@
 // RAM(T-2), ...): here all RAM steps of an iteration run concurrently and the swap sweep follows.
 // Both are compositions of kernels that leave the tempered joint posterior invariant.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
 
 #include "grp_device.h"
@@ -280,7 +281,7 @@ __device__ __forceinline__ unsigned long long pt_tag(unsigned long long iter, un
 // first half of the series forward, the odd one the second half backward, and the chain wave merges the two states; two chains per
 // workgroup, a ladder over ceil(T / 2) of them.  Both rows carry the chain's state (the same values, formed twice), the even row
 // publishes it.  The series sits in LDS for the producers (copied once per launch).
-template <int P, int MINW, bool WIN = false, bool TWO = false, bool HO = false>
+template <int P, int MINW, bool WIN = false, bool TWO = false, bool HO = false, bool SL = TWO>
 __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, const double4* __restrict__ series, Prior pr,
                                                    const double* __restrict__ temps, double* __restrict__ theta,
                                                    double* __restrict__ logpost, double* __restrict__ chol,
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
     double2* lds_yz = reinterpret_cast<double2*>(reinterpret_cast<char*>(smem4) +
                                                  ((reinterpret_cast<char*>(s_tha + T * (PT_DMAX + 1)) - reinterpret_cast<char*>(smem4) + 15) & ~(ptrdiff_t)15));
     double* lds_t = reinterpret_cast<double*>(lds_yz + L.n + (L.n & 1));
-    if constexpr (TWO) {
+    // (SL: the series in LDS; without, for series the LDS does not hold, each row's window of 64 records in registers -- carma_pipew.h)
+    if constexpr (TWO && SL) {
         for (int i = tid; i < L.n; i += 256) {
             const double4 r = series[i];
             lds_yz[i] = make_double2(r.y, r.z);
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
             const uint64_t iter = L.iter0 + (uint64_t)it;
             __syncthreads();                               // proposals visible
             if constexpr (WIN)
-                pipew_produce<P, TWO, TWO, HO>(g, wave - 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
+                pipew_produce<P, TWO, TWO && SL, HO>(g, wave - 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
             else
                 pipe3l_produce<P>(g, wave - 2, thn_lds, series, L.n + npad, npad, ring, [](int) {});
             if (wave == 2) {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256, MINW) void k_pt_row(PtLaunch L, PtRowSync S, c
                 if constexpr (WIN) {
                     const double lpri = log_prior(m.scale, pr.measerr_dof);
                     if (j == 0) ringw[PipeWGeom<P>::OUT_OFF + row] = make_double2(lpri, m.valid ? 1.0 : 0.0);
-                    pipew_produce<P, TWO, TWO, HO>(g, 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
+                    pipew_produce<P, TWO, TWO && SL, HO>(g, 2, thn_lds, series, L.n, ringw, [](int) {}, nullptr, lds_t, lds_yz);
                 } else {
                 double lpri = log_prior(m.scale, pr.measerr_dof) + pipe3l_pad_correction(npad, thn_lds[0], m.scale, series[L.n - 1].y, m.mu);
                 asm volatile("" : "+v"(lpri));
@@ -619,9 +621,10 @@ static size_t pt_row_lds(int d, int T, int n_series = 0)
 }
 
 template <int P>
-static const void* pt_row_fn(int minw, bool win = false, bool two = false, bool ho = false)
+static const void* pt_row_fn(int minw, bool win = false, bool two = false, bool ho = false, bool sl = true)
 {
-    // (HO: the two-sided form's schedule hand-over, where workgroups share a CU: carma_pipew.h SSCHED)
+    // (HO: the two-sided form's schedule hand-over, where workgroups share a CU: carma_pipew.h SSCHED; !sl: the series stays in global memory)
+    if (two && minw < 3 && !sl) return reinterpret_cast<const void*>(&k_pt_row<P, 2, true, true, false, false>);
     if (two && minw < 3) return ho ? reinterpret_cast<const void*>(&k_pt_row<P, 2, true, true, true>) : reinterpret_cast<const void*>(&k_pt_row<P, 2, true, true, false>);
     if (win && minw < 3) return reinterpret_cast<const void*>(&k_pt_row<P, 2, true>);
     return minw >= 3 ? reinterpret_cast<const void*>(&k_pt_row<P, 3>) : reinterpret_cast<const void*>(&k_pt_row<P, 2>);
@@ -665,6 +668,9 @@ long pt_row_capacity(int p, int d, int T, int n)
     return (long)device_cus() * per_cu;
 }
 
+static std::atomic<int> g_row_pipeline{-1};
+int pt_row_last_pipeline() { return g_row_pipeline.load(std::memory_order_relaxed); }
+
 template <int P>
 static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const double4* series, const Prior& pr,
                                   const double* temps, double* theta, double* logpost, double* chol, unsigned* naccept,
@@ -676,10 +682,15 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     // or 2 (two-sided) overrides.
     const long grid2_global = (long)L.R * (((long)L.T_global + 1) / 2);
     const bool w2ok = (S.window_ok & SERIES_WINDOW2_OK) || ((S.window_ok & SERIES_WINDOW2_SMALL) && grid2_global <= (long)S.ncu);
-    bool two = grid2_global <= 2L * S.ncu && w2ok && L.n >= 32 && L.n <= 1024;    // (24 KiB of series: two workgroups still share a CU)
-    if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) two = ew == 2 && grid2_global <= 2L * S.ncu && L.n >= 32 && L.n <= 1024;
+    // the series sits in LDS: up to 1024 data (24 KiB) two workgroups still share a CU; longer ones -- as long as the LDS holds them
+    // (~4800 data) -- where the ladder set leaves a CU to every workgroup, e.g. the single ladder of a run_mcmc call
+    // -- and any longer series from global memory through the rows' register windows (18.5 against 17.7 us per launch of the README
+    // series: the slower way to feed the producers, and the only one there)
+    const bool sl = L.n <= 1024 || (grid2_global <= (long)S.ncu && pt_row_lds(L.d, L.T, L.n) <= 160 * 1024);
+    bool two = grid2_global <= 2L * S.ncu && w2ok && L.n >= 32;
+    if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) two = ew == 2 && grid2_global <= 2L * S.ncu && L.n >= 32;
     const int wpl = two ? (L.T + 1) / 2 : S.wpl;
-    const size_t lds = pt_row_lds(L.d, L.T, two ? L.n : 0);
+    const size_t lds = pt_row_lds(L.d, L.T, two && sl ? L.n : 0);
     const long grid = (long)L.R * wpl;
     const int minw = grid > 2L * S.ncu ? 3 : 2;             // the 168-register build only where three workgroups share a CU
     // the windowed pipeline where the WHOLE ladder's grid is at most one workgroup per CU (from T_global: a sharded ladder's blocks
@@ -688,7 +699,8 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     bool win = grid_global <= (long)S.ncu && (S.window_ok & SERIES_WINDOW_OK);       // (and the series suits it: carma_types.h)
     if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) win = ew != 0 && minw < 3;
     two = two && minw < 3;
-    const void* fn = pt_row_fn<P>(minw, win, two, grid > (long)S.ncu);
+    const void* fn = pt_row_fn<P>(minw, win, two, grid > (long)S.ncu, sl);
+    g_row_pipeline.store(two ? 2 : (win && minw < 3 ? 1 : 0), std::memory_order_relaxed);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     PtLaunch La = L;

@@ -656,6 +656,8 @@ int carma_pt_kernel_in_use(const carma_ctx* h)
     return s->use_row ? 1 : (s->use_lane ? 2 : 0);
 }
 
+int carma_pt_row_pipeline(void) { return pt_row_last_pipeline(); }
+
 long carma_pt_iterations_done(const carma_ctx* h)
 {
     if (!h || !reinterpret_cast<const Ctx*>(h)->pt) return CARMA_EINVAL;

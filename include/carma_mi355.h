@@ -260,6 +260,10 @@ long carma_pt_iterations_done(const carma_ctx* h);
  * update and the log-density differently (launch shapes of the same evaluation, 1e-8 apart at most on well-conditioned
  * states): after a fall-back the chains are STATISTICALLY equivalent to, not bit-identical with, an uninterrupted run. */
 int carma_pt_kernel_in_use(const carma_ctx* h);
+/* which recursion the LAST k_pt_row launch of this process ran on: 0 = one-datum wave pipeline, 1 = windowed pipeline (one-sided),
+ * 2 = two-sided windowed pipeline; -1 before the first such launch.  For tests and measurements: the choice (launch_pt_row_p in
+ * carma_pt.hip) depends on the whole ladder set's grid, the series (SERIES_WINDOW2_OK) and its length. */
+int carma_pt_row_pipeline(void);
 
 /*
  * ONE temperature ladder sharded across the GPUs of a node (one process per GPU): the reference has no counterpart --

@@ -172,6 +172,69 @@ def test_row_and_ladder_kernels_walk_the_same_trajectory(cpa, p, q, T, R, monkey
     np.testing.assert_array_equal(b[5], a[5])
 
 
+def test_which_series_and_ladder_sets_take_the_two_sided_row_sampler(cpa, golden_dir):
+    """launch_pt_row_p (carma_pt.hip): the two-sided window pipeline for ladder sets of at most two workgroups per CU on series that
+    suit it (SERIES_WINDOW2_OK) -- the README series, the OGLE quick-start series --, up to 1024 data; LONGER series (the LDS holds
+    ~4800 data) where every workgroup has a CU to itself, e.g. the single ladder of a run_mcmc call; the one-datum pipeline
+    otherwise.  On the long series the two pipelines walk the same trajectory, and the stored log-posteriors are the oracle's."""
+    import os
+    from helpers import assert_parity, loglik_truth
+    import oracle as orc
+    g = np.load(os.path.join(golden_dir, "carma53_readme.npz"))
+    d = np.loadtxt(os.path.join(golden_dir, "ogle_lmc_lpv_00007.dat"))
+    for (t, y, e, p, q, T, R, want) in ((g["t"], g["y"], g["yerr"], 5, 3, 10, 1, "two-sided"), (d[:, 0], d[:, 1], d[:, 2], 6, 0, 10, 1, "two-sided"),
+                                        (g["t"], g["y"], g["yerr"], 5, 3, 16, 64, "two-sided"), (g["t"], g["y"], g["yerr"], 5, 3, 16, 80, "one-datum")):
+        ctx = cpa.Context(t, y, e, p, q)
+        ctx.pt_create(T, R, adapt_iters=50, seed=3)
+        ctx.pt_start(None)
+        ctx.pt_iterate(5)
+        assert ctx.pt_kernel() == "row" and ctx.pt_row_pipeline() == want, (p, q, T, R, ctx.pt_row_pipeline())
+    # n = 3000: in LDS with a CU per workgroup only; n = 6000: from global memory (the rows' register windows) at any grid of the form
+    for n in (3000, 6000):
+        rng = np.random.default_rng(12)
+        t = np.cumsum(0.6 + 0.8 * rng.random(n))
+        yv = np.cumsum(rng.normal(0.0, 0.3, n))
+        yv = yv - np.linspace(yv[0], yv[-1], n) + rng.normal(0.0, 0.1, n)
+        e = np.full(n, 0.1)
+        p, q, T = 3, 1, 10
+        res = {}
+        for form, sw in (("two-sided", None), ("one-datum", 0)):
+            cpa._lib.tune_reset()
+            if sw is not None:
+                cpa._lib.tune_set("PT_ROW_WIN", sw)
+            ctx = cpa.Context(t, yv, e, p, q)
+            ctx.pt_create(T, 1, adapt_iters=40, seed=21)
+            ctx.pt_start(None)
+            ctx.pt_iterate(40)
+            assert ctx.pt_kernel() == "row" and ctx.pt_row_pipeline() == form, ctx.pt_row_pipeline()
+            res[form] = ctx.pt_get_chains()
+            if form == "two-sided":
+                c2 = cpa.Context(t, yv, e, p, q)
+                c2.pt_create(T, 80, adapt_iters=40, seed=21)          # 400 workgroups in the two-sided form: two on some CUs
+                c2.pt_start(None)
+                c2.pt_iterate(3)
+                assert c2.pt_row_pipeline() == "two-sided"              # (the series from global memory)
+                c3 = cpa.Context(t, yv, e, p, q)
+                c3.pt_create(T, 200, adapt_iters=40, seed=21)         # 1000 workgroups: beyond two per CU
+                c3.pt_start(None)
+                c3.pt_iterate(3)
+                assert c3.pt_row_pipeline() == "one-datum"
+        cpa._lib.tune_reset()
+        th2, lp2 = res["two-sided"]
+        th1, lp1 = res["one-datum"]
+        np.testing.assert_allclose(th2, th1, rtol=1e-6, atol=1e-9)
+        m = orc.OracleModel(t, yv, e, p, q, max_stdev=ctx.prior()[0])
+        th = th2.reshape(-1, th2.shape[-1])
+        want = m.logdensity_batch(th)
+        assert_parity(lp2.reshape(-1), want, 1e-10, "two-sided row sampler, n = %d" % n,
+                      arbiter=lambda k: loglik_truth(t, yv, e, th[k], p, q)[0], arb_factor=1.25, max_arb_frac=0.2)
+        # the batched launch on the same series: two-sided at every size it is given (n > 5000: from global memory)
+        assert ctx.kernel_name(64) == ctx.kernel_name(1536) == "k_logdens_carma_w2<%d>" % p
+        got = ctx.logdensity(th)
+        assert_parity(got, want, 1e-10, "two-sided log-density launch, n = %d" % n, arbiter=lambda k: loglik_truth(t, yv, e, th[k], p, q)[0],
+                      arb_factor=1.25, max_arb_frac=0.2)
+
+
 @pytest.mark.parametrize("p,q,T,R", [(2, 1, 3, 2), (3, 0, 6, 3), (5, 3, 10, 2), (7, 6, 5, 1), (3, 1, 1, 5), (4, 2, 17, 2),
                                      (2, 0, 33, 1), (3, 2, 64, 1), (5, 3, 16, 9), (6, 2, 7, 40), (5, 0, 16, 130),
                                      (1, 0, 8, 5), (1, 0, 16, 64)])
