@@ -472,6 +472,22 @@ int carma_pt_bind_state(carma_ctx* h, double* d_theta, double* d_logpost)
     return CARMA_OK;
 }
 
+// Log-posteriors of chain states (starting values, carma_pt_set_chains without them) in launches of at most START_BATCH evaluations:
+// which kernel a launch takes depends on its size (and, for the two-sided kernels on series of the SMALL class, on whether it leaves
+// a CU to every workgroup), and a block of a sharded ladder or a rank's share of the replicas holds fewer chains than the
+// single-process run -- its log-posteriors would come from another launch shape, a rounding apart, and the chains would no longer be
+// the one-GPU run's bit for bit.  Below this size the choice does not depend on the count.
+static int logdensity_of_chain_states(carma_ctx* h, const double* theta, size_t n, int d, double* out)
+{
+    constexpr size_t START_BATCH = 256;
+    for (size_t i0 = 0; i0 < n; i0 += START_BATCH) {
+        const size_t nb = std::min(START_BATCH, n - i0);
+        const int rc = carma_logdensity_batch(h, theta + i0 * d, (int)nb, 0, out + i0);
+        if (rc != CARMA_OK) return rc;
+    }
+    return CARMA_OK;
+}
+
 int carma_pt_set_chains(carma_ctx* h, const double* theta, const double* logpost)
 {
     if (!h || !reinterpret_cast<Ctx*>(h)->pt || !theta) return CARMA_EINVAL;
@@ -482,7 +498,7 @@ int carma_pt_set_chains(carma_ctx* h, const double* theta, const double* logpost
     if (logpost) {
         std::memcpy(lp.data(), logpost, sizeof(double) * nchain);
     } else {
-        int rc = carma_logdensity_batch(h, theta, (int)nchain, 0, lp.data());
+        int rc = logdensity_of_chain_states(h, theta, nchain, c->d, lp.data());
         if (rc != CARMA_OK) return rc;
     }
     hipError_t e = hipMemcpy(s->d_theta, theta, sizeof(double) * nchain * c->d, hipMemcpyHostToDevice);
@@ -557,7 +573,7 @@ int carma_pt_start(carma_ctx* h, const double* init, int ninit)
             std::mt19937_64 rng = chain_rng(todo[i], round);
             draw_start(c, rng, &cand[i * d]);
         }
-        int rc = carma_logdensity_batch(h, cand.data(), (int)todo.size(), 0, out.data());
+        int rc = logdensity_of_chain_states(h, cand.data(), todo.size(), d, out.data());
         if (rc != CARMA_OK) return rc;
         for (size_t i = 0; i < todo.size(); i++) {
             if (std::isfinite(out[i])) {
