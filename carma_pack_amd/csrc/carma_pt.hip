@@ -686,7 +686,8 @@ static hipError_t launch_pt_row_p(const PtLaunch& L, const PtRowSync& S, const d
     // (~4800 data) -- where the ladder set leaves a CU to every workgroup, e.g. the single ladder of a run_mcmc call
     // -- and any longer series from global memory through the rows' register windows (18.5 against 17.7 us per launch of the README
     // series: the slower way to feed the producers, and the only one there)
-    const bool sl = L.n <= 1024 || (grid2_global <= (long)S.ncu && pt_row_lds(L.d, L.T, L.n) <= 160 * 1024);
+    // (from T_global, like every other choice here: a block of a sharded ladder holds fewer temperatures and would fit more)
+    const bool sl = L.n <= 1024 || (grid2_global <= (long)S.ncu && pt_row_lds(L.d, (int)L.T_global, L.n) <= 160 * 1024);
     bool two = grid2_global <= 2L * S.ncu && w2ok && L.n >= 32;
     if (const long ew = tune_get(TUNE_PT_ROW_WIN); ew != TUNE_UNSET) two = ew == 2 && grid2_global <= 2L * S.ncu && L.n >= 32;
     const int wpl = two ? (L.T + 1) / 2 : S.wpl;

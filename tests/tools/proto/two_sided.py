@@ -122,10 +122,14 @@ LEVELS = (4e-3, 4e-6, 4e-9, 4e-12, 4e-15)
 
 
 def lane_merge_chol(Da, a, Db, beta, stats=None):
-    """merge_chol as pipew_merge lays it out: lane j holds column j of the Schur complement and, once it has been taken, column j
-    of L.  THRESHOLD PIVOTING: the coordinates are taken in their own order, but only those whose remaining diagonal is above the
-    level's threshold; the others wait for a later level.  A pivot is then within 1e3 of everything taken after it (the guarantee
-    of diagonal pivoting up to that factor) and every broadcast comes from a lane known in advance."""
+    """merge_chol in pipew_merge's lane layout: lane j holds column j of the Schur complement and, once it has been taken, column j
+    of L.  THIS function pivots by THRESHOLD LEVELS: the coordinates are taken in their own order, but only those whose remaining
+    diagonal is above the level's threshold; the others wait for a later level.  A pivot is then within 1e3 of everything taken
+    after it (the guarantee of diagonal pivoting up to that factor) and every broadcast comes from a lane known in advance.  The
+    device tried this form (robust, but 3.6 k cycles for the loop against 2.6 k: profiles/r06/merge_variants_v1.txt) and kept plain
+    DIAGONAL pivoting -- the largest remaining diagonal by a DPP maximum, its column by ds_bpermute, same equilibration, same rank
+    threshold (4e-15) -- which is chol_psd / merge_chol above; this emulation stays as the record of the variant and as a second
+    route to the same numbers in tests/test_two_sided_proto.py."""
     P = a.size
     A = np.array([[-(Da[i, j] if i >= j else Da[j, i]) for i in range(P)] for j in range(P)])      # A[j][i] = X_ij, lane j
     kf = np.array([[Db[i, j] for i in range(P)] for j in range(P)])
