@@ -323,17 +323,8 @@ __global__ __launch_bounds__(256) void k_logdens_carma_w2(const double* __restri
 // Throughput regime proper (tens of thousands of evaluations): ONE EVALUATION PER LANE (carma_lane.h) -- nothing crosses
 // lanes, all 64 lanes work; a wave per 64 evaluations.
 // REPDT (here and below): the variant for series with repeated time steps (carma_lane.h, lane_filter)
-// Three waves per SIMD where the registers allow it without spilling to speak of: with the polynomial constants in scalar registers
-// (carma_math.h, fma3k) p = 5 fits 168 VGPRs with 64 bytes of scratch (208 before: two waves per SIMD) -- 2.60 -> 2.52 ms per 2^20
-// evaluations, 707 -> 678 us per 262 144, nothing lost at 65 536, where a SIMD holds one wave anyway (profiles/r06/ab_sconst_lane_v1.txt).
-// p <= 4 is there on its own (129-152 VGPRs); p = 6, 7 would spill 240-750 bytes and stay as they are.
-#if defined(CARMA_LANE_NO_WPE)
-#define CARMA_LANE_ATTR(P)
-#else
-#define CARMA_LANE_ATTR(P) __attribute__((amdgpu_waves_per_eu((P) == 5 ? 3 : 1)))
-#endif
 template <int P, bool REPDT = false>
-__global__ __launch_bounds__(64) CARMA_LANE_ATTR(P) void k_logdens_carma_lane(const double* __restrict__ theta, int B, int d, int q,
+__global__ __launch_bounds__(64) void k_logdens_carma_lane(const double* __restrict__ theta, int B, int d, int q,
                                                           const double4* __restrict__ series, int n, Prior pr,
                                                           int ignore_prior, double* __restrict__ out)
 {

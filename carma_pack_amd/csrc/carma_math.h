@@ -27,27 +27,6 @@ CARMA_DEV double fma3(double a, double b, double c)
 #else
 static inline double fma3(double a, double b, double c) { return fma(a, b, c); }
 #endif
-// ... with a wave-uniform CONSTANT as the addend (fma3k) or as the second factor (fma3m) taken from a scalar register: a VOP3
-// instruction reads one, and the constant then costs neither a vector register nor -- when the compiler re-materialises it inside
-// a loop for want of registers -- a v_mov_b64 per use (ten per step of the one-evaluation-per-lane kernel).  Same operation, same bits:
-// 22.0 -> 21.4 us per 1024 evaluations (the producers), 2.60 -> 2.55-2.59 ms per 2^20 (profiles/r06/ab_sconst_v1.txt, ab_sconst_lane_v1.txt).
-#if defined(__HIPCC__) && !defined(CARMA_FMA_VCONST)        // (the switch: A/B builds, profiles/r06/ab_sconst_v1.txt)
-CARMA_DEV double fma3k(double a, double b, double c)
-{
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
-}
-CARMA_DEV double fma3m(double a, double b, double c)
-{
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-    return r;
-}
-#else
-CARMA_DEV double fma3k(double a, double b, double c) { return fma3(a, b, c); }
-CARMA_DEV double fma3m(double a, double b, double c) { return fma3(a, b, c); }
-#endif
 
 CARMA_DEV double exp_neg(double x)
 {
@@ -55,23 +34,23 @@ CARMA_DEV double exp_neg(double x)
     const double LN2_HI = 6.93147180369123816490e-01;   // 33 significant bits
     const double LN2_LO = 1.90821492927058770002e-10;
     double n = rint(x * LOG2E);
-    double r = fma3m(-n, LN2_HI, x);
-    r = fma3m(-n, LN2_LO, r);
+    double r = fma3(-n, LN2_HI, x);
+    r = fma3(-n, LN2_LO, r);
     // exp(r), |r| <= ln2/2: Taylor to r^13 (truncation 4e-18)
     double p = 1.0 / 6227020800.0;
-    p = fma3k(p, r, 1.0 / 479001600.0);
-    p = fma3k(p, r, 1.0 / 39916800.0);
-    p = fma3k(p, r, 1.0 / 3628800.0);
-    p = fma3k(p, r, 1.0 / 362880.0);
-    p = fma3k(p, r, 1.0 / 40320.0);
-    p = fma3k(p, r, 1.0 / 5040.0);
-    p = fma3k(p, r, 1.0 / 720.0);
-    p = fma3k(p, r, 1.0 / 120.0);
-    p = fma3k(p, r, 1.0 / 24.0);
-    p = fma3k(p, r, 1.0 / 6.0);
-    p = fma3k(p, r, 0.5);
-    p = fma3k(p, r, 1.0);
-    p = fma3k(p, r, 1.0);
+    p = fma3(p, r, 1.0 / 479001600.0);
+    p = fma3(p, r, 1.0 / 39916800.0);
+    p = fma3(p, r, 1.0 / 3628800.0);
+    p = fma3(p, r, 1.0 / 362880.0);
+    p = fma3(p, r, 1.0 / 40320.0);
+    p = fma3(p, r, 1.0 / 5040.0);
+    p = fma3(p, r, 1.0 / 720.0);
+    p = fma3(p, r, 1.0 / 120.0);
+    p = fma3(p, r, 1.0 / 24.0);
+    p = fma3(p, r, 1.0 / 6.0);
+    p = fma3(p, r, 0.5);
+    p = fma3(p, r, 1.0);
+    p = fma3(p, r, 1.0);
     // n is integral; beyond +-2000 the result has long over/underflowed, clamp so the int
     // conversion is well defined
     double nc = fmin(fmax(n, -2200.0), 2200.0);
@@ -87,29 +66,29 @@ CARMA_DEV void sincos_cw(double x, double* s_out, double* c_out)
     const double PIO2_3 = 2.02226624871116645580e-21;    // next 33 bits
     const double PIO2_3T = 8.47842766036889956997e-32;   // tail
     double n = rint(x * TWO_OVER_PI);
-    double r = fma3m(-n, PIO2_1, x);
-    r = fma3m(-n, PIO2_2, r);
-    r = fma3m(-n, PIO2_3, r);
-    r = fma3m(-n, PIO2_3T, r);
+    double r = fma3(-n, PIO2_1, x);
+    r = fma3(-n, PIO2_2, r);
+    r = fma3(-n, PIO2_3, r);
+    r = fma3(-n, PIO2_3T, r);
     const int q = (int)n;
     const double z = r * r;
     // sin(r) = r + r^3 (S1 + z (S2 + ... ))
     double ps = 1.58969099521155010221e-10;
-    ps = fma3k(ps, z, -2.50507602534068634195e-08);
-    ps = fma3k(ps, z, 2.75573137070700676789e-06);
-    ps = fma3k(ps, z, -1.98412698298579493134e-04);
-    ps = fma3k(ps, z, 8.33333333332248946124e-03);
-    ps = fma3k(ps, z, -1.66666666666666324348e-01);
+    ps = fma3(ps, z, -2.50507602534068634195e-08);
+    ps = fma3(ps, z, 2.75573137070700676789e-06);
+    ps = fma3(ps, z, -1.98412698298579493134e-04);
+    ps = fma3(ps, z, 8.33333333332248946124e-03);
+    ps = fma3(ps, z, -1.66666666666666324348e-01);
     const double sn = fma3(z * r, ps, r);
     // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
     double pc = -1.13596475577881948265e-11;
-    pc = fma3k(pc, z, 2.08757232129817482790e-09);
-    pc = fma3k(pc, z, -2.75573143513906633035e-07);
-    pc = fma3k(pc, z, 2.48015872894767294178e-05);
-    pc = fma3k(pc, z, -1.38888888888741095749e-03);
-    pc = fma3k(pc, z, 4.16666666666666019037e-02);
-    pc = fma3k(pc, z, -0.5);
-    const double cs = fma3k(pc, z, 1.0);
+    pc = fma3(pc, z, 2.08757232129817482790e-09);
+    pc = fma3(pc, z, -2.75573143513906633035e-07);
+    pc = fma3(pc, z, 2.48015872894767294178e-05);
+    pc = fma3(pc, z, -1.38888888888741095749e-03);
+    pc = fma3(pc, z, 4.16666666666666019037e-02);
+    pc = fma3(pc, z, -0.5);
+    const double cs = fma3(pc, z, 1.0);
     // quadrant
     const bool swap = q & 1;
     double so = swap ? cs : sn;
@@ -181,33 +160,33 @@ CARMA_DEV void cexp_step_impl(double a, double b, double dt, double* re, double*
     double po = 1.0 / 6227020800.0;         // r^13
     double ps = 1.58969099521155010221e-10;
     double pc = -1.13596475577881948265e-11;
-    pe = fma3k(pe, r2, 1.0 / 3628800.0);
-    po = fma3k(po, r2, 1.0 / 39916800.0);
-    ps = fma3k(ps, z, -2.50507602534068634195e-08);
-    pc = fma3k(pc, z, 2.08757232129817482790e-09);
-    pe = fma3k(pe, r2, 1.0 / 40320.0);
-    po = fma3k(po, r2, 1.0 / 362880.0);
-    ps = fma3k(ps, z, 2.75573137070700676789e-06);
-    pc = fma3k(pc, z, -2.75573143513906633035e-07);
-    pe = fma3k(pe, r2, 1.0 / 720.0);
-    po = fma3k(po, r2, 1.0 / 5040.0);
-    ps = fma3k(ps, z, -1.98412698298579493134e-04);
-    pc = fma3k(pc, z, 2.48015872894767294178e-05);
-    pe = fma3k(pe, r2, 1.0 / 24.0);
-    po = fma3k(po, r2, 1.0 / 120.0);
-    ps = fma3k(ps, z, 8.33333333332248946124e-03);
-    pc = fma3k(pc, z, -1.38888888888741095749e-03);
-    pe = fma3k(pe, r2, 0.5);
-    po = fma3k(po, r2, 1.0 / 6.0);
-    ps = fma3k(ps, z, -1.66666666666666324348e-01);
-    pc = fma3k(pc, z, 4.16666666666666019037e-02);
-    pe = fma3k(pe, r2, 1.0);
-    po = fma3k(po, r2, 1.0);
+    pe = fma3(pe, r2, 1.0 / 3628800.0);
+    po = fma3(po, r2, 1.0 / 39916800.0);
+    ps = fma3(ps, z, -2.50507602534068634195e-08);
+    pc = fma3(pc, z, 2.08757232129817482790e-09);
+    pe = fma3(pe, r2, 1.0 / 40320.0);
+    po = fma3(po, r2, 1.0 / 362880.0);
+    ps = fma3(ps, z, 2.75573137070700676789e-06);
+    pc = fma3(pc, z, -2.75573143513906633035e-07);
+    pe = fma3(pe, r2, 1.0 / 720.0);
+    po = fma3(po, r2, 1.0 / 5040.0);
+    ps = fma3(ps, z, -1.98412698298579493134e-04);
+    pc = fma3(pc, z, 2.48015872894767294178e-05);
+    pe = fma3(pe, r2, 1.0 / 24.0);
+    po = fma3(po, r2, 1.0 / 120.0);
+    ps = fma3(ps, z, 8.33333333332248946124e-03);
+    pc = fma3(pc, z, -1.38888888888741095749e-03);
+    pe = fma3(pe, r2, 0.5);
+    po = fma3(po, r2, 1.0 / 6.0);
+    ps = fma3(ps, z, -1.66666666666666324348e-01);
+    pc = fma3(pc, z, 4.16666666666666019037e-02);
+    pe = fma3(pe, r2, 1.0);
+    po = fma3(po, r2, 1.0);
     const double tz = t * z;
-    pc = fma3k(pc, z, -0.5);
+    pc = fma3(pc, z, -0.5);
     const double ep = fma3(po, r, pe);
     const double sn = fma3(tz, ps, t);
-    const double cs = fma3k(pc, z, 1.0);
+    const double cs = fma3(pc, z, 1.0);
     const double nc = fmin(fmax(n1, -2200.0), 2200.0);
     const double e = ldexp(ep, (int)nc);
     // --- quadrant
@@ -237,18 +216,18 @@ CARMA_DEV double exp_neg_tab(double x, const double* tab)
     // the throughput kernels' instruction stream (8.29e7 -> 8.65e7 VALU instructions per 65 536-evaluation launch, measured in
     // round 5) -- not taken: such an evaluation returns NaN, which every caller treats as a failed evaluation.)
     const double n = rint(x * INV_LN2_32);
-    double r = fma3m(-n, LN2_32_HI, x);
-    r = fma3m(-n, LN2_32_LO, r);
+    double r = fma3(-n, LN2_32_HI, x);
+    r = fma3(-n, LN2_32_LO, r);
     // n is integral; beyond +-2200 * 32 the result has long over/underflowed, clamp so the int conversion is well defined
     const int i = (int)fmin(fmax(n, -70400.0), 70400.0);
     const double e = tab[i & 31];
     // exp(r) - 1 = r q(r): the table entry enters as e + e (r q), so its rounding is the only half-ulp that is not scaled down
     double q = 1.0 / 720.0;
-    q = fma3k(q, r, 1.0 / 120.0);
-    q = fma3k(q, r, 1.0 / 24.0);
-    q = fma3k(q, r, 1.0 / 6.0);
-    q = fma3k(q, r, 0.5);
-    q = fma3k(q, r, 1.0);
+    q = fma3(q, r, 1.0 / 120.0);
+    q = fma3(q, r, 1.0 / 24.0);
+    q = fma3(q, r, 1.0 / 6.0);
+    q = fma3(q, r, 0.5);
+    q = fma3(q, r, 1.0);
     return ldexp(fma3(e, q * r, e), i >> 5);
 }
 
@@ -278,11 +257,11 @@ CARMA_DEV void cexp_step_tab_impl(double a, double b, double dt, double* re, dou
     }
     const double n1 = rint(x * INV_LN2_32);
     const double n2 = rint(ph * INV_PI_32);
-    double r = fma3m(-n1, LN2_32_HI, x);
-    double t = fma3m(-n2, PI_32_1, ph);
-    r = fma3m(-n1, LN2_32_LO, r);
-    t = fma3m(-n2, PI_32_2, t);
-    t = fma3m(-n2, PI_32_3, t);
+    double r = fma3(-n1, LN2_32_HI, x);
+    double t = fma3(-n2, PI_32_1, ph);
+    r = fma3(-n1, LN2_32_LO, r);
+    t = fma3(-n2, PI_32_2, t);
+    t = fma3(-n2, PI_32_3, t);
     if constexpr (EXACT) {
         r += fma3(a, dt, -x);
         t += fma3(b, dt, -ph);
@@ -296,19 +275,19 @@ CARMA_DEV void cexp_step_tab_impl(double a, double b, double dt, double* re, dou
     double pe = 1.0 / 720.0;
     double ps = 1.0 / 362880.0;
     double pc = 1.0 / 40320.0;
-    pe = fma3k(pe, r, 1.0 / 120.0);
-    ps = fma3k(ps, z, -1.0 / 5040.0);
-    pc = fma3k(pc, z, -1.0 / 720.0);
-    pe = fma3k(pe, r, 1.0 / 24.0);
-    ps = fma3k(ps, z, 1.0 / 120.0);
-    pc = fma3k(pc, z, 1.0 / 24.0);
-    pe = fma3k(pe, r, 1.0 / 6.0);
-    ps = fma3k(ps, z, -1.0 / 6.0);
-    pc = fma3k(pc, z, -0.5);
-    pe = fma3k(pe, r, 0.5);
+    pe = fma3(pe, r, 1.0 / 120.0);
+    ps = fma3(ps, z, -1.0 / 5040.0);
+    pc = fma3(pc, z, -1.0 / 720.0);
+    pe = fma3(pe, r, 1.0 / 24.0);
+    ps = fma3(ps, z, 1.0 / 120.0);
+    pc = fma3(pc, z, 1.0 / 24.0);
+    pe = fma3(pe, r, 1.0 / 6.0);
+    ps = fma3(ps, z, -1.0 / 6.0);
+    pc = fma3(pc, z, -0.5);
+    pe = fma3(pe, r, 0.5);
     const double tz = t * z;
     const double cm = pc * z;                                // cos t - 1
-    pe = fma3k(pe, r, 1.0);
+    pe = fma3(pe, r, 1.0);
     const double st = fma3(tz, ps, t);                       // sin t
     const double e = ldexp(fma3(e0, pe * r, e0), i1 >> 5);
     const double sn = fma3(sa, cm, ca * st) + sa;            // sin(k pi / 32 + t) = sa + (sa (cos t - 1) + ca sin t)
