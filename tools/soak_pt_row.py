@@ -12,7 +12,11 @@ from helpers import assert_parity_states, irregular_series, loglik_truth
 niter = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 fails = 0
 for (p, q, T, R, n) in ((5, 3, 16, 64, 270), (5, 3, 16, 128, 270), (5, 3, 16, 192, 150), (5, 3, 10, 100, 200), (7, 6, 8, 128, 400),
-                        (3, 1, 33, 20, 120), (2, 1, 70, 8, 100), (4, 2, 4, 300, 150), (6, 5, 12, 63, 180), (2, 0, 16, 192, 90)):
+                        (3, 1, 33, 20, 120), (2, 1, 70, 8, 100), (4, 2, 4, 300, 150), (6, 5, 12, 63, 180), (2, 0, 16, 192, 90),
+                        # round 6: shapes of the two-sided form -- a single ladder (a run_mcmc call), odd ladder lengths (the last row
+                        # pair of a ladder idle), one and two workgroups per CU, a series in LDS beyond 1024 data and one from global memory
+                        (5, 3, 10, 1, 270), (6, 0, 10, 1, 437), (7, 6, 5, 100, 330), (3, 1, 7, 70, 210), (2, 0, 3, 250, 160), (4, 3, 16, 20, 500),
+                        (3, 1, 10, 1, 3000), (5, 2, 9, 2, 6000)):
     t, y, yerr = irregular_series(n, seed=11 * p + q)
     ctx = cpa.Context(t, y, yerr, p, q)
     ctx.pt_create(T, R, adapt_iters=niter // 2, seed=1000 + T)
@@ -51,6 +55,6 @@ for (p, q, T, R, n) in ((5, 3, 16, 64, 270), (5, 3, 16, 128, 270), (5, 3, 16, 19
     still = ctx.pt_kernel()
     good = ok and still == k0 == "row" and (T == 1 or swp[:, 1:].mean() > 0.01) and acc.mean() > 0.02
     fails += not good
-    print("CARMA(%d,%d) T=%2d R=%3d n=%3d: %s -> %s, %d iterations in %.2f s (%.0f it/s), accept %.2f swap %.2f  %s" % (
-        p, q, T, R, n, k0, still, niter, dt, niter / dt, acc.mean(), swp[:, 1:].mean() if T > 1 else 0.0, "ok" if good else "FAILED"), flush=True)
+    print("CARMA(%d,%d) T=%2d R=%3d n=%4d: %s -> %s (%s), %d iterations in %.2f s (%.0f it/s), accept %.2f swap %.2f  %s" % (
+        p, q, T, R, n, k0, still, ctx.pt_row_pipeline(), niter, dt, niter / dt, acc.mean(), swp[:, 1:].mean() if T > 1 else 0.0, "ok" if good else "FAILED"), flush=True)
 print("soak:", "all shapes ok" if fails == 0 else "%d shapes FAILED" % fails)
