@@ -129,7 +129,7 @@ def parity_census(got, want, thetas, p, labels, bounds, arbiter, rtol=1e-10, wha
     Every such entry is arbitrated against the quad-precision value (the device must be within rtol of it, or no further from
     it than arb_factor x the oracle's own distance: sampler states with cond(EigenMat) ~ 1e5 exist on which BOTH
     double-precision recursions end up 2e-10 from the exact value, 2.11e-10 against 1.96e-10 measured: a ratio of 1.08, the
-    largest any run has used -- profiles/r05/parity_allowances_v1.json), and the census is printed: per class the count, the fraction, the worst difference, and cond(EigenMat)
+    largest any run has used -- profiles/r05/parity_allowances.json), and the census is printed: per class the count, the fraction, the worst difference, and cond(EigenMat)
     of the entries beyond rtol against the rest -- the entries beyond rtol are the ill-conditioned ones, on which the
     reference's own LU is rtol ... 1e-3 away from the exact value of its formulas."""
     got, want, labels = np.asarray(got, dtype=float), np.asarray(want, dtype=float), np.asarray(labels)
